@@ -1,0 +1,74 @@
+"""ctypes binding of libadvstep.so (include/advstep.h).  Fails loudly when the library is missing."""
+from __future__ import annotations
+
+import ctypes
+from pathlib import Path
+
+_LIB_PATH = Path(__file__).resolve().parent / "libadvstep.so"
+_lib = None
+
+OK, EINVAL, EWORKSPACE, ELAUNCH, ENODEVICE = 0, 1, 2, 3, 4
+ABI_VERSION = 1
+
+_p, _i64, _f32, _f64, _u64, _sz = (ctypes.c_void_p, ctypes.c_int64, ctypes.c_float, ctypes.c_double,
+                                   ctypes.c_uint64, ctypes.c_size_t)
+
+# name -> (restype, argtypes); one entry per symbol declared in include/advstep.h
+SIGNATURES = {
+    "advstep_abi_version": (ctypes.c_int, []),
+    "advstep_status_string": (ctypes.c_char_p, [ctypes.c_int]),
+    "advstep_device_count": (ctypes.c_int, []),
+    "advstep_row_workspace_bytes": (_sz, [_i64, _i64]),
+    "advstep_minmax_normalize_f32": (ctypes.c_int, [_p, _p, _p, _p, _i64, _i64, _p, _sz, _p]),
+    "advstep_minmax_revert_f32": (ctypes.c_int, [_p, _p, _p, _p, _i64, _i64, _p]),
+    "advstep_fgsm_step_f32": (ctypes.c_int, [_p, _p, _p, _i64, _f32, _f32, _f32, _p]),
+    "advstep_pgd_linf_init_noise_f32": (ctypes.c_int, [_p, _p, _p, _i64, _f32, _f32, _p]),
+    "advstep_pgd_linf_init_philox_f32": (ctypes.c_int, [_p, _p, _i64, _f32, _f32, _f32, _u64, _u64, _p]),
+    "advstep_pgd_linf_step_f32": (ctypes.c_int, [_p, _p, _p, _p, _i64, _f32, _f32, _f32, _f32, _p]),
+    "advstep_pgd_l2_init_noise_f32": (ctypes.c_int, [_p, _p, _p, _p, _i64, _i64, _f32, _f32, _f32, _p, _sz, _p]),
+    "advstep_pgd_l2_init_philox_f32": (ctypes.c_int, [_p, _p, _i64, _i64, _f32, _f32, _f32, _u64, _u64, _p, _sz, _p]),
+    "advstep_pgd_l2_step_f32": (ctypes.c_int, [_p, _p, _p, _p, _i64, _i64, _f32, _f32, _f32, _f32, _f32, _p, _p,
+                                               _p, _sz, _p]),
+    "advstep_cw_init_w_f32": (ctypes.c_int, [_p, _p, _i64, _p]),
+    "advstep_cw_tanh_sqdist_f32": (ctypes.c_int, [_p, _p, _p, _p, _i64, _i64, _p, _sz, _p]),
+    "advstep_cw_adam_step_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _i64, _f64, _f64, _f64, _f64, _p]),
+    "advstep_cw_best_update_f32": (ctypes.c_int, [_p, _p, _p, _i64, _i64, _p]),
+    "advstep_ce2_loss_grad_f32": (ctypes.c_int, [_p, _p, _p, _p, _i64, _f32, _p]),
+}
+
+
+class AdvstepError(RuntimeError):
+    """A libadvstep.so entry point returned a non-zero status."""
+
+
+def library_path() -> Path:
+    return _LIB_PATH
+
+
+def load() -> ctypes.CDLL:
+    """Load libadvstep.so and bind every symbol of the header.  No fallback: a missing library is an error."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not _LIB_PATH.exists():
+        raise AdvstepError(
+            f"{_LIB_PATH} is missing: the HIP extension has not been built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (or "
+            "`python -m audio_deepfake_adversarial_attacks_amd.build`) from the repository root. "
+            "There is no CPU fallback for the attack kernels.")
+    lib = ctypes.CDLL(str(_LIB_PATH))
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = restype
+        fn.argtypes = argtypes
+    got = lib.advstep_abi_version()
+    if got != ABI_VERSION:
+        raise AdvstepError(f"libadvstep.so ABI version {got} != binding version {ABI_VERSION}; rebuild the library")
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str) -> None:
+    if status != OK:
+        msg = load().advstep_status_string(status).decode()
+        raise AdvstepError(f"{what}: {msg} (status {status})")

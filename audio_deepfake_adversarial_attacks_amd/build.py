@@ -1,0 +1,34 @@
+"""Compile csrc/advstep.hip into libadvstep.so for gfx950 (hipcc cross-compiles without a GPU)."""
+from __future__ import annotations
+
+import shutil
+import subprocess
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+ROOT = PKG.parent
+SRC = PKG / "csrc" / "advstep.hip"
+HDR = ROOT / "include" / "advstep.h"
+LIB = PKG / "libadvstep.so"
+
+# -ffp-contract=off: the kernels must round exactly like the reference's one-ATen-op-per-expression chains
+# (bit-exactness rules); f32 division/sqrt stay IEEE (hipcc default).
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    newest_src = max(SRC.stat().st_mtime, HDR.stat().st_mtime)
+    if not force and LIB.exists() and LIB.stat().st_mtime >= newest_src:
+        return LIB
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    cmd = [hipcc, *HIPCC_FLAGS, f"-I{ROOT / 'include'}", str(SRC), "-o", str(LIB)]
+    if verbose:
+        print(" ".join(cmd))
+    proc = subprocess.run(cmd, capture_output=True, text=True)
+    if proc.returncode != 0:
+        raise RuntimeError(f"hipcc failed ({proc.returncode}):\n{proc.stdout}\n{proc.stderr}")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

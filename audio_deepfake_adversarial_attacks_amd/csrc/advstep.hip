@@ -1,0 +1,1041 @@
+// advstep.hip — gfx950 (MI355X / CDNA4) kernels + the C ABI declared in include/advstep.h.
+//
+// Every kernel here is HBM-bound streaming or row-reduction work over (B, T) float32 waveforms:
+//   * 16 B per lane (float4) coalesced loads, 4 independent float4 per input stream per thread in flight
+//     (a wave64 instruction moves 1 KiB; a 256-thread workgroup owns one 16 KiB tile per stream);
+//   * row reductions: wave64 xor-shuffles -> 4-entry LDS -> one partial per (row, tile) in the caller's
+//     workspace -> re-reduced by every workgroup of the row in the consuming pass (fixed order, no float
+//     atomics: run-to-run deterministic);
+//   * the (row, tile) -> workgroup id map is identical in the producing and consuming pass of a row
+//     operation, so with the observed id % 8 -> XCD placement a tile is re-read on the XCD whose L2 saw it;
+//   * arithmetic follows the reference expression by expression (see include/advstep.h): this file is built
+//     with -ffp-contract=off, divisions are IEEE (hipcc default for f32), clamps propagate NaN.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared (see build.py).
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "advstep.h"
+
+namespace {
+
+constexpr int kBlock = 256;                        // 4 wave64 per workgroup
+constexpr int kVecs = 4;                           // float4 per thread per stream
+constexpr int kTileVec = kBlock * kVecs;           // 1024 float4 per workgroup tile
+constexpr int kTile = kTileVec * 4;                // 4096 floats (16 KiB) per stream per tile
+constexpr int kMaxGrid = 256 * 16;                 // flat kernels: grid-stride beyond 16 tiles per CU
+
+// ---------------------------------------------------------------------------------------------------------
+// scalar semantics shared by all kernels
+// ---------------------------------------------------------------------------------------------------------
+
+// torch.sign: (0 < g) - (g < 0); NaN and +-0 give 0.
+__device__ __forceinline__ float sgn(float g) { return (float)(0.0f < g) - (float)(g < 0.0f); }
+
+// torch.clamp(v, lo, hi) = min(max(v, lo), hi), NaN in v propagates.
+__device__ __forceinline__ float clampf(float v, float lo, float hi) {
+    v = (v < lo) ? lo : v;
+    return (v > hi) ? hi : v;
+}
+
+// torch.min(a, b) for tensors: NaN propagates.
+__device__ __forceinline__ float min_nan(float a, float b) {
+    if (a != a) return a;
+    if (b != b) return b;
+    return a < b ? a : b;
+}
+__device__ __forceinline__ float max_nan(float a, float b) {
+    if (a != a) return a;
+    if (b != b) return b;
+    return a > b ? a : b;
+}
+
+__device__ __forceinline__ float fgsm_elem(float x, float g, float eps, float lo, float hi) {
+    return clampf(x + eps * sgn(g), lo, hi);
+}
+
+__device__ __forceinline__ float pgd_linf_elem(float a, float g, float x, float alpha, float eps, float lo,
+                                               float hi) {
+    a = a + alpha * sgn(g);
+    float d = clampf(a - x, -eps, eps);
+    return clampf(x + d, lo, hi);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al., SC'11), counter-based: the same stream on the CPU oracle and on the device.
+// ---------------------------------------------------------------------------------------------------------
+
+struct Quad {
+    uint32_t v[4];
+};
+
+__device__ __forceinline__ Quad philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0;
+        c1 = lo1;
+        c2 = n2;
+        c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return Quad{{c0, c1, c2, c3}};
+}
+
+__device__ __forceinline__ float u01(uint32_t bits) { return (float)(bits >> 8) * 5.9604644775390625e-08f; }
+__device__ __forceinline__ float u01_open0(uint32_t bits) {  // (0, 1]
+    return (float)((bits >> 8) + 1u) * 5.9604644775390625e-08f;
+}
+
+// 4 uniforms in [-eps, eps): u * (eps - (-eps)) + (-eps)
+__device__ __forceinline__ float4 philox_uniform4(uint64_t q, uint64_t seed, uint64_t offset, float eps) {
+    const Quad r = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), (uint32_t)offset, (uint32_t)(offset >> 32),
+                                 (uint32_t)seed, (uint32_t)(seed >> 32));
+    const float from = -eps, range = eps - from;
+    return make_float4(u01(r.v[0]) * range + from, u01(r.v[1]) * range + from, u01(r.v[2]) * range + from,
+                       u01(r.v[3]) * range + from);
+}
+
+// 4 standard normals for quad q of row b (Box-Muller on two uniform pairs).
+__device__ __forceinline__ float4 philox_normal4(uint32_t q, uint32_t b, uint64_t seed, uint64_t offset) {
+    const Quad r = philox4x32_10(q, b, (uint32_t)offset, (uint32_t)(offset >> 32), (uint32_t)seed,
+                                 (uint32_t)(seed >> 32));
+    const float r0 = sqrtf(-2.0f * logf(u01_open0(r.v[0])));
+    const float r1 = sqrtf(-2.0f * logf(u01_open0(r.v[2])));
+    const float t0 = 6.283185307179586f * u01(r.v[1]);
+    const float t1 = 6.283185307179586f * u01(r.v[3]);
+    return make_float4(r0 * cosf(t0), r0 * sinf(t0), r1 * cosf(t1), r1 * sinf(t1));
+}
+
+__device__ __forceinline__ float f4_get(const float4 &v, int k) {
+    return k == 0 ? v.x : (k == 1 ? v.y : (k == 2 ? v.z : v.w));
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// workgroup reductions (wave64 shuffles -> LDS)
+// ---------------------------------------------------------------------------------------------------------
+
+struct SumOp {
+    __device__ __forceinline__ float operator()(float a, float b) const { return a + b; }
+};
+struct MinOp {
+    __device__ __forceinline__ float operator()(float a, float b) const { return min_nan(a, b); }
+};
+struct MaxOp {
+    __device__ __forceinline__ float operator()(float a, float b) const { return max_nan(a, b); }
+};
+
+template <class Op>
+__device__ __forceinline__ float wave_reduce(float v, Op op) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = op(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+// All threads of the workgroup receive the result. `lds` holds >= 4 floats; two calls in a row must use
+// different slots (or be separated by the caller) — each call ends with a barrier on its own slot.
+template <class Op>
+__device__ __forceinline__ float block_reduce(float v, Op op, float *lds) {
+    v = wave_reduce(v, op);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) lds[wave] = v;
+    __syncthreads();
+    float r = lds[0];
+#pragma unroll
+    for (int w = 1; w < kBlock / 64; ++w) r = op(r, lds[w]);
+    return r;
+}
+
+// Re-reduce the C per-tile partials of one row (every workgroup of the row does this; C is 16 at T = 64 600).
+template <class Op>
+__device__ __forceinline__ float reduce_partials(const float *__restrict__ part, int C, float identity, Op op,
+                                                 float *lds) {
+    float v = identity;
+    for (int i = threadIdx.x; i < C; i += kBlock) v = op(v, part[i]);
+    return block_reduce(v, op, lds);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// flat elementwise kernels: n = B*T samples, tile-strided, float4 when all pointers are 16-byte aligned
+// ---------------------------------------------------------------------------------------------------------
+
+// Generic driver: NIN input streams, one output stream, Op applied per sample.
+template <int NIN, class Op>
+__global__ __launch_bounds__(kBlock) void flat_vec_kernel(const float4 *__restrict__ in0,
+                                                          const float4 *__restrict__ in1,
+                                                          const float4 *__restrict__ in2, float4 *out, int64_t n4,
+                                                          int64_t ntiles, Op op) {
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t base = tile * kTileVec + threadIdx.x;
+        float4 a[kVecs] = {}, b[kVecs] = {}, c[kVecs] = {};
+#pragma unroll
+        for (int j = 0; j < kVecs; ++j) {
+            const int64_t i = base + (int64_t)j * kBlock;
+            if (i < n4) {
+                a[j] = in0[i];
+                if (NIN > 1) b[j] = in1[i];
+                if (NIN > 2) c[j] = in2[i];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < kVecs; ++j) {
+            const int64_t i = base + (int64_t)j * kBlock;
+            if (i < n4) {
+                float4 o;
+                o.x = op(a[j].x, b[j].x, c[j].x);
+                o.y = op(a[j].y, b[j].y, c[j].y);
+                o.z = op(a[j].z, b[j].z, c[j].z);
+                o.w = op(a[j].w, b[j].w, c[j].w);
+                out[i] = o;
+            }
+        }
+    }
+}
+
+// Scalar twin for the (< 4)-sample tail and for unaligned buffers: samples [begin, n).
+template <int NIN, class Op>
+__global__ __launch_bounds__(kBlock) void flat_scalar_kernel(const float *__restrict__ in0,
+                                                             const float *__restrict__ in1,
+                                                             const float *__restrict__ in2, float *out,
+                                                             int64_t begin, int64_t n, Op op) {
+    for (int64_t i = begin + (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const float a = in0[i];
+        const float b = NIN > 1 ? in1[i] : 0.0f;
+        const float c = NIN > 2 ? in2[i] : 0.0f;
+        out[i] = op(a, b, c);
+    }
+}
+
+struct FgsmOp {
+    float eps, lo, hi;
+    __device__ __forceinline__ float operator()(float x, float g, float) const {
+        return fgsm_elem(x, g, eps, lo, hi);
+    }
+};
+struct PgdLinfOp {
+    float alpha, eps, lo, hi;
+    __device__ __forceinline__ float operator()(float a, float g, float x) const {
+        return pgd_linf_elem(a, g, x, alpha, eps, lo, hi);
+    }
+};
+struct AddClampOp {
+    float lo, hi;
+    __device__ __forceinline__ float operator()(float x, float nz, float) const { return clampf(x + nz, lo, hi); }
+};
+struct CwInitOp {
+    // cw.py:117-122: atanh(x*2 - 1) spelled 0.5*log((1+y)/(1-y))
+    __device__ __forceinline__ float operator()(float x, float, float) const {
+        const float y = x * 2.0f - 1.0f;
+        return 0.5f * logf((1.0f + y) / (1.0f - y));
+    }
+};
+
+// PGD L-inf random start with in-kernel Philox: quad index == float4 index.
+__global__ __launch_bounds__(kBlock) void pgd_linf_init_philox_vec_kernel(const float4 *__restrict__ x, float4 *out,
+                                                                          int64_t n4, int64_t ntiles, float eps,
+                                                                          float lo, float hi, uint64_t seed,
+                                                                          uint64_t offset) {
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t base = tile * kTileVec + threadIdx.x;
+        float4 a[kVecs];
+#pragma unroll
+        for (int j = 0; j < kVecs; ++j) {
+            const int64_t i = base + (int64_t)j * kBlock;
+            if (i < n4) a[j] = x[i];
+        }
+#pragma unroll
+        for (int j = 0; j < kVecs; ++j) {
+            const int64_t i = base + (int64_t)j * kBlock;
+            if (i < n4) {
+                const float4 nz = philox_uniform4((uint64_t)i, seed, offset, eps);
+                float4 o;
+                o.x = clampf(a[j].x + nz.x, lo, hi);
+                o.y = clampf(a[j].y + nz.y, lo, hi);
+                o.z = clampf(a[j].z + nz.z, lo, hi);
+                o.w = clampf(a[j].w + nz.w, lo, hi);
+                out[i] = o;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void pgd_linf_init_philox_scalar_kernel(const float *__restrict__ x, float *out,
+                                                                             int64_t begin, int64_t n, float eps,
+                                                                             float lo, float hi, uint64_t seed,
+                                                                             uint64_t offset) {
+    for (int64_t i = begin + (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const float4 nz = philox_uniform4((uint64_t)(i >> 2), seed, offset, eps);
+        out[i] = clampf(x[i] + f4_get(nz, (int)(i & 3)), lo, hi);
+    }
+}
+
+// CW Adam step on w (tanh recomputed; see header).
+struct AdamScalars {
+    float w1;        // 1 - beta1           (lerp weight)
+    float beta2;     // beta2
+    float omb2;      // 1 - beta2
+    float neg_step;  // -(lr / (1 - beta1^t))
+    float bc2_sqrt;  // sqrt(1 - beta2^t)
+    float eps;
+};
+
+__device__ __forceinline__ void cw_adam_elem(float &w, float &m, float &v, float x, float gm, const AdamScalars &s) {
+    const float y = tanhf(w);
+    const float a = 0.5f * (y + 1.0f);
+    const float g = ((2.0f * (a - x) + gm) * 0.5f) * (1.0f - y * y);
+    m = m + s.w1 * (g - m);
+    v = v * s.beta2 + (s.omb2 * g) * g;
+    const float denom = sqrtf(v) / s.bc2_sqrt + s.eps;
+    w = w + s.neg_step * (m / denom);
+}
+
+__global__ __launch_bounds__(kBlock) void cw_adam_vec_kernel(float4 *w, float4 *m, float4 *v,
+                                                             const float4 *__restrict__ x,
+                                                             const float4 *__restrict__ gm, int64_t n4,
+                                                             int64_t ntiles, AdamScalars s) {
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t base = tile * kTileVec + threadIdx.x;
+#pragma unroll 2
+        for (int j = 0; j < kVecs; ++j) {
+            const int64_t i = base + (int64_t)j * kBlock;
+            if (i < n4) {
+                float4 W = w[i], M = m[i], V = v[i];
+                const float4 X = x[i], G = gm[i];
+                cw_adam_elem(W.x, M.x, V.x, X.x, G.x, s);
+                cw_adam_elem(W.y, M.y, V.y, X.y, G.y, s);
+                cw_adam_elem(W.z, M.z, V.z, X.z, G.z, s);
+                cw_adam_elem(W.w, M.w, V.w, X.w, G.w, s);
+                w[i] = W;
+                m[i] = M;
+                v[i] = V;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void cw_adam_scalar_kernel(float *w, float *m, float *v,
+                                                                const float *__restrict__ x,
+                                                                const float *__restrict__ gm, int64_t begin,
+                                                                int64_t n, AdamScalars s) {
+    for (int64_t i = begin + (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        float W = w[i], M = m[i], V = v[i];
+        cw_adam_elem(W, M, V, x[i], gm[i], s);
+        w[i] = W;
+        m[i] = M;
+        v[i] = V;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// row kernels: grid = (C tiles per row, B rows); tile c of row b covers samples [c*kTile, min(T, (c+1)*kTile))
+// VEC = rows are float4-addressable (T % 4 == 0 and 16-byte aligned bases).
+// ---------------------------------------------------------------------------------------------------------
+
+// Loads the workgroup's tile of one row into registers (out-of-range lanes get `fill`).
+template <bool VEC>
+__device__ __forceinline__ void load_tile(const float *__restrict__ row, int64_t T, int tile, float fill,
+                                          float4 (&r)[kVecs]) {
+    if (VEC) {
+        const float4 *row4 = reinterpret_cast<const float4 *>(row);
+        const int64_t T4 = T >> 2;
+#pragma unroll
+        for (int j = 0; j < kVecs; ++j) {
+            const int64_t i = (int64_t)tile * kTileVec + j * kBlock + threadIdx.x;
+            r[j] = (i < T4) ? row4[i] : make_float4(fill, fill, fill, fill);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < kVecs; ++j) {
+            const int64_t i = ((int64_t)tile * kTileVec + j * kBlock + threadIdx.x) * 4;
+            r[j].x = (i + 0 < T) ? row[i + 0] : fill;
+            r[j].y = (i + 1 < T) ? row[i + 1] : fill;
+            r[j].z = (i + 2 < T) ? row[i + 2] : fill;
+            r[j].w = (i + 3 < T) ? row[i + 3] : fill;
+        }
+    }
+}
+
+template <bool VEC>
+__device__ __forceinline__ void store_tile(float *row, int64_t T, int tile, const float4 (&r)[kVecs]) {
+    if (VEC) {
+        float4 *row4 = reinterpret_cast<float4 *>(row);
+        const int64_t T4 = T >> 2;
+#pragma unroll
+        for (int j = 0; j < kVecs; ++j) {
+            const int64_t i = (int64_t)tile * kTileVec + j * kBlock + threadIdx.x;
+            if (i < T4) row4[i] = r[j];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < kVecs; ++j) {
+            const int64_t i = ((int64_t)tile * kTileVec + j * kBlock + threadIdx.x) * 4;
+            if (i + 0 < T) row[i + 0] = r[j].x;
+            if (i + 1 < T) row[i + 1] = r[j].y;
+            if (i + 2 < T) row[i + 2] = r[j].z;
+            if (i + 3 < T) row[i + 3] = r[j].w;
+        }
+    }
+}
+
+// Is sample k (0..3) of vector j of this thread inside the row?  (only needed where `fill` cannot be neutral)
+__device__ __forceinline__ bool in_row(int64_t T, int tile, int j, int k) {
+    return ((int64_t)tile * kTileVec + j * kBlock + threadIdx.x) * 4 + k < T;
+}
+
+#define ADV_FOR_EACH_LANE(r, expr)      \
+    _Pragma("unroll") for (int j = 0; j < kVecs; ++j) { \
+        { float &e = r[j].x; const int k = 0; (void)k; expr; } \
+        { float &e = r[j].y; const int k = 1; (void)k; expr; } \
+        { float &e = r[j].z; const int k = 2; (void)k; expr; } \
+        { float &e = r[j].w; const int k = 3; (void)k; expr; } \
+    }
+
+// ---- a1: to_minmax ----------------------------------------------------------------------------------------
+
+template <bool VEC>
+__global__ __launch_bounds__(kBlock) void minmax_partial_kernel(const float *__restrict__ x, int64_t T,
+                                                                float *__restrict__ pmin, float *__restrict__ pmax) {
+    __shared__ float lds[8];
+    const int tile = blockIdx.x, C = gridDim.x;
+    const int64_t b = blockIdx.y;
+    const float *row = x + b * T;
+    // neutral fill: the row's first sample (always in range) keeps NaN propagation intact
+    const float fill = row[0];
+    float4 r[kVecs];
+    load_tile<VEC>(row, T, tile, fill, r);
+    float lo = fill, hi = fill;
+    ADV_FOR_EACH_LANE(r, lo = min_nan(lo, e); hi = max_nan(hi, e));
+    lo = block_reduce(lo, MinOp(), lds);
+    hi = block_reduce(hi, MaxOp(), lds + 4);
+    if (threadIdx.x == 0) {
+        pmin[b * C + tile] = lo;
+        pmax[b * C + tile] = hi;
+    }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(kBlock) void minmax_apply_kernel(const float *__restrict__ x, float *x01,
+                                                              float *__restrict__ mn_out, float *__restrict__ mx_out,
+                                                              int64_t T, const float *__restrict__ pmin,
+                                                              const float *__restrict__ pmax) {
+    __shared__ float lds[8];
+    const int tile = blockIdx.x, C = gridDim.x;
+    const int64_t b = blockIdx.y;
+    float4 r[kVecs];
+    load_tile<VEC>(x + b * T, T, tile, 0.0f, r);
+    const float first = pmin[b * C];
+    const float mn = reduce_partials(pmin + b * C, C, first, MinOp(), lds);
+    const float mx = reduce_partials(pmax + b * C, C, pmax[b * C], MaxOp(), lds + 4);
+    const float range = mx - mn;
+    ADV_FOR_EACH_LANE(r, e = (e - mn) / range);
+    store_tile<VEC>(x01 + b * T, T, tile, r);
+    if (tile == 0 && threadIdx.x == 0) {
+        mn_out[b] = mn;
+        mx_out[b] = mx;
+    }
+}
+
+// ---- a2: revert_minmax ------------------------------------------------------------------------------------
+
+template <bool VEC>
+__global__ __launch_bounds__(kBlock) void minmax_revert_kernel(const float *__restrict__ x01,
+                                                               const float *__restrict__ mn,
+                                                               const float *__restrict__ mx, float *out, int64_t T) {
+    const int tile = blockIdx.x;
+    const int64_t b = blockIdx.y;
+    float4 r[kVecs];
+    load_tile<VEC>(x01 + b * T, T, tile, 0.0f, r);
+    const float lo = mn[b];
+    const float range = mx[b] - lo;
+    ADV_FOR_EACH_LANE(r, e = (e * range) + lo);
+    store_tile<VEC>(out + b * T, T, tile, r);
+}
+
+// ---- row sum of squares (||grad||^2, ||normal||^2) ------------------------------------------------------------
+
+template <bool VEC>
+__global__ __launch_bounds__(kBlock) void sumsq_partial_kernel(const float *__restrict__ g, int64_t T,
+                                                               float *__restrict__ part) {
+    __shared__ float lds[4];
+    const int tile = blockIdx.x, C = gridDim.x;
+    const int64_t b = blockIdx.y;
+    float4 r[kVecs];
+    load_tile<VEC>(g + b * T, T, tile, 0.0f, r);
+    float s = 0.0f;
+#pragma unroll
+    for (int j = 0; j < kVecs; ++j) s += (r[j].x * r[j].x + r[j].y * r[j].y) + (r[j].z * r[j].z + r[j].w * r[j].w);
+    s = block_reduce(s, SumOp(), lds);
+    if (threadIdx.x == 0) part[b * C + tile] = s;
+}
+
+// ---- a6: PGD-L2 step ------------------------------------------------------------------------------------------
+
+// pass 2: gn from the grad partials; a = adv + alpha * (g / gn); d = a - orig; partial sum d^2
+template <bool VEC>
+__global__ __launch_bounds__(kBlock) void pgd_l2_delta_kernel(const float *__restrict__ adv,
+                                                              const float *__restrict__ grad,
+                                                              const float *__restrict__ orig, int64_t T, float alpha,
+                                                              float eps_div, const float *__restrict__ gpart,
+                                                              float *__restrict__ dpart, float *__restrict__ gnorm) {
+    __shared__ float lds[8];
+    const int tile = blockIdx.x, C = gridDim.x;
+    const int64_t b = blockIdx.y;
+    float4 a[kVecs], g[kVecs], x[kVecs];
+    load_tile<VEC>(adv + b * T, T, tile, 0.0f, a);
+    load_tile<VEC>(grad + b * T, T, tile, 0.0f, g);
+    load_tile<VEC>(orig + b * T, T, tile, 0.0f, x);
+    const float gsq = reduce_partials(gpart + b * C, C, 0.0f, SumOp(), lds);
+    const float gn_raw = sqrtf(gsq);
+    const float gn = gn_raw + eps_div;
+    float s = 0.0f;
+#pragma unroll
+    for (int j = 0; j < kVecs; ++j) {
+        float4 d;
+        d.x = (a[j].x + alpha * (g[j].x / gn)) - x[j].x;
+        d.y = (a[j].y + alpha * (g[j].y / gn)) - x[j].y;
+        d.z = (a[j].z + alpha * (g[j].z / gn)) - x[j].z;
+        d.w = (a[j].w + alpha * (g[j].w / gn)) - x[j].w;
+        // out-of-row lanes: a = g = x = 0 -> d = 0 when gn != 0; mask explicitly so gn == 0 / NaN cannot leak
+        if (!in_row(T, tile, j, 0)) d.x = 0.0f;
+        if (!in_row(T, tile, j, 1)) d.y = 0.0f;
+        if (!in_row(T, tile, j, 2)) d.z = 0.0f;
+        if (!in_row(T, tile, j, 3)) d.w = 0.0f;
+        s += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+    }
+    s = block_reduce(s, SumOp(), lds + 4);
+    if (threadIdx.x == 0) {
+        dpart[b * C + tile] = s;
+        if (tile == 0 && gnorm) gnorm[b] = gn_raw;
+    }
+}
+
+// pass 3: recompute d, f = min((1/dn) * eps, 1), out = clamp(orig + d * f, lo, hi)
+template <bool VEC>
+__global__ __launch_bounds__(kBlock) void pgd_l2_project_kernel(const float *__restrict__ adv,
+                                                                const float *__restrict__ grad,
+                                                                const float *__restrict__ orig, float *out, int64_t T,
+                                                                float alpha, float eps, float eps_div, float lo,
+                                                                float hi, const float *__restrict__ gpart,
+                                                                const float *__restrict__ dpart,
+                                                                float *__restrict__ dnorm) {
+    __shared__ float lds[8];
+    const int tile = blockIdx.x, C = gridDim.x;
+    const int64_t b = blockIdx.y;
+    float4 a[kVecs], g[kVecs], x[kVecs];
+    load_tile<VEC>(adv + b * T, T, tile, 0.0f, a);
+    load_tile<VEC>(grad + b * T, T, tile, 0.0f, g);
+    load_tile<VEC>(orig + b * T, T, tile, 0.0f, x);
+    const float gn = sqrtf(reduce_partials(gpart + b * C, C, 0.0f, SumOp(), lds)) + eps_div;
+    const float dn = sqrtf(reduce_partials(dpart + b * C, C, 0.0f, SumOp(), lds + 4));
+    const float f = min_nan((1.0f / dn) * eps, 1.0f);
+#pragma unroll
+    for (int j = 0; j < kVecs; ++j) {
+        float4 d;
+        d.x = (a[j].x + alpha * (g[j].x / gn)) - x[j].x;
+        d.y = (a[j].y + alpha * (g[j].y / gn)) - x[j].y;
+        d.z = (a[j].z + alpha * (g[j].z / gn)) - x[j].z;
+        d.w = (a[j].w + alpha * (g[j].w / gn)) - x[j].w;
+        a[j].x = clampf(x[j].x + d.x * f, lo, hi);
+        a[j].y = clampf(x[j].y + d.y * f, lo, hi);
+        a[j].z = clampf(x[j].z + d.z * f, lo, hi);
+        a[j].w = clampf(x[j].w + d.w * f, lo, hi);
+    }
+    store_tile<VEC>(out + b * T, T, tile, a);
+    if (tile == 0 && threadIdx.x == 0 && dnorm) dnorm[b] = dn;
+}
+
+// ---- a6: PGD-L2 random start -----------------------------------------------------------------------------------
+
+// explicit draws: out = clamp(x + normal * ((r / nrm) * eps), lo, hi)
+template <bool VEC>
+__global__ __launch_bounds__(kBlock) void pgd_l2_init_noise_kernel(const float *__restrict__ x,
+                                                                   const float *__restrict__ normal,
+                                                                   const float *__restrict__ r, float *out, int64_t T,
+                                                                   float eps, float lo, float hi,
+                                                                   const float *__restrict__ npart) {
+    __shared__ float lds[4];
+    const int tile = blockIdx.x, C = gridDim.x;
+    const int64_t b = blockIdx.y;
+    float4 xv[kVecs], nz[kVecs];
+    load_tile<VEC>(x + b * T, T, tile, 0.0f, xv);
+    load_tile<VEC>(normal + b * T, T, tile, 0.0f, nz);
+    const float nrm = sqrtf(reduce_partials(npart + b * C, C, 0.0f, SumOp(), lds));
+    const float scale = (r[b] / nrm) * eps;
+#pragma unroll
+    for (int j = 0; j < kVecs; ++j) {
+        xv[j].x = clampf(xv[j].x + nz[j].x * scale, lo, hi);
+        xv[j].y = clampf(xv[j].y + nz[j].y * scale, lo, hi);
+        xv[j].z = clampf(xv[j].z + nz[j].z * scale, lo, hi);
+        xv[j].w = clampf(xv[j].w + nz[j].w * scale, lo, hi);
+    }
+    store_tile<VEC>(out + b * T, T, tile, xv);
+}
+
+// Philox normals for this thread's kVecs quads of (row b, tile); out-of-row samples are zeroed.
+__device__ __forceinline__ void philox_normal_tile(int64_t T, int tile, uint32_t b, uint64_t seed, uint64_t offset,
+                                                   float4 (&nz)[kVecs]) {
+#pragma unroll
+    for (int j = 0; j < kVecs; ++j) {
+        const int64_t q = (int64_t)tile * kTileVec + j * kBlock + threadIdx.x;
+        if (q * 4 < T) {
+            nz[j] = philox_normal4((uint32_t)q, b, seed, offset);
+            if (q * 4 + 1 >= T) nz[j].y = 0.0f;
+            if (q * 4 + 2 >= T) nz[j].z = 0.0f;
+            if (q * 4 + 3 >= T) nz[j].w = 0.0f;
+        } else {
+            nz[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void philox_normal_sumsq_kernel(int64_t T, uint64_t seed, uint64_t offset,
+                                                                     float *__restrict__ part) {
+    __shared__ float lds[4];
+    const int tile = blockIdx.x, C = gridDim.x;
+    const int64_t b = blockIdx.y;
+    float4 nz[kVecs];
+    philox_normal_tile(T, tile, (uint32_t)b, seed, offset, nz);
+    float s = 0.0f;
+#pragma unroll
+    for (int j = 0; j < kVecs; ++j)
+        s += (nz[j].x * nz[j].x + nz[j].y * nz[j].y) + (nz[j].z * nz[j].z + nz[j].w * nz[j].w);
+    s = block_reduce(s, SumOp(), lds);
+    if (threadIdx.x == 0) part[b * C + tile] = s;
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(kBlock) void pgd_l2_init_philox_kernel(const float *__restrict__ x, float *out,
+                                                                    int64_t T, float eps, float lo, float hi,
+                                                                    uint64_t seed, uint64_t offset,
+                                                                    const float *__restrict__ npart) {
+    __shared__ float lds[4];
+    const int tile = blockIdx.x, C = gridDim.x;
+    const int64_t b = blockIdx.y;
+    float4 xv[kVecs], nz[kVecs];
+    load_tile<VEC>(x + b * T, T, tile, 0.0f, xv);
+    philox_normal_tile(T, tile, (uint32_t)b, seed, offset, nz);
+    const float nrm = sqrtf(reduce_partials(npart + b * C, C, 0.0f, SumOp(), lds));
+    const uint64_t off1 = offset + 1;
+    const Quad rq = philox4x32_10((uint32_t)b, (uint32_t)((uint64_t)b >> 32), (uint32_t)off1, (uint32_t)(off1 >> 32),
+                                  (uint32_t)seed, (uint32_t)(seed >> 32));
+    const float scale = (u01(rq.v[0]) / nrm) * eps;
+#pragma unroll
+    for (int j = 0; j < kVecs; ++j) {
+        xv[j].x = clampf(xv[j].x + nz[j].x * scale, lo, hi);
+        xv[j].y = clampf(xv[j].y + nz[j].y * scale, lo, hi);
+        xv[j].z = clampf(xv[j].z + nz[j].z * scale, lo, hi);
+        xv[j].w = clampf(xv[j].w + nz[j].w * scale, lo, hi);
+    }
+    store_tile<VEC>(out + b * T, T, tile, xv);
+}
+
+// ---- a7: CW -------------------------------------------------------------------------------------------------------
+
+// adv = 1/2 * (tanh(w) + 1); partial sum (adv - x)^2
+template <bool VEC>
+__global__ __launch_bounds__(kBlock) void cw_tanh_sqdist_kernel(const float *__restrict__ w,
+                                                                const float *__restrict__ x, float *adv, int64_t T,
+                                                                float *__restrict__ part) {
+    __shared__ float lds[4];
+    const int tile = blockIdx.x, C = gridDim.x;
+    const int64_t b = blockIdx.y;
+    float4 wv[kVecs], xv[kVecs];
+    load_tile<VEC>(w + b * T, T, tile, 0.0f, wv);
+    // fill = 0.5 == tanh_space(0): out-of-row lanes contribute (0.5 - 0.5)^2 = 0
+    load_tile<VEC>(x + b * T, T, tile, 0.5f, xv);
+    float s = 0.0f;
+#pragma unroll
+    for (int j = 0; j < kVecs; ++j) {
+        wv[j].x = 0.5f * (tanhf(wv[j].x) + 1.0f);
+        wv[j].y = 0.5f * (tanhf(wv[j].y) + 1.0f);
+        wv[j].z = 0.5f * (tanhf(wv[j].z) + 1.0f);
+        wv[j].w = 0.5f * (tanhf(wv[j].w) + 1.0f);
+        const float dx = wv[j].x - xv[j].x, dy = wv[j].y - xv[j].y, dz = wv[j].z - xv[j].z, dw = wv[j].w - xv[j].w;
+        s += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+    }
+    store_tile<VEC>(adv + b * T, T, tile, wv);
+    s = block_reduce(s, SumOp(), lds);
+    if (threadIdx.x == 0) part[b * C + tile] = s;
+}
+
+// one wave per row: l2[b] = sum of the row's partials
+__global__ __launch_bounds__(64) void row_partials_sum_kernel(const float *__restrict__ part, int C,
+                                                              float *__restrict__ out) {
+    const int64_t b = blockIdx.x;
+    float v = 0.0f;
+    for (int i = threadIdx.x; i < C; i += 64) v += part[b * C + i];
+    v = wave_reduce(v, SumOp());
+    if (threadIdx.x == 0) out[b] = v;
+}
+
+// best = mask * adv + (1 - mask) * best
+template <bool VEC>
+__global__ __launch_bounds__(kBlock) void cw_best_update_kernel(const float *__restrict__ adv,
+                                                                const float *__restrict__ mask, float *best,
+                                                                int64_t T) {
+    const int tile = blockIdx.x;
+    const int64_t b = blockIdx.y;
+    const float mk = mask[b];
+    const float inv = 1.0f - mk;
+    float4 a[kVecs], bs[kVecs];
+    load_tile<VEC>(adv + b * T, T, tile, 0.0f, a);
+    load_tile<VEC>(best + b * T, T, tile, 0.0f, bs);
+#pragma unroll
+    for (int j = 0; j < kVecs; ++j) {
+        bs[j].x = mk * a[j].x + inv * bs[j].x;
+        bs[j].y = mk * a[j].y + inv * bs[j].y;
+        bs[j].z = mk * a[j].z + inv * bs[j].z;
+        bs[j].w = mk * a[j].w + inv * bs[j].w;
+    }
+    store_tile<VEC>(best + b * T, T, tile, bs);
+}
+
+// ---- a8: 2-logit cross-entropy, closed form ------------------------------------------------------------------------
+
+__device__ __forceinline__ float softplusf(float t) {  // log(1 + exp(t)), stable
+    return (t > 0.0f ? t : 0.0f) + log1pf(expf(-fabsf(t)));
+}
+
+__global__ __launch_bounds__(kBlock) void ce2_loss_grad_kernel(const float *__restrict__ z,
+                                                               const int64_t *__restrict__ labels,
+                                                               float *__restrict__ dz, float *__restrict__ loss,
+                                                               int64_t B, float scale) {
+    __shared__ float lds[4];
+    const float invB = 1.0f / (float)B;
+    float acc = 0.0f;
+    for (int64_t b = threadIdx.x; b < B; b += kBlock) {
+        const float t = 2.0f * z[b];
+        const float y = (float)labels[b];
+        // CE([-z, z], y): y = 1 -> softplus(-2z), y = 0 -> softplus(2z)
+        acc += softplusf((1.0f - 2.0f * y) * t);
+        const float sig = 1.0f / (1.0f + expf(-t));
+        dz[b] = scale * ((2.0f * invB) * (sig - y));
+    }
+    acc = block_reduce(acc, SumOp(), lds);
+    if (threadIdx.x == 0) loss[0] = scale * (acc * invB);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// host-side helpers
+// ---------------------------------------------------------------------------------------------------------
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+inline int tiles_per_row(int64_t T) { return (int)ceil_div(T, kTile); }
+inline int status_after_launch() { return hipGetLastError() == hipSuccess ? ADVSTEP_OK : ADVSTEP_ELAUNCH; }
+inline hipStream_t as_stream(advstep_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+struct RowWs {
+    float *p0;
+    float *p1;
+};
+inline size_t row_ws_bytes(int64_t B, int64_t T) {
+    const size_t one = (size_t)B * (size_t)tiles_per_row(T) * sizeof(float);
+    return 2 * ((one + 15) & ~(size_t)15);
+}
+inline bool carve_ws(void *ws, size_t ws_bytes, int64_t B, int64_t T, RowWs *out) {
+    if (!ws || !aligned16(ws) || ws_bytes < row_ws_bytes(B, T)) return false;
+    out->p0 = static_cast<float *>(ws);
+    out->p1 = reinterpret_cast<float *>(static_cast<char *>(ws) + row_ws_bytes(B, T) / 2);
+    return true;
+}
+
+// grid.y is limited to 65535 rows per launch; batches beyond that are launched in slabs.
+constexpr int64_t kMaxRowsPerLaunch = 65535;
+
+template <int NIN, class Op>
+int launch_flat(const float *in0, const float *in1, const float *in2, float *out, int64_t n, Op op,
+                hipStream_t st) {
+    if (n == 0) return ADVSTEP_OK;
+    const bool vec = aligned16(in0) && aligned16(out) && (NIN < 2 || aligned16(in1)) && (NIN < 3 || aligned16(in2));
+    const int64_t n4 = vec ? n / 4 : 0;
+    if (n4 > 0) {
+        const int64_t ntiles = ceil_div(n4, kTileVec);
+        const int grid = (int)(ntiles < kMaxGrid ? ntiles : kMaxGrid);
+        hipLaunchKernelGGL((flat_vec_kernel<NIN, Op>), dim3(grid), dim3(kBlock), 0, st,
+                           reinterpret_cast<const float4 *>(in0), reinterpret_cast<const float4 *>(in1),
+                           reinterpret_cast<const float4 *>(in2), reinterpret_cast<float4 *>(out), n4, ntiles, op);
+    }
+    const int64_t begin = n4 * 4;
+    if (begin < n) {
+        const int64_t blocks = ceil_div(n - begin, kBlock);
+        const int grid = (int)(blocks < kMaxGrid ? blocks : kMaxGrid);
+        hipLaunchKernelGGL((flat_scalar_kernel<NIN, Op>), dim3(grid), dim3(kBlock), 0, st, in0, in1, in2, out, begin,
+                           n, op);
+    }
+    return status_after_launch();
+}
+
+inline bool rows_vec(int64_t T, std::initializer_list<const void *> ptrs) {
+    if (T % 4 != 0) return false;
+    for (const void *p : ptrs)
+        if (!aligned16(p)) return false;
+    return true;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------------------
+
+#define ADV_REQUIRE(cond) \
+    do {                  \
+        if (!(cond)) return ADVSTEP_EINVAL; \
+    } while (0)
+
+// Launch a row kernel over all B rows in slabs of <= 65535 rows; `ARGS` may use `b0` (first row of the slab).
+#define ADV_LAUNCH_ROWS(KERNEL, VECFLAG, B, T, st, ...)                                          \
+    do {                                                                                         \
+        const int C_ = tiles_per_row(T);                                                         \
+        for (int64_t b0 = 0; b0 < (B); b0 += kMaxRowsPerLaunch) {                                \
+            const int64_t nb_ = ((B)-b0 < kMaxRowsPerLaunch) ? ((B)-b0) : kMaxRowsPerLaunch;     \
+            if (VECFLAG)                                                                         \
+                hipLaunchKernelGGL((KERNEL<true>), dim3(C_, (unsigned)nb_), dim3(kBlock), 0, st, __VA_ARGS__); \
+            else                                                                                 \
+                hipLaunchKernelGGL((KERNEL<false>), dim3(C_, (unsigned)nb_), dim3(kBlock), 0, st, __VA_ARGS__); \
+        }                                                                                        \
+    } while (0)
+
+extern "C" {
+
+int advstep_abi_version(void) { return ADVSTEP_ABI_VERSION; }
+
+const char *advstep_status_string(int status) {
+    switch (status) {
+        case ADVSTEP_OK: return "ok";
+        case ADVSTEP_EINVAL: return "invalid argument";
+        case ADVSTEP_EWORKSPACE: return "row workspace missing, misaligned or too small";
+        case ADVSTEP_ELAUNCH: return "HIP kernel launch failed";
+        case ADVSTEP_ENODEVICE: return "no HIP device";
+        default: return "unknown status";
+    }
+}
+
+int advstep_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+size_t advstep_row_workspace_bytes(int64_t B, int64_t T) {
+    if (B <= 0 || T <= 0) return 0;
+    return row_ws_bytes(B, T);
+}
+
+int advstep_minmax_normalize_f32(const float *x, float *x01, float *mn, float *mx, int64_t B, int64_t T, void *ws,
+                                 size_t ws_bytes, advstep_stream_t stream) {
+    ADV_REQUIRE(B >= 0 && T >= 0);
+    if (B == 0 || T == 0) return ADVSTEP_OK;
+    ADV_REQUIRE(x && x01 && mn && mx && x != x01);
+    RowWs w;
+    if (!carve_ws(ws, ws_bytes, B, T, &w)) return ADVSTEP_EWORKSPACE;
+    hipStream_t st = as_stream(stream);
+    const bool vec = rows_vec(T, {x, x01});
+    const int C = tiles_per_row(T);
+    ADV_LAUNCH_ROWS(minmax_partial_kernel, vec, B, T, st, x + b0 * T, T, w.p0 + b0 * C, w.p1 + b0 * C);
+    ADV_LAUNCH_ROWS(minmax_apply_kernel, vec, B, T, st, x + b0 * T, x01 + b0 * T, mn + b0, mx + b0, T, w.p0 + b0 * C,
+                    w.p1 + b0 * C);
+    return status_after_launch();
+}
+
+int advstep_minmax_revert_f32(const float *x01, const float *mn, const float *mx, float *out, int64_t B, int64_t T,
+                              advstep_stream_t stream) {
+    ADV_REQUIRE(B >= 0 && T >= 0);
+    if (B == 0 || T == 0) return ADVSTEP_OK;
+    ADV_REQUIRE(x01 && mn && mx && out);
+    hipStream_t st = as_stream(stream);
+    const bool vec = rows_vec(T, {x01, out});
+    ADV_LAUNCH_ROWS(minmax_revert_kernel, vec, B, T, st, x01 + b0 * T, mn + b0, mx + b0, out + b0 * T, T);
+    return status_after_launch();
+}
+
+int advstep_fgsm_step_f32(const float *x, const float *grad, float *out, int64_t n, float eps, float lo, float hi,
+                          advstep_stream_t stream) {
+    ADV_REQUIRE(n >= 0);
+    if (n == 0) return ADVSTEP_OK;
+    ADV_REQUIRE(x && grad && out);
+    return launch_flat<2>(x, grad, nullptr, out, n, FgsmOp{eps, lo, hi}, as_stream(stream));
+}
+
+int advstep_pgd_linf_init_noise_f32(const float *x, const float *noise, float *out, int64_t n, float lo, float hi,
+                                    advstep_stream_t stream) {
+    ADV_REQUIRE(n >= 0);
+    if (n == 0) return ADVSTEP_OK;
+    ADV_REQUIRE(x && noise && out);
+    return launch_flat<2>(x, noise, nullptr, out, n, AddClampOp{lo, hi}, as_stream(stream));
+}
+
+int advstep_pgd_linf_init_philox_f32(const float *x, float *out, int64_t n, float eps, float lo, float hi,
+                                     uint64_t seed, uint64_t offset, advstep_stream_t stream) {
+    ADV_REQUIRE(n >= 0);
+    if (n == 0) return ADVSTEP_OK;
+    ADV_REQUIRE(x && out);
+    hipStream_t st = as_stream(stream);
+    const bool vec = aligned16(x) && aligned16(out);
+    const int64_t n4 = vec ? n / 4 : 0;
+    if (n4 > 0) {
+        const int64_t ntiles = ceil_div(n4, kTileVec);
+        const int grid = (int)(ntiles < kMaxGrid ? ntiles : kMaxGrid);
+        hipLaunchKernelGGL(pgd_linf_init_philox_vec_kernel, dim3(grid), dim3(kBlock), 0, st,
+                           reinterpret_cast<const float4 *>(x), reinterpret_cast<float4 *>(out), n4, ntiles, eps, lo,
+                           hi, seed, offset);
+    }
+    const int64_t begin = n4 * 4;
+    if (begin < n) {
+        const int64_t blocks = ceil_div(n - begin, kBlock);
+        const int grid = (int)(blocks < kMaxGrid ? blocks : kMaxGrid);
+        hipLaunchKernelGGL(pgd_linf_init_philox_scalar_kernel, dim3(grid), dim3(kBlock), 0, st, x, out, begin, n, eps,
+                           lo, hi, seed, offset);
+    }
+    return status_after_launch();
+}
+
+int advstep_pgd_linf_step_f32(const float *adv, const float *grad, const float *orig, float *out, int64_t n,
+                              float alpha, float eps, float lo, float hi, advstep_stream_t stream) {
+    ADV_REQUIRE(n >= 0);
+    if (n == 0) return ADVSTEP_OK;
+    ADV_REQUIRE(adv && grad && orig && out);
+    return launch_flat<3>(adv, grad, orig, out, n, PgdLinfOp{alpha, eps, lo, hi}, as_stream(stream));
+}
+
+int advstep_pgd_l2_init_noise_f32(const float *x, const float *normal, const float *r, float *out, int64_t B,
+                                  int64_t T, float eps, float lo, float hi, void *ws, size_t ws_bytes,
+                                  advstep_stream_t stream) {
+    ADV_REQUIRE(B >= 0 && T >= 0);
+    if (B == 0 || T == 0) return ADVSTEP_OK;
+    ADV_REQUIRE(x && normal && r && out);
+    RowWs w;
+    if (!carve_ws(ws, ws_bytes, B, T, &w)) return ADVSTEP_EWORKSPACE;
+    hipStream_t st = as_stream(stream);
+    const bool vec = rows_vec(T, {x, normal, out});
+    const int C = tiles_per_row(T);
+    ADV_LAUNCH_ROWS(sumsq_partial_kernel, vec, B, T, st, normal + b0 * T, T, w.p0 + b0 * C);
+    ADV_LAUNCH_ROWS(pgd_l2_init_noise_kernel, vec, B, T, st, x + b0 * T, normal + b0 * T, r + b0, out + b0 * T, T, eps,
+                    lo, hi, w.p0 + b0 * C);
+    return status_after_launch();
+}
+
+int advstep_pgd_l2_init_philox_f32(const float *x, float *out, int64_t B, int64_t T, float eps, float lo, float hi,
+                                   uint64_t seed, uint64_t offset, void *ws, size_t ws_bytes,
+                                   advstep_stream_t stream) {
+    ADV_REQUIRE(B >= 0 && T >= 0);
+    if (B == 0 || T == 0) return ADVSTEP_OK;
+    ADV_REQUIRE(x && out);
+    ADV_REQUIRE(B <= kMaxRowsPerLaunch);  // the Philox counter carries the absolute row index
+    RowWs w;
+    if (!carve_ws(ws, ws_bytes, B, T, &w)) return ADVSTEP_EWORKSPACE;
+    hipStream_t st = as_stream(stream);
+    const bool vec = rows_vec(T, {x, out});
+    const int C = tiles_per_row(T);
+    hipLaunchKernelGGL(philox_normal_sumsq_kernel, dim3(C, (unsigned)B), dim3(kBlock), 0, st, T, seed, offset, w.p0);
+    ADV_LAUNCH_ROWS(pgd_l2_init_philox_kernel, vec, B, T, st, x, out, T, eps, lo, hi, seed, offset, w.p0);
+    return status_after_launch();
+}
+
+int advstep_pgd_l2_step_f32(const float *adv, const float *grad, const float *orig, float *out, int64_t B, int64_t T,
+                            float alpha, float eps, float eps_div, float lo, float hi, float *gnorm, float *dnorm,
+                            void *ws, size_t ws_bytes, advstep_stream_t stream) {
+    ADV_REQUIRE(B >= 0 && T >= 0);
+    if (B == 0 || T == 0) return ADVSTEP_OK;
+    ADV_REQUIRE(adv && grad && orig && out);
+    RowWs w;
+    if (!carve_ws(ws, ws_bytes, B, T, &w)) return ADVSTEP_EWORKSPACE;
+    hipStream_t st = as_stream(stream);
+    const bool vec = rows_vec(T, {adv, grad, orig, out});
+    const int C = tiles_per_row(T);
+    ADV_LAUNCH_ROWS(sumsq_partial_kernel, vec, B, T, st, grad + b0 * T, T, w.p0 + b0 * C);
+    ADV_LAUNCH_ROWS(pgd_l2_delta_kernel, vec, B, T, st, adv + b0 * T, grad + b0 * T, orig + b0 * T, T, alpha, eps_div,
+                    w.p0 + b0 * C, w.p1 + b0 * C, gnorm ? gnorm + b0 : nullptr);
+    ADV_LAUNCH_ROWS(pgd_l2_project_kernel, vec, B, T, st, adv + b0 * T, grad + b0 * T, orig + b0 * T, out + b0 * T, T,
+                    alpha, eps, eps_div, lo, hi, w.p0 + b0 * C, w.p1 + b0 * C, dnorm ? dnorm + b0 : nullptr);
+    return status_after_launch();
+}
+
+int advstep_cw_init_w_f32(const float *x, float *w, int64_t n, advstep_stream_t stream) {
+    ADV_REQUIRE(n >= 0);
+    if (n == 0) return ADVSTEP_OK;
+    ADV_REQUIRE(x && w);
+    return launch_flat<1>(x, nullptr, nullptr, w, n, CwInitOp{}, as_stream(stream));
+}
+
+int advstep_cw_tanh_sqdist_f32(const float *w, const float *x, float *adv, float *l2, int64_t B, int64_t T, void *ws,
+                               size_t ws_bytes, advstep_stream_t stream) {
+    ADV_REQUIRE(B >= 0 && T >= 0);
+    if (B == 0 || T == 0) return ADVSTEP_OK;
+    ADV_REQUIRE(w && x && adv && l2);
+    RowWs wsp;
+    if (!carve_ws(ws, ws_bytes, B, T, &wsp)) return ADVSTEP_EWORKSPACE;
+    hipStream_t st = as_stream(stream);
+    const bool vec = rows_vec(T, {w, x, adv});
+    const int C = tiles_per_row(T);
+    ADV_LAUNCH_ROWS(cw_tanh_sqdist_kernel, vec, B, T, st, w + b0 * T, x + b0 * T, adv + b0 * T, T, wsp.p0 + b0 * C);
+    hipLaunchKernelGGL(row_partials_sum_kernel, dim3((unsigned)B), dim3(64), 0, st, wsp.p0, C, l2);
+    return status_after_launch();
+}
+
+int advstep_cw_adam_step_f32(float *w, float *m, float *v, const float *x, const float *grad_adv, int64_t n,
+                             int64_t step, double lr, double beta1, double beta2, double adam_eps,
+                             advstep_stream_t stream) {
+    ADV_REQUIRE(n >= 0 && step >= 1);
+    if (n == 0) return ADVSTEP_OK;
+    ADV_REQUIRE(w && m && v && x && grad_adv);
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2 = 1.0 - pow(beta2, (double)step);
+    AdamScalars s;
+    s.w1 = (float)(1.0 - beta1);
+    s.beta2 = (float)beta2;
+    s.omb2 = (float)(1.0 - beta2);
+    s.neg_step = (float)(-(lr / bc1));
+    s.bc2_sqrt = (float)sqrt(bc2);
+    s.eps = (float)adam_eps;
+    hipStream_t st = as_stream(stream);
+    const bool vec = aligned16(w) && aligned16(m) && aligned16(v) && aligned16(x) && aligned16(grad_adv);
+    const int64_t n4 = vec ? n / 4 : 0;
+    if (n4 > 0) {
+        const int64_t ntiles = ceil_div(n4, kTileVec);
+        const int grid = (int)(ntiles < kMaxGrid ? ntiles : kMaxGrid);
+        hipLaunchKernelGGL(cw_adam_vec_kernel, dim3(grid), dim3(kBlock), 0, st, reinterpret_cast<float4 *>(w),
+                           reinterpret_cast<float4 *>(m), reinterpret_cast<float4 *>(v),
+                           reinterpret_cast<const float4 *>(x), reinterpret_cast<const float4 *>(grad_adv), n4, ntiles,
+                           s);
+    }
+    const int64_t begin = n4 * 4;
+    if (begin < n) {
+        const int64_t blocks = ceil_div(n - begin, kBlock);
+        const int grid = (int)(blocks < kMaxGrid ? blocks : kMaxGrid);
+        hipLaunchKernelGGL(cw_adam_scalar_kernel, dim3(grid), dim3(kBlock), 0, st, w, m, v, x, grad_adv, begin, n, s);
+    }
+    return status_after_launch();
+}
+
+int advstep_cw_best_update_f32(const float *adv, const float *mask, float *best, int64_t B, int64_t T,
+                               advstep_stream_t stream) {
+    ADV_REQUIRE(B >= 0 && T >= 0);
+    if (B == 0 || T == 0) return ADVSTEP_OK;
+    ADV_REQUIRE(adv && mask && best);
+    hipStream_t st = as_stream(stream);
+    const bool vec = rows_vec(T, {adv, best});
+    ADV_LAUNCH_ROWS(cw_best_update_kernel, vec, B, T, st, adv + b0 * T, mask + b0, best + b0 * T, T);
+    return status_after_launch();
+}
+
+int advstep_ce2_loss_grad_f32(const float *z, const int64_t *labels, float *dz, float *loss, int64_t B, float scale,
+                              advstep_stream_t stream) {
+    ADV_REQUIRE(B >= 1);
+    ADV_REQUIRE(z && labels && dz && loss);
+    hipLaunchKernelGGL(ce2_loss_grad_kernel, dim3(1), dim3(kBlock), 0, as_stream(stream), z, labels, dz, loss, B,
+                       scale);
+    return status_after_launch();
+}
+
+}  // extern "C"

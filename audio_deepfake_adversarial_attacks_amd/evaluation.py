@@ -1,0 +1,217 @@
+"""The adversarial-evaluation loop (reference: evaluate_models_on_adversarial_attacks.py:146-298).
+
+`generate_attacks` keeps the reference's signature and per-batch order of operations
+(min-max -> attack -> revert -> target forward -> sigmoid / threshold -> accumulate -> final report) and its
+log line.  What is different is how the work is placed on the machine:
+
+  * one process per GPU instead of `nn.DataParallel` (reference :163,:167): every rank owns a replica of both
+    models and a CONTIGUOUS slice of each global batch — the same chunking DataParallel's scatter would do, so
+    the LFCC batch-wide dB floor sees the same rows — and there is NO per-step traffic between GPUs;
+  * scores stay on the device until the end (the reference synchronises with `.item()` / `.cpu()` every batch,
+    :261-265); one D2H copy per run;
+  * the final aggregate is the only communication: an all-reduce(SUM) of the two counters and one all-gather of
+    the packed (score, predicted label, label) rows over RCCL/xGMI (`backend="nccl"`), or gloo on CPU tests.
+"""
+from __future__ import annotations
+
+import logging
+import os
+from typing import Any, Callable, Dict, Iterator, List, Optional, Tuple, Union
+
+import numpy as np
+import torch
+import torch.distributed as dist
+from torch.utils.data import DataLoader, Dataset, Sampler
+
+from . import metrics
+from .aa import utils as aa_utils
+from .datasets.synthetic import SyntheticDetectionDataset
+from .utils import load_model
+
+LOGGER = logging.getLogger()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# ranks and shards
+# ---------------------------------------------------------------------------------------------------------
+
+def rank_and_world() -> Tuple[int, int]:
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard_bounds(n: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous [lo, hi) of rank `rank` when n rows are cut into `world` chunks (torch.chunk / DataParallel
+    scatter semantics: every chunk has ceil(n / world) rows except possibly the last ones)."""
+    per = -(-n // world)
+    lo = min(rank * per, n)
+    return lo, min(lo + per, n)
+
+
+class ShardedBatchSampler(Sampler[List[int]]):
+    """Yields, for every GLOBAL batch (drop_last=True as in the reference's DataLoader, :197-203), the indices
+    of this rank's contiguous slice.  The permutation comes from a dedicated generator seeded identically on
+    every rank, so all ranks agree on the global batches without communicating."""
+
+    def __init__(self, n_items: int, global_batch: int, rank: int = 0, world: int = 1, shuffle: bool = True,
+                 seed: int = 42):
+        if global_batch % world != 0:
+            raise ValueError(f"global batch {global_batch} is not divisible by world size {world}")
+        self.n_items, self.global_batch, self.rank, self.world = n_items, global_batch, rank, world
+        self.shuffle, self.seed = shuffle, seed
+
+    def __len__(self) -> int:
+        return self.n_items // self.global_batch
+
+    def __iter__(self) -> Iterator[List[int]]:
+        if self.shuffle:
+            order = torch.randperm(self.n_items, generator=torch.Generator().manual_seed(self.seed)).tolist()
+        else:
+            order = list(range(self.n_items))
+        lo, hi = shard_bounds(self.global_batch, self.rank, self.world)
+        for b in range(len(self)):
+            batch = order[b * self.global_batch:(b + 1) * self.global_batch]
+            yield batch[lo:hi]
+
+
+def aggregate_across_ranks(y_pred: torch.Tensor, y_pred_label: torch.Tensor, y: torch.Tensor,
+                           num_correct: torch.Tensor, num_total: torch.Tensor):
+    """End-of-run exchange.  Inputs are this rank's 1-D tensors / 0-d counters on the
+    compute device; returns numpy arrays for the whole job, ordered by rank, plus the two global counters."""
+    rank, world = rank_and_world()
+    packed = torch.stack([y_pred.float(), y_pred_label.float(), y.float()], dim=1).contiguous()  # (n_local, 3)
+    counters = torch.stack([num_correct.to(torch.int64), num_total.to(torch.int64)])
+    if world > 1:
+        dist.all_reduce(counters, op=dist.ReduceOp.SUM)
+        parts = [torch.empty_like(packed) for _ in range(world)]
+        dist.all_gather(parts, packed)
+        packed = torch.cat(parts, dim=0)
+    host = packed.cpu().numpy()
+    c = counters.cpu().numpy()
+    return host[:, 0].astype(np.float32), host[:, 1].astype(np.int32), host[:, 2].astype(np.int64), int(c[0]), int(c[1])
+
+
+# ---------------------------------------------------------------------------------------------------------
+# per-batch body
+# ---------------------------------------------------------------------------------------------------------
+
+def attack_batch(atk, batch_x: torch.Tensor, batch_y: torch.Tensor) -> torch.Tensor:
+    """Reference :218-221 — normalise each utterance to [0, 1], attack, map back to the original range."""
+    x01, mn, mx = aa_utils.to_minmax(batch_x)
+    adv01 = atk(x01, batch_y)
+    return aa_utils.revert_minmax(adv01, mn, mx)
+
+
+@torch.no_grad()
+def score_batch(model, batch_x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Reference :236-238 — probability of the bonafide class and the hard label ((p + .5).int() == p >= .5)."""
+    preds = torch.sigmoid(model(batch_x).squeeze(1).detach())
+    return preds, (preds + 0.5).int()
+
+
+def format_report(report: Dict[str, float]) -> str:
+    """The reference's final log line (:295-298)."""
+    order = ("eer", "accuracy", "precision", "recall", "f1_score", "auc")
+    return ", ".join(f"adv_eval/{k}: {report['adv_eval/' + k]:.4f}" for k in order)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the loop
+# ---------------------------------------------------------------------------------------------------------
+
+def generate_attacks(
+    datasets_paths: List[Union[str, os.PathLike, None]],
+    model_config: Dict,
+    device: str,
+    attack_model_config: Optional[Dict] = None,
+    attack_method: Optional[Any] = None,
+    attack_params: Dict = {},
+    amount_to_use: Optional[int] = None,
+    batch_size: int = 64,
+    on_attack_end_callback: Optional[Callable] = None,
+    raw_sample_from_dataset: bool = False,
+    dataset: Optional[Dataset] = None,
+    share_weights: bool = False,
+    shuffle: bool = True,
+    num_workers: int = 0,
+) -> Dict[str, float]:
+    """Reference signature (:146-157) plus additive keywords: `dataset` (a ready Dataset yielding the reference's
+    4-tuple; the real-corpus `DetectionDataset` is out of scope, so one must be supplied or `amount_to_use`
+    synthetic utterances are generated), `share_weights` (white-box runs without checkpoints: copy the target's
+    weights into the attack model), `shuffle`, `num_workers`.  `batch_size` is the GLOBAL batch."""
+    rank, world = rank_and_world()
+    LOGGER.info("Loading data...")
+
+    model = load_model(model_config, device)                       # :162  (no DataParallel: one process per GPU)
+    if attack_model_config is not None and attack_method is not None:
+        attack_model = load_model(attack_model_config, device)     # :166
+        if share_weights:
+            attack_model.load_state_dict(model.state_dict())
+        atk = attack_method(attack_model, **attack_params)         # :169
+        atk.set_training_mode(model_training=True, batchnorm_training=False)  # :170
+    else:
+        attack_model, atk = None, None
+
+    if raw_sample_from_dataset:
+        raise NotImplementedError("--raw_from_dataset needs the SoX-based WaveFake preprocessing of the real-corpus "
+                                  "dataset (src/datasets/base_dataset.py:122-148), which is outside the hot-path scope")
+    if dataset is None:
+        dataset = SyntheticDetectionDataset(amount_to_use if amount_to_use else 4 * batch_size)
+    data_val = dataset
+
+    LOGGER.info(f"Testing '{model.__class__.__name__}' model, weights path: '{model.weights_path}', "
+                f"on {len(data_val)} audio files.")
+    if attack_model is not None:
+        LOGGER.info(f"Attack using '{attack_model.__class__.__name__}' model and '{atk.__class__.__name__}' method "
+                    f"({attack_params}), weights path: '{attack_model.weights_path}'")
+    else:
+        LOGGER.info("No attack applied")
+
+    seed = model_config.get("data", {}).get("seed", 42)
+    sampler = ShardedBatchSampler(len(data_val), batch_size, rank, world, shuffle=shuffle, seed=seed)
+    test_loader = DataLoader(data_val, batch_sampler=sampler, num_workers=num_workers)
+    if world > 1:
+        # decorrelate the random starts of different ranks (all ranks were seeded alike to build equal replicas)
+        torch.manual_seed(seed + rank)
+
+    num_correct = torch.zeros((), dtype=torch.int64, device=device)
+    num_total = torch.zeros((), dtype=torch.int64, device=device)
+    y_pred, y_pred_label, y = [], [], []
+
+    for batch_x, batch_sr, batch_y, batch_metadata in test_loader:
+        model.eval()
+        batch_x = batch_x.to(device, non_blocking=True)
+        batch_y = batch_y.to(device, non_blocking=True)
+        num_total += batch_x.size(0)
+
+        if attack_model is not None:
+            batch_x_attacked = attack_batch(atk, batch_x, batch_y)
+        else:
+            batch_x_attacked = torch.clone(batch_x)
+
+        batch_preds, batch_preds_label = score_batch(model, batch_x_attacked)
+
+        if on_attack_end_callback is not None:  # :240-259
+            batch_preds_noattack, batch_preds_noattack_label = score_batch(model, batch_x)
+            on_attack_end_callback(batch_x=batch_x, batch_x_attacked=batch_x_attacked, batch_y=batch_y,
+                                   batch_preds_label=batch_preds_label, batch_preds=batch_preds,
+                                   batch_preds_noattack_label=batch_preds_noattack_label,
+                                   batch_preds_noattack=batch_preds_noattack, batch_metadata=batch_metadata)
+
+        num_correct += (batch_preds_label == batch_y.int()).sum()
+        y_pred.append(batch_preds)
+        y_pred_label.append(batch_preds_label)
+        y.append(batch_y)
+
+    if not y:
+        raise ValueError(f"no complete batch: {len(data_val)} items < global batch {batch_size} (drop_last=True)")
+    all_pred, all_label, all_y, n_correct, n_total = aggregate_across_ranks(
+        torch.cat(y_pred), torch.cat(y_pred_label), torch.cat(y), num_correct, num_total)
+
+    report = metrics.adversarial_report(all_y, all_pred, all_label)
+    report["adv_eval/accuracy"] = (n_correct / n_total) * 100  # :267 (from the all-reduced counters)
+    report["num_total"] = n_total
+    if rank == 0:
+        LOGGER.info(format_report(report))
+    return report

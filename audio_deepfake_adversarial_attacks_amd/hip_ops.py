@@ -1,0 +1,326 @@
+"""Torch-facing wrappers of the C ABI (include/advstep.h): device tensors in, raw pointers + HIP stream out.
+
+PyTorch is used for plumbing only — device memory, the current HIP stream, autograd around the model.  Every
+function requires contiguous float32 tensors that live on a HIP device and launches on torch's *current*
+stream of that device, so the kernels are ordered with the model's forward/backward work without any
+synchronisation.  There is NO CPU path here: a CPU tensor, a missing libadvstep.so or a non-zero status
+raises.
+
+Reference op chains replaced (see the header for line-by-line citations):
+  to_minmax / revert_minmax          src/aa/utils.py:4-14
+  fgsm_step                          adversarial_attacks/torchattacks/attacks/fgsm.py:59-60
+  pgd_linf_init / pgd_linf_step      .../attacks/pgd.py:54-57, 74-76
+  pgd_l2_init / pgd_l2_step          .../attacks/pgdl2.py:55-62, 78-88
+  cw_*                               .../attacks/cw.py:57, 72-77, 87-103
+  ce2_loss_grad                      .../attacks/pgd.py:62,50,68 (and the same lines of fgsm.py / pgdl2.py)
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import _lib
+
+NAME = "hip"
+
+# ---------------------------------------------------------------------------------------------------------
+# plumbing
+# ---------------------------------------------------------------------------------------------------------
+
+_workspaces: Dict[Tuple[int, int], torch.Tensor] = {}
+_profile: Optional[Dict[str, List[Tuple[torch.cuda.Event, torch.cuda.Event]]]] = None
+
+
+def _require(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor, got {type(t).__name__}")
+    if not t.is_cuda:
+        raise _lib.AdvstepError(
+            f"{name}: tensor lives on '{t.device}'. The attack kernels run only on a HIP device "
+            "(there is no CPU fallback in this package; the CPU restatement is the test-only oracle/ tree).")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: tensor must be contiguous")
+    return t
+
+
+def _same_shape(*named) -> None:
+    first_name, first = named[0]
+    for name, t in named[1:]:
+        if t.shape != first.shape or t.device != first.device:
+            raise ValueError(f"{name} {tuple(t.shape)}@{t.device} does not match {first_name} "
+                             f"{tuple(first.shape)}@{first.device}")
+
+
+def _rows(t: torch.Tensor, name: str) -> Tuple[int, int]:
+    if t.dim() < 2:
+        raise ValueError(f"{name}: expected (B, ...) with at least 2 dims, got {tuple(t.shape)}")
+    B = t.shape[0]
+    return B, (t.numel() // B if B else 0)
+
+
+def _stream(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _workspace(device: torch.device, B: int, T: int) -> Tuple[int, int]:
+    need = _lib.load().advstep_row_workspace_bytes(B, T)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), _stream(device))
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(need, 1 << 16), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws.data_ptr(), ws.numel()
+
+
+def _out_like(ref: torch.Tensor, out: Optional[torch.Tensor], name: str = "out") -> torch.Tensor:
+    if out is None:
+        return torch.empty_like(ref, memory_format=torch.contiguous_format)
+    _require(out, name)
+    _same_shape(("input", ref), (name, out))
+    return out
+
+
+class _Launch:
+    """Device guard + optional HIP-event bracket around one C-ABI call (events sit on the launch stream)."""
+
+    def __init__(self, name: str, device: torch.device):
+        self.name, self.device = name, device
+        self.guard = torch.cuda.device(device)
+
+    def __enter__(self):
+        self.guard.__enter__()
+        self.pair = None
+        if _profile is not None and self.name in _profile:
+            self.pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            self.pair[0].record(torch.cuda.current_stream(self.device))
+        return self
+
+    def __exit__(self, *exc):
+        if self.pair is not None:
+            self.pair[1].record(torch.cuda.current_stream(self.device))
+            _profile[self.name].append(self.pair)
+        return self.guard.__exit__(*exc)
+
+
+def start_profile(*entry_points: str) -> None:
+    """Bracket every later launch of the named entry points with HIP events on their launch stream."""
+    global _profile
+    _profile = {n: [] for n in entry_points}
+
+
+def stop_profile() -> Dict[str, List[float]]:
+    """Synchronise and return {entry point: [milliseconds per launch]}."""
+    global _profile
+    prof, _profile = _profile or {}, None
+    torch.cuda.synchronize()
+    return {n: [a.elapsed_time(b) for a, b in pairs] for n, pairs in prof.items()}
+
+
+# ---------------------------------------------------------------------------------------------------------
+# a1 / a2
+# ---------------------------------------------------------------------------------------------------------
+
+def to_minmax(batch_x: torch.Tensor):
+    """src/aa/utils.py:4-9 — returns (x01 (B,T), mn (B,1), mx (B,1))."""
+    x = _require(batch_x, "batch_x")
+    B, T = _rows(x, "batch_x")
+    x01 = torch.empty_like(x)
+    mn = torch.empty((B, 1), dtype=torch.float32, device=x.device)
+    mx = torch.empty((B, 1), dtype=torch.float32, device=x.device)
+    with _Launch("minmax_normalize", x.device):
+        ws, ws_bytes = _workspace(x.device, B, T)
+        st = _lib.load().advstep_minmax_normalize_f32(x.data_ptr(), x01.data_ptr(), mn.data_ptr(), mx.data_ptr(), B, T,
+                                                      ws, ws_bytes, _stream(x.device))
+    _lib.check(st, "advstep_minmax_normalize_f32")
+    return x01, mn, mx
+
+
+def revert_minmax(batch_x: torch.Tensor, mn: torch.Tensor, mx: torch.Tensor, out: Optional[torch.Tensor] = None):
+    """src/aa/utils.py:12-14."""
+    x = _require(batch_x, "batch_x")
+    B, T = _rows(x, "batch_x")
+    _require(mn, "mn"), _require(mx, "mx")
+    if mn.numel() != B or mx.numel() != B:
+        raise ValueError(f"mn/mx must hold one value per row ({B}), got {mn.numel()} / {mx.numel()}")
+    out = _out_like(x, out)
+    with _Launch("minmax_revert", x.device):
+        st = _lib.load().advstep_minmax_revert_f32(x.data_ptr(), mn.data_ptr(), mx.data_ptr(), out.data_ptr(), B, T,
+                                                   _stream(x.device))
+    _lib.check(st, "advstep_minmax_revert_f32")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------
+# a4 / a5
+# ---------------------------------------------------------------------------------------------------------
+
+def fgsm_step(x, grad, eps: float, lo: float = 0.0, hi: float = 1.0, out=None):
+    _require(x, "x"), _require(grad, "grad")
+    _same_shape(("x", x), ("grad", grad))
+    out = _out_like(x, out)
+    with _Launch("fgsm_step", x.device):
+        st = _lib.load().advstep_fgsm_step_f32(x.data_ptr(), grad.data_ptr(), out.data_ptr(), x.numel(), eps, lo, hi,
+                                               _stream(x.device))
+    _lib.check(st, "advstep_fgsm_step_f32")
+    return out
+
+
+def pgd_linf_init(x, eps: float, noise=None, seed: Optional[int] = None, offset: int = 0, lo: float = 0.0,
+                  hi: float = 1.0, out=None):
+    """Random start of pgd.py:54-57.  `noise` (the caller's U(-eps, eps) draw) or a Philox `seed`."""
+    _require(x, "x")
+    out = _out_like(x, out)
+    if noise is not None:
+        _require(noise, "noise")
+        _same_shape(("x", x), ("noise", noise))
+        with _Launch("pgd_linf_init", x.device):
+            st = _lib.load().advstep_pgd_linf_init_noise_f32(x.data_ptr(), noise.data_ptr(), out.data_ptr(), x.numel(),
+                                                             lo, hi, _stream(x.device))
+        _lib.check(st, "advstep_pgd_linf_init_noise_f32")
+    else:
+        if seed is None:
+            raise ValueError("pgd_linf_init needs either `noise` or a Philox `seed`")
+        with _Launch("pgd_linf_init", x.device):
+            st = _lib.load().advstep_pgd_linf_init_philox_f32(x.data_ptr(), out.data_ptr(), x.numel(), eps, lo, hi,
+                                                              seed, offset, _stream(x.device))
+        _lib.check(st, "advstep_pgd_linf_init_philox_f32")
+    return out
+
+
+def pgd_linf_step(adv, grad, orig, alpha: float, eps: float, lo: float = 0.0, hi: float = 1.0, out=None):
+    _require(adv, "adv"), _require(grad, "grad"), _require(orig, "orig")
+    _same_shape(("adv", adv), ("grad", grad), ("orig", orig))
+    out = _out_like(adv, out)
+    with _Launch("pgd_linf_step", adv.device):
+        st = _lib.load().advstep_pgd_linf_step_f32(adv.data_ptr(), grad.data_ptr(), orig.data_ptr(), out.data_ptr(),
+                                                   adv.numel(), alpha, eps, lo, hi, _stream(adv.device))
+    _lib.check(st, "advstep_pgd_linf_step_f32")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------
+# a6
+# ---------------------------------------------------------------------------------------------------------
+
+def pgd_l2_init(x, eps: float, draws=None, seed: Optional[int] = None, offset: int = 0, lo: float = 0.0,
+                hi: float = 1.0, out=None):
+    """Random start of pgdl2.py:55-62.  `draws` = (normal (B,T), r (B)) or a Philox `seed`."""
+    _require(x, "x")
+    B, T = _rows(x, "x")
+    out = _out_like(x, out)
+    with _Launch("pgd_l2_init", x.device):
+        ws, ws_bytes = _workspace(x.device, B, T)
+        if draws is not None:
+            normal, r = draws
+            _require(normal, "normal"), _require(r, "r")
+            _same_shape(("x", x), ("normal", normal))
+            if r.numel() != B:
+                raise ValueError(f"r must hold one value per row ({B}), got {r.numel()}")
+            st = _lib.load().advstep_pgd_l2_init_noise_f32(x.data_ptr(), normal.data_ptr(), r.data_ptr(), out.data_ptr(),
+                                                           B, T, eps, lo, hi, ws, ws_bytes, _stream(x.device))
+            what = "advstep_pgd_l2_init_noise_f32"
+        else:
+            if seed is None:
+                raise ValueError("pgd_l2_init needs either `draws` or a Philox `seed`")
+            st = _lib.load().advstep_pgd_l2_init_philox_f32(x.data_ptr(), out.data_ptr(), B, T, eps, lo, hi, seed,
+                                                            offset, ws, ws_bytes, _stream(x.device))
+            what = "advstep_pgd_l2_init_philox_f32"
+    _lib.check(st, what)
+    return out
+
+
+def pgd_l2_step(adv, grad, orig, alpha: float, eps: float, eps_div: float = 1e-10, lo: float = 0.0, hi: float = 1.0,
+                out=None, return_norms: bool = False):
+    _require(adv, "adv"), _require(grad, "grad"), _require(orig, "orig")
+    _same_shape(("adv", adv), ("grad", grad), ("orig", orig))
+    B, T = _rows(adv, "adv")
+    out = _out_like(adv, out)
+    gn = dn = None
+    if return_norms:
+        gn = torch.empty(B, dtype=torch.float32, device=adv.device)
+        dn = torch.empty(B, dtype=torch.float32, device=adv.device)
+    with _Launch("pgd_l2_step", adv.device):
+        ws, ws_bytes = _workspace(adv.device, B, T)
+        st = _lib.load().advstep_pgd_l2_step_f32(adv.data_ptr(), grad.data_ptr(), orig.data_ptr(), out.data_ptr(), B, T,
+                                                 alpha, eps, eps_div, lo, hi, gn.data_ptr() if return_norms else None,
+                                                 dn.data_ptr() if return_norms else None, ws, ws_bytes,
+                                                 _stream(adv.device))
+    _lib.check(st, "advstep_pgd_l2_step_f32")
+    return (out, gn, dn) if return_norms else out
+
+
+# ---------------------------------------------------------------------------------------------------------
+# a7
+# ---------------------------------------------------------------------------------------------------------
+
+def cw_init_w(x, out=None):
+    _require(x, "x")
+    out = _out_like(x, out)
+    with _Launch("cw_init_w", x.device):
+        st = _lib.load().advstep_cw_init_w_f32(x.data_ptr(), out.data_ptr(), x.numel(), _stream(x.device))
+    _lib.check(st, "advstep_cw_init_w_f32")
+    return out
+
+
+def cw_tanh_sqdist(w, x, adv_out=None):
+    """Returns (adv = 1/2 (tanh w + 1), l2 (B) = row sums of (adv - x)^2)."""
+    _require(w, "w"), _require(x, "x")
+    _same_shape(("w", w), ("x", x))
+    B, T = _rows(w, "w")
+    adv = _out_like(w, adv_out, "adv_out")
+    l2 = torch.empty(B, dtype=torch.float32, device=w.device)
+    with _Launch("cw_tanh_sqdist", w.device):
+        ws, ws_bytes = _workspace(w.device, B, T)
+        st = _lib.load().advstep_cw_tanh_sqdist_f32(w.data_ptr(), x.data_ptr(), adv.data_ptr(), l2.data_ptr(), B, T, ws,
+                                                    ws_bytes, _stream(w.device))
+    _lib.check(st, "advstep_cw_tanh_sqdist_f32")
+    return adv, l2
+
+
+def cw_adam_step(w, m, v, x, grad_adv, step: int, lr: float = 0.01, beta1: float = 0.9, beta2: float = 0.999,
+                 adam_eps: float = 1e-8) -> None:
+    """In-place Adam step on (w, m, v); `step` is 1-based."""
+    for name, t in (("w", w), ("m", m), ("v", v), ("x", x), ("grad_adv", grad_adv)):
+        _require(t, name)
+    _same_shape(("w", w), ("m", m), ("v", v), ("x", x), ("grad_adv", grad_adv))
+    with _Launch("cw_adam_step", w.device):
+        st = _lib.load().advstep_cw_adam_step_f32(w.data_ptr(), m.data_ptr(), v.data_ptr(), x.data_ptr(),
+                                                  grad_adv.data_ptr(), w.numel(), step, lr, beta1, beta2, adam_eps,
+                                                  _stream(w.device))
+    _lib.check(st, "advstep_cw_adam_step_f32")
+
+
+def cw_best_update(adv, mask, best) -> None:
+    """In place: best = mask * adv + (1 - mask) * best, mask (B) float32 in {0, 1}."""
+    _require(adv, "adv"), _require(mask, "mask"), _require(best, "best")
+    _same_shape(("adv", adv), ("best", best))
+    B, T = _rows(adv, "adv")
+    if mask.numel() != B:
+        raise ValueError(f"mask must hold one value per row ({B}), got {mask.numel()}")
+    with _Launch("cw_best_update", adv.device):
+        st = _lib.load().advstep_cw_best_update_f32(adv.data_ptr(), mask.data_ptr(), best.data_ptr(), B, T,
+                                                    _stream(adv.device))
+    _lib.check(st, "advstep_cw_best_update_f32")
+
+
+# ---------------------------------------------------------------------------------------------------------
+# a8
+# ---------------------------------------------------------------------------------------------------------
+
+def ce2_loss_grad(z, labels, scale: float = 1.0):
+    """CE(cat([-z, z], 1), labels) (mean) in closed form: returns (d cost / d z shaped like z, cost (1,))."""
+    _require(z, "z")
+    _require(labels, "labels", torch.int64)
+    B = z.numel()
+    if labels.numel() != B:
+        raise ValueError(f"labels must hold one value per logit ({B}), got {labels.numel()}")
+    dz = torch.empty_like(z)
+    loss = torch.empty(1, dtype=torch.float32, device=z.device)
+    with _Launch("ce2_loss_grad", z.device):
+        st = _lib.load().advstep_ce2_loss_grad_f32(z.data_ptr(), labels.data_ptr(), dz.data_ptr(), loss.data_ptr(), B,
+                                                   scale, _stream(z.device))
+    _lib.check(st, "advstep_ce2_loss_grad_f32")
+    return dz, loss

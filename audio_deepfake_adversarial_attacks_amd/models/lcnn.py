@@ -1,0 +1,127 @@
+"""LCNN detector (reference: src/models/lcnn.py:24-243; upstream ASVspoof2021 LFCC-LCNN baseline).
+
+Same architecture, same `state_dict` key names (`m_transform.<i>.*`, `m_before_pooling.<i>.l_blstm.*`,
+`m_output_act.*`, `frontend.*`), so reference checkpoints load unchanged.  Forward + input-backward run
+under PyTorch-ROCm (MIOpen convolutions / RNN); tests/test_models.py pins `BaseLCNN` against logits and input
+gradients produced by the reference's own BaseLCNN (tests/golden/lcnn_body.npz)."""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from .. import frontends
+
+
+class BLSTMLayer(nn.Module):
+    """Bidirectional LSTM that keeps (batch, length, dim) on both sides (lcnn.py:24-46)."""
+
+    def __init__(self, input_dim: int, output_dim: int):
+        super().__init__()
+        if output_dim % 2 != 0:
+            raise ValueError(f"BLSTMLayer expects an even layer size, got {output_dim}")
+        self.l_blstm = nn.LSTM(input_dim, output_dim // 2, bidirectional=True)
+
+    def forward(self, x):
+        out, _ = self.l_blstm(x.permute(1, 0, 2))  # the LSTM is sequence-first
+        return out.permute(1, 0, 2)
+
+
+class MaxFeatureMap2D(nn.Module):
+    """Max-feature-map: split `max_dim` in two halves and keep the element-wise maximum (lcnn.py:49-95)."""
+
+    def __init__(self, max_dim: int = 1):
+        super().__init__()
+        self.max_dim = max_dim
+
+    def forward(self, inputs):
+        shape = list(inputs.size())
+        if self.max_dim >= len(shape):
+            raise ValueError(f"MaxFeatureMap: cannot maximise dim {self.max_dim} of a {len(shape)}-d input")
+        if shape[self.max_dim] % 2 != 0:
+            raise ValueError(f"MaxFeatureMap: dim {self.max_dim} has an odd size {shape[self.max_dim]}")
+        shape[self.max_dim] //= 2
+        shape.insert(self.max_dim, 2)
+        return inputs.view(*shape).max(self.max_dim)[0]
+
+
+# (kind, args) rows of `m_transform`, in the reference's order so the Sequential indices (= state_dict keys)
+# match lcnn.py:120-157.  conv: (in, out, kernel, padding); bn: channels (affine=False).
+_TRANSFORM = (
+    ("conv", (None, 64, 5, 2)), ("mfm",), ("pool",),
+    ("conv", (32, 64, 1, 0)), ("mfm",), ("bn", 32),
+    ("conv", (32, 96, 3, 1)), ("mfm",), ("pool",), ("bn", 48),
+    ("conv", (48, 96, 1, 0)), ("mfm",), ("bn", 48),
+    ("conv", (48, 128, 3, 1)), ("mfm",), ("pool",),
+    ("conv", (64, 128, 1, 0)), ("mfm",), ("bn", 64),
+    ("conv", (64, 64, 3, 1)), ("mfm",), ("bn", 32),
+    ("conv", (32, 64, 1, 0)), ("mfm",), ("bn", 32),
+    ("conv", (32, 64, 3, 1)), ("mfm",), ("pool",),
+    ("dropout", 0.7),
+)
+
+
+def _make_transform(input_channels: int) -> nn.Sequential:
+    layers = []
+    for row in _TRANSFORM:
+        kind = row[0]
+        if kind == "conv":
+            cin, cout, k, pad = row[1]
+            layers.append(nn.Conv2d(input_channels if cin is None else cin, cout, (k, k), 1, padding=(pad, pad)))
+        elif kind == "mfm":
+            layers.append(MaxFeatureMap2D())
+        elif kind == "pool":
+            layers.append(nn.MaxPool2d((2, 2), (2, 2)))
+        elif kind == "bn":
+            layers.append(nn.BatchNorm2d(row[1], affine=False))
+        else:
+            layers.append(nn.Dropout(row[1]))
+    return nn.Sequential(*layers)
+
+
+class BaseLCNN(nn.Module):
+    """Spectrogram (B, C, n_coeff, frames) -> logit (B, 1)   (lcnn.py:102-217)."""
+
+    def __init__(self, **kwargs):
+        super().__init__()
+        input_channels = kwargs.get("input_channels", 1)
+        self.num_coefficients = kwargs.get("num_coefficients", 80)
+        self.v_emd_dim = 1
+
+        self.m_transform = _make_transform(input_channels)
+        width = (self.num_coefficients // 16) * 32
+        self.m_before_pooling = nn.Sequential(BLSTMLayer(width, width), BLSTMLayer(width, width))
+        self.m_output_act = nn.Linear(width, self.v_emd_dim)
+
+    def _compute_embedding(self, x):
+        batch_size = x.shape[0]
+        # (B, C, coeff, frames) -> (B, C, frames, coeff) -> conv trunk -> (B, frames', C' * coeff')   (:190-199)
+        hidden = self.m_transform(x.permute(0, 1, 3, 2))
+        hidden = hidden.permute(0, 2, 1, 3).contiguous()
+        hidden = hidden.view(batch_size, hidden.shape[1], -1)
+        # two BLSTMs with a skip connection, mean over frames, linear read-out   (:202-205)
+        lstm = self.m_before_pooling(hidden)
+        return self.m_output_act((lstm + hidden).mean(1))
+
+    def _compute_score(self, feature_vec):
+        return torch.sigmoid(feature_vec).squeeze(1)
+
+    def forward(self, x):
+        return self._compute_embedding(x)
+
+
+class LCNN(BaseLCNN):
+    """Waveform (B, T) -> logit (B, 1): frontend + BaseLCNN   (lcnn.py:221-243)."""
+
+    def __init__(self, device: str = "cuda", **kwargs):
+        super().__init__(**kwargs)
+        self.device = device
+        frontend_name = kwargs.get("frontend_algorithm", [])
+        self.frontend = frontends.get_frontend(frontend_name)
+        print(f"Using {frontend_name} frontend")
+
+    def _compute_frontend(self, x):
+        feats = self.frontend(x)
+        return feats.unsqueeze(1) if feats.ndim < 4 else feats  # (B, 1|n, n_coeff, frames)
+
+    def forward(self, x):
+        return self._compute_embedding(self._compute_frontend(x))

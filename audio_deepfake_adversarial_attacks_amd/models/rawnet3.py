@@ -1,0 +1,161 @@
+"""RawNet3 detector (reference: src/models/rawnet3.py:11-291): raw waveform (B, T) -> logit (B, 1).
+
+Pre-emphasis -> InstanceNorm -> parameterised sinc encoder -> log|.| -> mean-norm -> three Res2Net-style
+`Bottle2neck` blocks with AFMS -> 1x1 conv -> channel/context attentive statistics pooling -> BN -> FC.
+Module / parameter names follow the reference so its checkpoints load; everything after the sinc encoder
+is plain torch and runs forward + input-backward under PyTorch-ROCm (1x1 Conv1d = GEMMs on MFMA)."""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .sincfb import Encoder, ParamSincFB
+
+
+class PreEmphasis(nn.Module):
+    """y[t] = x[t] - coef * x[t-1] with reflect padding on the left (rawnet3.py:140-158)."""
+
+    def __init__(self, coef: float = 0.97) -> None:
+        super().__init__()
+        self.coef = coef
+        self.register_buffer("flipped_filter", torch.FloatTensor([-self.coef, 1.0]).unsqueeze(0).unsqueeze(0))
+
+    def forward(self, input: torch.Tensor) -> torch.Tensor:
+        assert len(input.size()) == 2, "The number of dimensions of input tensor must be 2!"
+        return F.conv1d(F.pad(input.unsqueeze(1), (1, 0), "reflect"), self.flipped_filter)
+
+
+class AFMS(nn.Module):
+    """Alpha-feature-map scaling: (x + alpha) * sigmoid(fc(mean_t x))   (rawnet3.py:161-182)."""
+
+    def __init__(self, nb_dim: int) -> None:
+        super().__init__()
+        self.alpha = nn.Parameter(torch.ones((nb_dim, 1)))
+        self.fc = nn.Linear(nb_dim, nb_dim)
+        self.sig = nn.Sigmoid()
+
+    def forward(self, x):
+        y = F.adaptive_avg_pool1d(x, 1).view(x.size(0), -1)
+        y = self.sig(self.fc(y)).view(x.size(0), x.size(1), -1)
+        return (x + self.alpha) * y
+
+
+class Bottle2neck(nn.Module):
+    """Res2Net bottleneck over time with hierarchical dilated convs (rawnet3.py:185-274)."""
+
+    def __init__(self, inplanes, planes, kernel_size=None, dilation=None, scale=4, pool=False):
+        super().__init__()
+        width = int(math.floor(planes / scale))
+        self.conv1 = nn.Conv1d(inplanes, width * scale, kernel_size=1)
+        self.bn1 = nn.BatchNorm1d(width * scale)
+        self.nums = scale - 1
+        pad = math.floor(kernel_size / 2) * dilation
+        self.convs = nn.ModuleList(
+            [nn.Conv1d(width, width, kernel_size=kernel_size, dilation=dilation, padding=pad) for _ in range(self.nums)])
+        self.bns = nn.ModuleList([nn.BatchNorm1d(width) for _ in range(self.nums)])
+        self.conv3 = nn.Conv1d(width * scale, planes, kernel_size=1)
+        self.bn3 = nn.BatchNorm1d(planes)
+        self.relu = nn.ReLU()
+        self.width = width
+        self.mp = nn.MaxPool1d(pool) if pool else False
+        self.afms = AFMS(planes)
+        if inplanes != planes:
+            self.residual = nn.Sequential(nn.Conv1d(inplanes, planes, kernel_size=1, stride=1, bias=False))
+        else:
+            self.residual = nn.Identity()
+
+    def forward(self, x):
+        residual = self.residual(x)
+        out = self.bn1(self.relu(self.conv1(x)))
+
+        groups = torch.split(out, self.width, 1)
+        pieces, carry = [], None
+        for i in range(self.nums):
+            carry = groups[i] if i == 0 else carry + groups[i]
+            carry = self.bns[i](self.relu(self.convs[i](carry)))
+            pieces.append(carry)
+        pieces.append(groups[self.nums])
+        out = torch.cat(pieces, 1)
+
+        out = self.bn3(self.relu(self.conv3(out)))
+        out = out + residual
+        if self.mp:
+            out = self.mp(out)
+        return self.afms(out)
+
+
+class RawNet3(nn.Module):
+    def __init__(self, block, model_scale, context, summed, C=1024, **kwargs):
+        super().__init__()
+        nOut = kwargs["nOut"]
+        self.context = context
+        self.encoder_type = kwargs["encoder_type"]
+        self.log_sinc = kwargs["log_sinc"]
+        self.norm_sinc = kwargs["norm_sinc"]
+        self.out_bn = kwargs["out_bn"]
+        self.summed = summed
+
+        self.preprocess = nn.Sequential(PreEmphasis(), nn.InstanceNorm1d(1, eps=1e-4, affine=True))
+        self.conv1 = Encoder(ParamSincFB(C // 4, 251, stride=kwargs["sinc_stride"]))
+        self.relu = nn.ReLU()
+        self.bn1 = nn.BatchNorm1d(C // 4)
+
+        self.layer1 = block(C // 4, C, kernel_size=3, dilation=2, scale=model_scale, pool=5)
+        self.layer2 = block(C, C, kernel_size=3, dilation=3, scale=model_scale, pool=3)
+        self.layer3 = block(C, C, kernel_size=3, dilation=4, scale=model_scale)
+        self.layer4 = nn.Conv1d(3 * C, 1536, kernel_size=1)
+
+        attn_input = 1536 * 3 if self.context else 1536
+        print("self.encoder_type", self.encoder_type)
+        if self.encoder_type == "ECA":
+            attn_output = 1536
+        elif self.encoder_type == "ASP":
+            attn_output = 1
+        else:
+            raise ValueError("Undefined encoder")
+
+        self.attention = nn.Sequential(
+            nn.Conv1d(attn_input, 128, kernel_size=1), nn.ReLU(), nn.BatchNorm1d(128),
+            nn.Conv1d(128, attn_output, kernel_size=1), nn.Softmax(dim=2))
+        self.bn5 = nn.BatchNorm1d(3072)
+        self.fc6 = nn.Linear(3072, nOut)
+        self.bn6 = nn.BatchNorm1d(nOut)
+        self.mp3 = nn.MaxPool1d(3)
+
+    def forward(self, x):
+        """x: (B, samples)   (rawnet3.py:73-137)."""
+        x = torch.abs(self.conv1(self.preprocess(x)))
+        if self.log_sinc:
+            x = torch.log(x + 1e-6)
+        if self.norm_sinc == "mean":
+            x = x - torch.mean(x, dim=-1, keepdim=True)
+        elif self.norm_sinc == "mean_std":
+            m = torch.mean(x, dim=-1, keepdim=True)
+            s = torch.std(x, dim=-1, keepdim=True).clamp(min=0.001)
+            x = (x - m) / s
+
+        x1 = self.layer1(x)
+        x2 = self.layer2(x1)
+        x3 = self.layer3(self.mp3(x1) + x2) if self.summed else self.layer3(x2)
+        x = self.relu(self.layer4(torch.cat((self.mp3(x1), x2, x3), dim=1)))
+
+        t = x.size()[-1]
+        if self.context:
+            mean = torch.mean(x, dim=2, keepdim=True).repeat(1, 1, t)
+            std = torch.sqrt(torch.var(x, dim=2, keepdim=True).clamp(min=1e-4, max=1e4)).repeat(1, 1, t)
+            global_x = torch.cat((x, mean, std), dim=1)
+        else:
+            global_x = x
+        w = self.attention(global_x)
+
+        mu = torch.sum(x * w, dim=2)
+        sg = torch.sqrt((torch.sum((x ** 2) * w, dim=2) - mu ** 2).clamp(min=1e-4, max=1e4))
+        x = self.fc6(self.bn5(torch.cat((mu, sg), 1)))
+        return self.bn6(x) if self.out_bn else x
+
+
+def prepare_model():
+    """rawnet3.py:277-291 — the configuration the repository uses."""
+    return RawNet3(Bottle2neck, model_scale=8, context=True, summed=True, encoder_type="ECA", nOut=1, out_bn=False,
+                   sinc_stride=10, log_sinc=True, norm_sinc="mean", grad_mult=1)

@@ -1,0 +1,114 @@
+"""SpecRNet detector (reference: src/models/specrnet.py:23-214; https://github.com/piotrkawa/specrnet).
+
+Same architecture and `state_dict` keys as the reference, including its two quirks: `Residual_block2D`
+feeds `conv1` with the block INPUT (the bn1/leaky-relu result is discarded, specrnet.py:75-81) and
+`get_config` is mutated while the blocks are built (:106-107).  Pinned against the reference's BaseSpecRNet
+logits in tests/test_models.py (tests/golden/specrnet_body.npz)."""
+from typing import Dict
+
+import torch.nn as nn
+
+from .. import frontends
+
+
+def get_config(input_channels: int) -> Dict:
+    return {
+        "filts": [input_channels, [input_channels, 20], [20, 64], [64, 64]],
+        "nb_fc_node": 64,
+        "gru_node": 64,
+        "nb_gru_layer": 2,
+        "nb_classes": 1,
+    }
+
+
+class Residual_block2D(nn.Module):
+    def __init__(self, nb_filts, first=False):
+        super().__init__()
+        cin, cout = nb_filts
+        self.first = first
+        if not first:
+            self.bn1 = nn.BatchNorm2d(num_features=cin)  # parameters exist (checkpoint keys); output unused
+        self.lrelu = nn.LeakyReLU(negative_slope=0.3)
+        self.conv1 = nn.Conv2d(cin, cout, kernel_size=3, padding=1, stride=1)
+        self.bn2 = nn.BatchNorm2d(num_features=cout)
+        self.conv2 = nn.Conv2d(cout, cout, kernel_size=3, padding=1, stride=1)
+        self.downsample = cin != cout
+        if self.downsample:
+            self.conv_downsample = nn.Conv2d(cin, cout, kernel_size=1, padding=0, stride=1)
+        self.mp = nn.MaxPool2d(2)
+
+    def forward(self, x):
+        # specrnet.py:73-91.  NB conv1 consumes x, not lrelu(bn1(x)) — reference behaviour, kept.
+        out = self.conv2(self.lrelu(self.bn2(self.conv1(x))))
+        identity = self.conv_downsample(x) if self.downsample else x
+        return self.mp(out + identity)
+
+
+class BaseSpecRNet(nn.Module):
+    """Spectrogram (B, C, 80, frames) -> logit (B, 1)   (specrnet.py:94-190)."""
+
+    def __init__(self, d_args, **kwargs):
+        super().__init__()
+        self.device = kwargs.get("device", "cuda")
+        filts = d_args["filts"]
+
+        self.first_bn = nn.BatchNorm2d(num_features=filts[0])
+        self.selu = nn.SELU(inplace=True)
+        self.block0 = nn.Sequential(Residual_block2D(nb_filts=filts[1], first=True))
+        self.block2 = nn.Sequential(Residual_block2D(nb_filts=filts[2]))
+        filts[2][0] = filts[2][1]
+        self.block4 = nn.Sequential(Residual_block2D(nb_filts=filts[2]))
+        self.avgpool = nn.AdaptiveAvgPool2d(1)
+
+        self.fc_attention0 = self._make_attention_fc(filts[1][-1], filts[1][-1])
+        self.fc_attention2 = self._make_attention_fc(filts[2][-1], filts[2][-1])
+        self.fc_attention4 = self._make_attention_fc(filts[2][-1], filts[2][-1])
+
+        self.bn_before_gru = nn.BatchNorm2d(num_features=filts[2][-1])
+        self.gru = nn.GRU(input_size=filts[2][-1], hidden_size=d_args["gru_node"],
+                          num_layers=d_args["nb_gru_layer"], batch_first=True, bidirectional=True)
+        self.fc1_gru = nn.Linear(d_args["gru_node"] * 2, d_args["nb_fc_node"] * 2)
+        self.fc2_gru = nn.Linear(d_args["nb_fc_node"] * 2, d_args["nb_classes"], bias=True)
+        self.sig = nn.Sigmoid()
+        self.pool = nn.MaxPool2d(2)
+
+    def _attend(self, feats, fc):
+        """Squeeze-excite style gate used after every block: x * y + y  (specrnet.py:145-149)."""
+        gate = self.sig(fc(self.avgpool(feats).view(feats.size(0), -1)))
+        gate = gate.view(gate.size(0), gate.size(1), 1, 1)
+        return feats * gate + gate
+
+    def _compute_embedding(self, x):
+        x = self.selu(self.first_bn(x))
+        x = self.pool(self._attend(self.block0(x), self.fc_attention0))
+        x = self.pool(self._attend(self.block2(x), self.fc_attention2))
+        x = self.pool(self._attend(self.block4(x), self.fc_attention4))
+        x = self.selu(self.bn_before_gru(x))
+        x = x.squeeze(-2).permute(0, 2, 1)
+        self.gru.flatten_parameters()
+        x, _ = self.gru(x)
+        return self.fc2_gru(self.fc1_gru(x[:, -1, :]))
+
+    def forward(self, x):
+        return self._compute_embedding(x)
+
+    def _make_attention_fc(self, in_features, l_out_features):
+        return nn.Sequential(nn.Linear(in_features=in_features, out_features=l_out_features))
+
+
+class SpecRNet(BaseSpecRNet):
+    """Waveform (B, T) -> logit (B, 1)   (specrnet.py:193-214)."""
+
+    def __init__(self, d_args, **kwargs):
+        super().__init__(d_args, **kwargs)
+        self.device = kwargs["device"]
+        frontend_name = kwargs.get("frontend_algorithm", [])
+        self.frontend = frontends.get_frontend(frontend_name)
+        print(f"Using {frontend_name} frontend")
+
+    def _compute_frontend(self, x):
+        feats = self.frontend(x)
+        return feats.unsqueeze(1) if feats.ndim < 4 else feats
+
+    def forward(self, x):
+        return self._compute_embedding(self._compute_frontend(x))

@@ -1,0 +1,92 @@
+"""TEST INFRASTRUCTURE — the op table of `hip_ops` re-implemented on CPU tensors through the plain-C oracle.
+
+Tests inject this table into the product's Attack classes (`atk.ops = oracle.torch_ops`) to exercise the HOST
+logic of the attacks (loop structure, mode juggling, buffers) on a box without a GPU, and `smoke()` uses it
+as the checker.  Same function names and arguments as audio_deepfake_adversarial_attacks_amd/hip_ops.py."""
+import numpy as np
+import torch
+
+from . import kernels as K
+
+NAME = "oracle"
+
+
+def _np(t: torch.Tensor) -> np.ndarray:
+    return t.detach().cpu().contiguous().numpy()
+
+
+def _t(a: np.ndarray, like: torch.Tensor) -> torch.Tensor:
+    return torch.from_numpy(np.ascontiguousarray(a)).to(like.device)
+
+
+def _emit(result: np.ndarray, like: torch.Tensor, out):
+    t = _t(result.reshape(like.shape), like)
+    if out is not None:
+        with torch.no_grad():
+            out.copy_(t)
+        return out
+    return t
+
+
+def to_minmax(batch_x):
+    x01, mn, mx = K.minmax_normalize(_np(batch_x).reshape(batch_x.shape[0], -1))
+    return _t(x01.reshape(batch_x.shape), batch_x), _t(mn.reshape(-1, 1), batch_x), _t(mx.reshape(-1, 1), batch_x)
+
+
+def revert_minmax(batch_x, mn, mx, out=None):
+    return _emit(K.minmax_revert(_np(batch_x).reshape(batch_x.shape[0], -1), _np(mn), _np(mx)), batch_x, out)
+
+
+def fgsm_step(x, grad, eps, lo=0.0, hi=1.0, out=None):
+    return _emit(K.fgsm_step(_np(x), _np(grad), eps, lo, hi), x, out)
+
+
+def pgd_linf_init(x, eps, noise=None, seed=None, offset=0, lo=0.0, hi=1.0, out=None):
+    if noise is not None:
+        return _emit(K.pgd_linf_init_noise(_np(x), _np(noise), lo, hi), x, out)
+    return _emit(K.pgd_linf_init_philox(_np(x), eps, seed, offset, lo, hi), x, out)
+
+
+def pgd_linf_step(adv, grad, orig, alpha, eps, lo=0.0, hi=1.0, out=None):
+    return _emit(K.pgd_linf_step(_np(adv), _np(grad), _np(orig), alpha, eps, lo, hi), adv, out)
+
+
+def pgd_l2_init(x, eps, draws=None, seed=None, offset=0, lo=0.0, hi=1.0, out=None):
+    x2 = _np(x).reshape(x.shape[0], -1)
+    if draws is not None:
+        normal, r = draws
+        return _emit(K.pgd_l2_init_noise(x2, _np(normal).reshape(x2.shape), _np(r), eps, lo, hi), x, out)
+    return _emit(K.pgd_l2_init_philox(x2, eps, seed, offset, lo, hi), x, out)
+
+
+def pgd_l2_step(adv, grad, orig, alpha, eps, eps_div=1e-10, lo=0.0, hi=1.0, out=None, return_norms=False):
+    B = adv.shape[0]
+    o, gn, dn = K.pgd_l2_step(_np(adv).reshape(B, -1), _np(grad).reshape(B, -1), _np(orig).reshape(B, -1), alpha, eps,
+                              eps_div, lo, hi)
+    res = _emit(o, adv, out)
+    return (res, _t(gn, adv), _t(dn, adv)) if return_norms else res
+
+
+def cw_init_w(x, out=None):
+    return _emit(K.cw_init_w(_np(x)), x, out)
+
+
+def cw_tanh_sqdist(w, x, adv_out=None):
+    B = w.shape[0]
+    adv, l2 = K.cw_tanh_sqdist(_np(w).reshape(B, -1), _np(x).reshape(B, -1))
+    return _emit(adv, w, adv_out), _t(l2, w)
+
+
+def cw_adam_step(w, m, v, x, grad_adv, step, lr=0.01, beta1=0.9, beta2=0.999, adam_eps=1e-8):
+    nw, nm, nv = K.cw_adam_step(_np(w), _np(m), _np(v), _np(x), _np(grad_adv), step, lr, beta1, beta2, adam_eps)
+    w.copy_(_t(nw.reshape(w.shape), w)), m.copy_(_t(nm.reshape(m.shape), m)), v.copy_(_t(nv.reshape(v.shape), v))
+
+
+def cw_best_update(adv, mask, best):
+    B = adv.shape[0]
+    best.copy_(_t(K.cw_best_update(_np(adv).reshape(B, -1), _np(mask), _np(best).reshape(B, -1)).reshape(best.shape), best))
+
+
+def ce2_loss_grad(z, labels, scale=1.0):
+    dz, loss = K.ce2_loss_grad(_np(z), _np(labels), scale)
+    return _t(dz.reshape(z.shape), z), torch.tensor([loss], dtype=torch.float32, device=z.device)

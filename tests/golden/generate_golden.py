@@ -1,0 +1,374 @@
+#!/usr/bin/env python
+"""Generate the golden vectors under tests/golden/ from the REFERENCE ITSELF.
+
+Run ONLY in the build container, where the Python reference is mounted read-only at /root/reference:
+
+    python tests/golden/generate_golden.py
+
+It imports the reference's own modules (adversarial_attacks.torchattacks, src.aa.utils, src.metrics and the
+BaseLCNN / BaseSpecRNet bodies), runs them on small seeded inputs with torch CPU kernels and stores inputs,
+intermediate tensors and outputs as .npz files.  The .npz files are data (inputs + expected outputs); no
+reference source travels.  The GPU box never runs this script (there is no /root/reference there).
+
+What is recorded and how
+  * per-step tensors of FGSM / PGD / PGDL2 / CW are captured by wrapping `torch.autograd.grad` and the
+    attacked model's forward while the reference's `forward` runs unmodified;
+  * random starts are reproduced by re-seeding torch's global generator and replaying the same draw calls
+    the reference makes (pgd.py:56, pgdl2.py:57,60); the replay is asserted against the first model input;
+  * the attacked model is a tiny pure-torch surrogate detector (Conv1d -> tanh -> mean -> Linear, (B,T)->(B,1))
+    whose weights are stored in the fixture;
+  * `src/models/lcnn.py` and `src/models/specrnet.py` import `src.frontends`, which imports torchaudio (absent
+    here).  To import the model BODIES (BaseLCNN / BaseSpecRNet, which never touch torchaudio) an inert module
+    object named `torchaudio` is placed in sys.modules; it performs no arithmetic and the frontends are NOT
+    pinned by these fixtures (see DESIGN.md "parity unpinned" list).
+"""
+from __future__ import annotations
+
+import contextlib
+import sys
+import types
+from pathlib import Path
+
+import numpy as np
+import torch
+
+REF = Path("/root/reference")
+OUT = Path(__file__).resolve().parent
+T_FULL = 64_600
+T_RAGGED = 4_099  # odd: exercises the scalar tails / unaligned rows
+T_SMALL = 4_096
+
+
+def _import_reference():
+    if not REF.exists():
+        sys.exit("the reference is not mounted at /root/reference; fixtures can only be generated in the build container")
+    sys.path.insert(0, str(REF))
+
+
+class Surrogate(torch.nn.Module):
+    """(B, T) -> (B, 1) differentiable detector with a handful of parameters."""
+
+    def __init__(self):
+        super().__init__()
+        self.conv = torch.nn.Conv1d(1, 4, kernel_size=9, stride=4)
+        self.fc = torch.nn.Linear(4, 1)
+
+    def forward(self, x):
+        h = torch.tanh(self.conv(x.unsqueeze(1)) * 8.0)
+        return self.fc(h.mean(dim=2)) * 4.0
+
+
+def surrogate(seed: int) -> Surrogate:
+    torch.manual_seed(seed)
+    m = Surrogate()
+    return m.eval()
+
+
+def waveforms(B: int, T: int, seed: int) -> torch.Tensor:
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, T, generator=g) * 0.05
+    return x.clamp_(-1.0, 1.0)
+
+
+def npy(t) -> np.ndarray:
+    return t.detach().cpu().numpy().copy()
+
+
+@contextlib.contextmanager
+def record_attack(model):
+    """Record every model input and every tensor returned by torch.autograd.grad while the body runs."""
+    rec = {"inputs": [], "grads": [], "logits": []}
+    orig_forward = model.forward
+    orig_grad = torch.autograd.grad
+
+    def fwd(x):
+        rec["inputs"].append(x.detach().clone())
+        out = orig_forward(x)
+        rec["logits"].append(out.detach().clone())
+        return out
+
+    def grad(*a, **k):
+        g = orig_grad(*a, **k)
+        rec["grads"].append(g[0].detach().clone())
+        return g
+
+    model.forward = fwd
+    torch.autograd.grad = grad
+    try:
+        yield rec
+    finally:
+        model.forward = orig_forward
+        torch.autograd.grad = orig_grad
+
+
+def gen_minmax(aa_utils):
+    out = {}
+    for tag, B, T, seed in (("full", 1, T_FULL, 11), ("ragged", 3, T_RAGGED, 12)):
+        x = waveforms(B, T, seed)
+        x01, mn, mx = aa_utils.to_minmax(x)
+        # perturb inside [0, 1] so revert is exercised on non-trivial data
+        g = torch.Generator().manual_seed(seed + 100)
+        p = (x01 + (torch.rand(B, T, generator=g) - 0.5) * 2e-3).clamp(0, 1)
+        back = aa_utils.revert_minmax(p, mn, mx)
+        out.update({f"{tag}_x": npy(x), f"{tag}_x01": npy(x01), f"{tag}_mn": npy(mn), f"{tag}_mx": npy(mx),
+                    f"{tag}_p": npy(p), f"{tag}_revert": npy(back)})
+    # constant row -> NaN (src/aa/utils.py:8-9 divides by zero)
+    xc = waveforms(2, 64, 13)
+    xc[1] = 0.25
+    x01, mn, mx = aa_utils.to_minmax(xc)
+    out.update({"const_x": npy(xc), "const_x01": npy(x01), "const_mn": npy(mn), "const_mx": npy(mx)})
+    np.savez_compressed(OUT / "minmax.npz", **out)
+
+
+def gen_fgsm(ta, aa_utils):
+    out = {}
+    model = surrogate(21)
+    out.update({f"model_{k}": npy(v) for k, v in model.state_dict().items()})
+    for tag, B, T, seed in (("ragged", 3, T_RAGGED, 22), ("small", 4, T_SMALL, 23)):
+        x01, _, _ = aa_utils.to_minmax(waveforms(B, T, seed))
+        y = torch.tensor([1, 0, 1, 0][:B])
+        for eps_tag, eps in (("e0005", 0.0005), ("e00075", 0.00075), ("e001", 0.001)):
+            atk = ta.FGSM(model, eps=eps)
+            atk.set_training_mode(model_training=True, batchnorm_training=False)
+            with record_attack(model) as rec:
+                adv = atk(x01, y)
+            assert len(rec["grads"]) == 1
+            out.update({f"{tag}_{eps_tag}_x": npy(x01), f"{tag}_{eps_tag}_y": npy(y),
+                        f"{tag}_{eps_tag}_grad": npy(rec["grads"][0]), f"{tag}_{eps_tag}_logits": npy(rec["logits"][0]),
+                        f"{tag}_{eps_tag}_adv": npy(adv), f"{tag}_{eps_tag}_eps": np.float64(eps)})
+    np.savez_compressed(OUT / "fgsm.npz", **out)
+
+
+def gen_pgd_linf(ta, aa_utils):
+    out = {}
+    model = surrogate(31)
+    out.update({f"model_{k}": npy(v) for k, v in model.state_dict().items()})
+    cases = (
+        # tag, B, T, seed, eps, steps, random_start
+        ("ragged_rs", 3, T_RAGGED, 32, 0.003, 3, True),     # BASELINE config 2 hyper-parameters (alpha default 2/255)
+        ("small_nors", 4, T_SMALL, 33, 0.0005, 3, False),   # AttackEnum.PGD eps (aa_types.py:9)
+        ("full_rs", 1, T_FULL, 34, 0.003, 1, True),
+    )
+    for tag, B, T, seed, eps, steps, rs in cases:
+        x01, _, _ = aa_utils.to_minmax(waveforms(B, T, seed))
+        y = torch.tensor([0, 1, 1, 0][:B])
+        atk = ta.PGD(model, eps=eps, steps=steps, random_start=rs)
+        atk.set_training_mode(model_training=True, batchnorm_training=False)
+        torch.manual_seed(seed + 1000)
+        with record_attack(model) as rec:
+            adv = atk(x01, y)
+        out.update({f"{tag}_x": npy(x01), f"{tag}_y": npy(y), f"{tag}_adv": npy(adv),
+                    f"{tag}_eps": np.float64(eps), f"{tag}_alpha": np.float64(atk.alpha), f"{tag}_steps": np.int64(steps)})
+        if rs:
+            torch.manual_seed(seed + 1000)
+            noise = torch.empty_like(x01).uniform_(-eps, eps)  # replay of pgd.py:56
+            a0 = torch.clamp(x01 + noise, min=0, max=1)
+            assert torch.equal(a0, rec["inputs"][0]), "noise replay does not reproduce the reference's start"
+            out[f"{tag}_noise"] = npy(noise)
+        for k in range(steps):
+            out[f"{tag}_a{k}"] = npy(rec["inputs"][k])
+            out[f"{tag}_g{k}"] = npy(rec["grads"][k])
+        out[f"{tag}_a{steps}"] = npy(adv)
+    np.savez_compressed(OUT / "pgd_linf.npz", **out)
+
+
+def gen_pgd_l2(ta, aa_utils):
+    out = {}
+    model = surrogate(41)
+    out.update({f"model_{k}": npy(v) for k, v in model.state_dict().items()})
+    cases = (
+        ("ragged_rs", 3, T_RAGGED, 42, 0.1, 3, True),      # AttackEnum.PGDL2 eps (aa_types.py:13), alpha default 0.2
+        ("small_nors", 4, T_SMALL, 43, 0.2, 3, False),
+    )
+    for tag, B, T, seed, eps, steps, rs in cases:
+        x01, _, _ = aa_utils.to_minmax(waveforms(B, T, seed))
+        y = torch.tensor([1, 1, 0, 0][:B])
+        atk = ta.PGDL2(model, eps=eps, steps=steps, random_start=rs)
+        atk.set_training_mode(model_training=True, batchnorm_training=False)
+        torch.manual_seed(seed + 1000)
+        with record_attack(model) as rec:
+            adv = atk(x01, y)
+        out.update({f"{tag}_x": npy(x01), f"{tag}_y": npy(y), f"{tag}_adv": npy(adv), f"{tag}_eps": np.float64(eps),
+                    f"{tag}_alpha": np.float64(atk.alpha), f"{tag}_eps_div": np.float64(atk.eps_for_division),
+                    f"{tag}_steps": np.int64(steps)})
+        if rs:
+            torch.manual_seed(seed + 1000)
+            normal = torch.empty_like(x01).normal_()                     # replay of pgdl2.py:57
+            n = normal.view(B, -1).norm(p=2, dim=1).view(B, 1)           # :58-59
+            r = torch.zeros_like(n).uniform_(0, 1)                       # :60
+            a0 = torch.clamp(x01 + normal * (r / n * eps), min=0, max=1)
+            assert torch.equal(a0, rec["inputs"][0]), "draw replay does not reproduce the reference's start"
+            out[f"{tag}_normal"] = npy(normal)
+            out[f"{tag}_r"] = npy(r.view(-1))
+            out[f"{tag}_nnorm"] = npy(n.view(-1))
+        for k in range(steps):
+            a_k, g_k = rec["inputs"][k], rec["grads"][k]
+            out[f"{tag}_a{k}"] = npy(a_k)
+            out[f"{tag}_g{k}"] = npy(g_k)
+            # the reference's own row norms for this step (pgdl2.py:78,83), recomputed with the same torch calls
+            gn = torch.norm(g_k.view(B, -1), p=2, dim=1)
+            a_mid = a_k + atk.alpha * (g_k / (gn + atk.eps_for_division).view(B, 1))
+            dn = torch.norm((a_mid - x01).view(B, -1), p=2, dim=1)
+            out[f"{tag}_gnorm{k}"] = npy(gn)
+            out[f"{tag}_dnorm{k}"] = npy(dn)
+        out[f"{tag}_a{steps}"] = npy(adv)
+    np.savez_compressed(OUT / "pgd_l2.npz", **out)
+
+
+def gen_cw(ta, aa_utils):
+    out = {}
+    model = surrogate(51)
+    out.update({f"model_{k}": npy(v) for k, v in model.state_dict().items()})
+    # c = 100 / 20 steps: the reference runs 19 optimiser steps before its early stop (cw.py:107-110) and the
+    # best-so-far blend (cw.py:94-103) fires for part of the batch
+    B, T, steps, c, lr, keep = 4, 2048, 20, 100.0, 0.01, 4
+    x01, _, _ = aa_utils.to_minmax(waveforms(B, T, 52))
+    y = torch.tensor([1, 0, 0, 1])
+    atk = ta.CW(model, c=c, kappa=0, steps=steps, lr=lr)
+    atk.set_training_mode(model_training=True, batchnorm_training=False)
+
+    # Record the optimiser's view of every step: w before, grad, and (w, m, v) after.
+    trace = []
+    RealAdam = torch.optim.Adam
+
+    class TracingAdam(RealAdam):
+        def step(self, closure=None):
+            p = self.param_groups[0]["params"][0]
+            entry = {"w": p.detach().clone(), "grad_w": p.grad.detach().clone()}
+            r = super().step(closure)
+            st = self.state[p]
+            entry.update({"w_after": p.detach().clone(), "m_after": st["exp_avg"].detach().clone(),
+                          "v_after": st["exp_avg_sq"].detach().clone()})
+            trace.append(entry)
+            return r
+
+    ref_cw_module = sys.modules[ta.CW.__module__]
+    ref_cw_module.optim.Adam = TracingAdam
+    try:
+        with record_attack(model) as rec:
+            best = atk(x01, y)
+    finally:
+        ref_cw_module.optim.Adam = RealAdam
+    # cw.py:107-110: with steps < 10 the early-stop test runs every step, so fewer than `steps` updates may happen
+    assert 1 <= len(trace) <= steps
+    out["steps_done"] = np.int64(len(trace))
+    print("cw: optimiser steps executed by the reference:", len(trace), "of", steps)
+    out.update({"x": npy(x01), "y": npy(y), "best": npy(best), "c": np.float64(c), "lr": np.float64(lr),
+                "steps": np.int64(steps), "kappa": np.float64(0)})
+    out["w0"] = npy(atk.inverse_tanh_space(x01))
+    out["all_l2"] = np.stack([npy(((rec["inputs"][k] - x01) ** 2).sum(dim=1)) for k in range(len(trace))])
+    out["all_logits"] = np.stack([npy(rec["logits"][k]) for k in range(len(trace))])
+    for k, e in enumerate(trace[:keep]):
+        adv_k = rec["inputs"][k]
+        # model-side gradient d(c * sum f)/d adv for this step, with the reference's own f() (cw.py:125-134)
+        a = adv_k.clone().requires_grad_(True)
+        o = model.forward(a)
+        o = torch.cat([-o, o], dim=1)
+        gm = torch.autograd.grad(c * atk.f(o, y).sum(), a)[0]
+        l2 = ((adv_k - x01) ** 2).sum(dim=1)
+        out.update({f"s{k}_w": npy(e["w"]), f"s{k}_grad_w": npy(e["grad_w"]), f"s{k}_adv": npy(adv_k),
+                    f"s{k}_l2": npy(l2), f"s{k}_grad_adv": npy(gm), f"s{k}_logits": npy(rec["logits"][k]),
+                    f"s{k}_w_after": npy(e["w_after"]), f"s{k}_m_after": npy(e["m_after"]),
+                    f"s{k}_v_after": npy(e["v_after"])})
+    np.savez_compressed(OUT / "cw.npz", **out)
+
+
+def gen_metrics():
+    from src.metrics import calculate_eer
+    from sklearn.metrics import precision_recall_fscore_support, roc_auc_score
+
+    out = {}
+    rng = np.random.default_rng(61)
+    for tag, N, sep in (("random", 1024, 0.0), ("separable", 1024, 1.5), ("tiny", 16, 0.7)):
+        y = rng.integers(0, 2, size=N).astype(np.int64)
+        score = 1.0 / (1.0 + np.exp(-(rng.standard_normal(N) + sep * (2 * y - 1))))
+        score = score.astype(np.float32)
+        label = (score + 0.5).astype(np.int32)  # evaluate_models_on_adversarial_attacks.py:238
+        thresh, eer, fpr, tpr = calculate_eer(y=1 - y, y_score=score)  # :285-290
+        p, r, f1, _ = precision_recall_fscore_support(y, label, average="binary", beta=1.0)  # :272-277
+        auc = roc_auc_score(y_true=y, y_score=score)  # :278
+        acc = 100.0 * float((label == y).sum()) / N
+        out.update({f"{tag}_y": y, f"{tag}_score": score, f"{tag}_eer": np.float64(eer), f"{tag}_thresh": np.float64(thresh),
+                    f"{tag}_precision": np.float64(p), f"{tag}_recall": np.float64(r), f"{tag}_f1": np.float64(f1),
+                    f"{tag}_auc": np.float64(auc), f"{tag}_accuracy": np.float64(acc)})
+    np.savez_compressed(OUT / "metrics.npz", **out)
+
+
+def _inert_torchaudio():
+    """An object that satisfies `import torchaudio` + the three module-level constructor calls of
+    src/frontends.py:13-38 and does nothing else (calling the result raises)."""
+    class _Inert:
+        def __init__(self, *a, **k):
+            pass
+
+        def to(self, *_):
+            return self
+
+        def __call__(self, *a, **k):
+            raise RuntimeError("inert torchaudio placeholder: the frontends are not part of the golden fixtures")
+
+    ta = types.ModuleType("torchaudio")
+    ta.transforms = types.SimpleNamespace(MFCC=_Inert, LFCC=_Inert, MelScale=_Inert)
+    return ta
+
+
+def gen_model_bodies():
+    sys.modules.setdefault("torchaudio", _inert_torchaudio())
+    from src.models import lcnn as ref_lcnn
+    from src.models import specrnet as ref_specrnet
+
+    g = torch.Generator().manual_seed(71)
+    torch.manual_seed(72)
+    body = ref_lcnn.BaseLCNN(input_channels=1, num_coefficients=80).eval()
+    spec = torch.randn(2, 1, 80, 404, generator=g) * 10.0
+    with torch.no_grad():
+        logits = body(spec)
+    out = {f"sd_{k}": npy(v) for k, v in body.state_dict().items()}
+    out.update({"spec": npy(spec), "logits": npy(logits)})
+    # input-gradient of the train-mode-with-BN/Dropout-eval configuration the attacks use (attack.py:311-319)
+    body.train()
+    for m in body.modules():
+        if "BatchNorm" in m.__class__.__name__ or "Dropout" in m.__class__.__name__:
+            m.eval()
+    s = spec.clone().requires_grad_(True)
+    o = body(s)
+    out["logits_attackmode"] = npy(o)
+    out["grad_spec"] = npy(torch.autograd.grad(o.sum(), s)[0])
+    np.savez_compressed(OUT / "lcnn_body.npz", **out)
+
+    torch.manual_seed(73)
+    body = ref_specrnet.BaseSpecRNet(ref_specrnet.get_config(2), device="cpu").eval()
+    # non-trivial BN statistics so eval-mode BN is exercised
+    with torch.no_grad():
+        for m in body.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.uniform_(-0.2, 0.2, generator=g)
+                m.running_var.uniform_(0.5, 1.5, generator=g)
+    spec = torch.randn(2, 2, 80, 404, generator=g)
+    with torch.no_grad():
+        logits = body(spec)
+    out = {f"sd_{k}": npy(v) for k, v in body.state_dict().items()}
+    out.update({"spec": npy(spec), "logits": npy(logits)})
+    np.savez_compressed(OUT / "specrnet_body.npz", **out)
+
+
+def main():
+    _import_reference()
+    torch.set_num_threads(1)  # fixed thread count: the reference is bit-reproducible at a fixed thread count
+    torch.use_deterministic_algorithms(True)
+    from adversarial_attacks import torchattacks as ta
+    from src.aa import utils as aa_utils
+
+    gen_minmax(aa_utils)
+    gen_fgsm(ta, aa_utils)
+    gen_pgd_linf(ta, aa_utils)
+    gen_pgd_l2(ta, aa_utils)
+    gen_cw(ta, aa_utils)
+    gen_metrics()
+    gen_model_bodies()
+    for p in sorted(OUT.glob("*.npz")):
+        print(f"{p.name}: {p.stat().st_size / 1e6:.2f} MB")
+
+
+if __name__ == "__main__":
+    main()
