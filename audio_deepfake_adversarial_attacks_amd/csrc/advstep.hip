@@ -710,12 +710,13 @@ __global__ __launch_bounds__(kBlock) void ce2_loss_grad_kernel(const float *__re
     const float invB = 1.0f / (float)B;
     float acc = 0.0f;
     for (int64_t b = threadIdx.x; b < B; b += kBlock) {
-        const float t = 2.0f * z[b];
-        const float y = (float)labels[b];
-        // CE([-z, z], y): y = 1 -> softplus(-2z), y = 0 -> softplus(2z)
-        acc += softplusf((1.0f - 2.0f * y) * t);
-        const float sig = 1.0f / (1.0f + expf(-t));
-        dz[b] = scale * ((2.0f * invB) * (sig - y));
+        // CE([-z, z], y) = softplus(u), u = (1 - 2y) * 2z;  d/dz = (1 - 2y) * 2 * sigmoid(u).
+        // (sigmoid(2z) - y written without the cancellation at saturated logits.)
+        const float flip = 1.0f - 2.0f * (float)labels[b];
+        const float u = flip * (2.0f * z[b]);
+        acc += softplusf(u);
+        const float sig = 1.0f / (1.0f + expf(-u));
+        dz[b] = scale * ((2.0f * invB) * (flip * sig));
     }
     acc = block_reduce(acc, SumOp(), lds);
     if (threadIdx.x == 0) loss[0] = scale * (acc * invB);

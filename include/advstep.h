@@ -140,7 +140,8 @@ int advstep_cw_best_update_f32(const float *adv, const float *mask, float *best,
 /* ---- a8: one-logit -> two-logit adapter + mean cross-entropy, closed form ------------------------------- */
 
 /* pgd.py:62,50,68 (same lines in fgsm.py:47, pgdl2.py:67):  out = cat([-z, z], 1), cost = CE(out, y) (mean).
- *   loss_b = softplus((1 - 2 y_b) * 2 z_b) ;  dz[b] = scale * (2 / B) * (sigmoid(2 z_b) - y_b)
+ *   u_b = (1 - 2 y_b) * 2 z_b ;  loss_b = softplus(u_b) ;
+ *   dz[b] = scale * (2 / B) * (1 - 2 y_b) * sigmoid(u_b)      ( == (2 / B) * (sigmoid(2 z_b) - y_b), no cancellation )
  * loss (1) receives scale * mean_b loss_b; `scale` = +1 (untargeted) or -1 (targeted, cost = -CE).
  * Single-workgroup kernel (B is a batch size); labels are int64 in {0, 1}. */
 int advstep_ce2_loss_grad_f32(const float *z, const int64_t *labels, float *dz, float *loss, int64_t B,

@@ -189,12 +189,11 @@ void oracle_cw_best_update_f32(const float *adv, const float *mask, float *best,
 void oracle_ce2_loss_grad_f32(const float *z, const int64_t *labels, float *dz, float *loss, int64_t B, float scale) {
     double acc = 0.0;
     for (int64_t b = 0; b < B; ++b) {
-        const double t = 2.0 * (double)z[b];
-        const double y = (double)labels[b];
-        const double u = (1.0 - 2.0 * y) * t;
+        const double flip = 1.0 - 2.0 * (double)labels[b];
+        const double u = flip * 2.0 * (double)z[b];
         acc += (u > 0 ? u : 0) + log1p(exp(-fabs(u)));
-        const double sig = 1.0 / (1.0 + exp(-t));
-        dz[b] = (float)((double)scale * (2.0 / (double)B) * (sig - y));
+        const double sig = 1.0 / (1.0 + exp(-u));
+        dz[b] = (float)((double)scale * (2.0 / (double)B) * (flip * sig));
     }
     loss[0] = (float)((double)scale * acc / (double)B);
 }

@@ -1,0 +1,36 @@
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+GOLDEN = ROOT / "tests" / "golden"
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a HIP device (run on the MI355X box with `-m gpu`)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    cache = {}
+
+    def load(name: str):
+        if name not in cache:
+            cache[name] = dict(np.load(GOLDEN / f"{name}.npz"))
+        return cache[name]
+
+    return load
+
+
+@pytest.fixture(scope="session")
+def cuda():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("a test marked `gpu` ran without a HIP device; there is no CPU fallback for the attack kernels")
+    from audio_deepfake_adversarial_attacks_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")

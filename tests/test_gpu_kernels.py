@@ -1,0 +1,288 @@
+"""`-m gpu`: every C-ABI entry point of libadvstep.so against (i) the reference's golden vectors and (ii) the
+plain-C oracle on seeded inputs, through the product's ctypes binding (hip_ops -> libadvstep.so)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import kernels as K
+from tests.helpers import dev, rand01, randn
+
+pytestmark = pytest.mark.gpu
+
+T_FULL = 64_600
+SHAPES = [(1, 1), (2, 3), (3, 255), (2, 4096), (3, 4099), (5, 8192), (4, 12_289), (2, T_FULL), (1, 70_001)]
+
+
+@pytest.fixture(scope="module")
+def ops(cuda):
+    from audio_deepfake_adversarial_attacks_amd import hip_ops
+    return hip_ops
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def same(a, b):
+    return np.array_equal(a, b, equal_nan=True)
+
+
+# ---- golden vectors produced by the reference itself ----------------------------------------------------------------
+
+def test_minmax_golden(ops, cuda, golden):
+    g = golden("minmax")
+    for tag in ("full", "ragged", "const"):
+        x01, mn, mx = ops.to_minmax(dev(g[f"{tag}_x"], cuda))
+        assert same(host(x01), g[f"{tag}_x01"]) and same(host(mn), g[f"{tag}_mn"]) and same(host(mx), g[f"{tag}_mx"]), tag
+        if tag != "const":
+            back = ops.revert_minmax(dev(g[f"{tag}_p"], cuda), dev(g[f"{tag}_mn"], cuda), dev(g[f"{tag}_mx"], cuda))
+            assert same(host(back), g[f"{tag}_revert"]), tag
+    assert np.isnan(g["const_x01"][1]).all()  # the reference's own NaN row (src/aa/utils.py:8-9)
+
+
+def test_fgsm_golden(ops, cuda, golden):
+    g = golden("fgsm")
+    for tag in ("ragged", "small"):
+        for e in ("e0005", "e00075", "e001"):
+            p = f"{tag}_{e}_"
+            out = ops.fgsm_step(dev(g[p + "x"], cuda), dev(g[p + "grad"], cuda), float(g[p + "eps"]))
+            assert same(host(out), g[p + "adv"]), p  # bit-exact; north-star bound is 1e-5 max-abs
+
+
+def test_pgd_linf_golden(ops, cuda, golden):
+    g = golden("pgd_linf")
+    for tag in ("ragged_rs", "small_nors", "full_rs"):
+        eps, alpha, steps = float(g[tag + "_eps"]), float(g[tag + "_alpha"]), int(g[tag + "_steps"])
+        x = dev(g[tag + "_x"], cuda)
+        if tag + "_noise" in g:
+            a0 = ops.pgd_linf_init(x, eps, noise=dev(g[tag + "_noise"], cuda))
+            assert same(host(a0), g[tag + "_a0"]), tag
+        for k in range(steps):
+            out = ops.pgd_linf_step(dev(g[f"{tag}_a{k}"], cuda), dev(g[f"{tag}_g{k}"], cuda), x, alpha, eps)
+            assert same(host(out), g[f"{tag}_a{k + 1}"]), (tag, k)
+
+
+def test_pgd_l2_golden(ops, cuda, golden):
+    g = golden("pgd_l2")
+    for tag in ("ragged_rs", "small_nors"):
+        eps, alpha, steps = float(g[tag + "_eps"]), float(g[tag + "_alpha"]), int(g[tag + "_steps"])
+        eps_div = float(g[tag + "_eps_div"])
+        x = dev(g[tag + "_x"], cuda)
+        if tag + "_normal" in g:
+            a0 = ops.pgd_l2_init(x, eps, draws=(dev(g[tag + "_normal"], cuda), dev(g[tag + "_r"], cuda)))
+            np.testing.assert_allclose(host(a0), g[tag + "_a0"], atol=3e-7, rtol=0)
+        for k in range(steps):
+            out, gn, dn = ops.pgd_l2_step(dev(g[f"{tag}_a{k}"], cuda), dev(g[f"{tag}_g{k}"], cuda), x, alpha, eps, eps_div,
+                                          return_norms=True)
+            # stated tolerance: the reference's torch.norm and the kernel reduce in different f32 orders
+            np.testing.assert_allclose(host(gn), g[f"{tag}_gnorm{k}"], rtol=2e-6)
+            np.testing.assert_allclose(host(dn), g[f"{tag}_dnorm{k}"], rtol=2e-6)
+            np.testing.assert_allclose(host(out), g[f"{tag}_a{k + 1}"], atol=3e-7, rtol=0)
+
+
+def test_cw_golden(ops, cuda, golden):
+    g = golden("cw")
+    x = dev(g["x"], cuda)
+    w0 = host(ops.cw_init_w(x))
+    fin = np.isfinite(g["w0"])
+    assert same(np.isposinf(w0), np.isposinf(g["w0"])) and same(np.isneginf(w0), np.isneginf(g["w0"]))
+    np.testing.assert_allclose(w0[fin], g["w0"][fin], rtol=2e-6, atol=1e-6)
+    m = torch.zeros_like(x)
+    v = torch.zeros_like(x)
+    for k in range(4):
+        w = dev(g[f"s{k}_w"], cuda)
+        adv, l2 = ops.cw_tanh_sqdist(w, x)
+        np.testing.assert_allclose(host(adv), g[f"s{k}_adv"], atol=2e-7, rtol=0)
+        np.testing.assert_allclose(host(l2), g[f"s{k}_l2"], rtol=1e-4, atol=1e-9)
+        ops.cw_adam_step(w, m, v, x, dev(g[f"s{k}_grad_adv"], cuda), k + 1, lr=float(g["lr"]))
+        np.testing.assert_allclose(host(m), g[f"s{k}_m_after"], rtol=2e-5, atol=3e-8)
+        np.testing.assert_allclose(host(v), g[f"s{k}_v_after"], rtol=2e-4, atol=1e-12)
+        resolved = np.abs(g[f"s{k}_grad_w"]) > 1e-4  # elsewhere Adam amplifies rounding noise to +-lr
+        np.testing.assert_allclose(host(w)[resolved], g[f"s{k}_w_after"][resolved], atol=2e-6, rtol=0)
+        m, v = dev(g[f"s{k}_m_after"], cuda), dev(g[f"s{k}_v_after"], cuda)
+
+
+# ---- oracle on seeded inputs, ragged / unaligned / large shapes ----------------------------------------------------------
+
+@pytest.mark.parametrize("B,T", SHAPES)
+def test_minmax_and_revert_vs_oracle(ops, cuda, B, T):
+    x = randn((B, T), 100 + T, 0.05)
+    x01, mn, mx = ops.to_minmax(dev(x, cuda))
+    w01, wmn, wmx = K.minmax_normalize(x)
+    assert same(host(x01), w01) and same(host(mn).ravel(), wmn) and same(host(mx).ravel(), wmx)
+    p = rand01((B, T), 200 + T)
+    assert same(host(ops.revert_minmax(dev(p, cuda), mn, mx)), K.minmax_revert(p, wmn, wmx))
+
+
+def test_minmax_nan_and_constant_rows(ops, cuda):
+    x = randn((3, 5000), 5, 0.05)
+    x[1, 1234] = np.nan
+    x[2, :] = 0.125
+    x01, mn, mx = ops.to_minmax(dev(x, cuda))
+    w01, wmn, wmx = K.minmax_normalize(x)
+    assert same(host(x01), w01) and same(host(mn).ravel(), wmn) and same(host(mx).ravel(), wmx)
+    assert np.isnan(host(x01)[1]).all() and np.isnan(host(x01)[2]).all() and np.isfinite(host(x01)[0]).all()
+
+
+@pytest.mark.parametrize("B,T", SHAPES)
+def test_flat_steps_vs_oracle(ops, cuda, B, T):
+    x, a, g = rand01((B, T), 1 + T), rand01((B, T), 2 + T), randn((B, T), 3 + T, 1e-3)
+    g[0, 0] = 0.0
+    g.flat[-1] = np.nan
+    for eps in (0.0005, 0.001, 0.003):
+        assert same(host(ops.fgsm_step(dev(x, cuda), dev(g, cuda), eps)), K.fgsm_step(x, g, eps))
+        a_near = np.clip(x + randn((B, T), 4 + T, eps), 0, 1).astype(np.float32)
+        for alpha in (2 / 255, eps / 4):
+            got = ops.pgd_linf_step(dev(a_near, cuda), dev(g, cuda), dev(x, cuda), alpha, eps)
+            assert same(host(got), K.pgd_linf_step(a_near, g, x, alpha, eps))
+    nz = randn((B, T), 5 + T, 0.003)
+    assert same(host(ops.pgd_linf_init(dev(x, cuda), 0.003, noise=dev(nz, cuda))), K.pgd_linf_init_noise(x, nz))
+    for seed, off in ((0, 0), (123456789012345, 7), (2 ** 62 - 1, 2 ** 40)):
+        got = host(ops.pgd_linf_init(dev(x, cuda), 0.003, seed=seed, offset=off))
+        assert same(got, K.pgd_linf_init_philox(x, 0.003, seed, off))
+    assert np.abs(got - x).max() <= 0.003 + 1e-7
+
+
+def test_flat_steps_unaligned_pointers(ops, cuda):
+    """Views that start 4 bytes into an allocation take the scalar path of every flat kernel."""
+    n = 10_001
+    base = [dev(np.concatenate([[0], a]).astype(np.float32), cuda) for a in
+            (rand01(n, 1), randn(n, 2, 1e-3), rand01(n, 3))]
+    a, g, x = (b[1:] for b in base)
+    assert a.data_ptr() % 16 != 0
+    got = ops.pgd_linf_step(a, g, x, 2 / 255, 0.003)
+    assert same(host(got), K.pgd_linf_step(host(a), host(g), host(x), 2 / 255, 0.003))
+    out = torch.empty(n + 1, device=cuda)[1:]
+    ops.fgsm_step(x, g, 0.001, out=out)
+    assert same(host(out), K.fgsm_step(host(x), host(g), 0.001))
+
+
+def test_in_place_step(ops, cuda):
+    a, g, x = rand01((4, 4099), 1), randn((4, 4099), 2), rand01((4, 4099), 3)
+    da = dev(a, cuda)
+    ops.pgd_linf_step(da, dev(g, cuda), dev(x, cuda), 2 / 255, 0.003, out=da)
+    assert same(host(da), K.pgd_linf_step(a, g, x, 2 / 255, 0.003))
+    da = dev(a, cuda)
+    ops.pgd_l2_step(da, dev(g, cuda), dev(x, cuda), 0.2, 0.1, out=da)
+    np.testing.assert_allclose(host(da), K.pgd_l2_step(a, g, x, 0.2, 0.1)[0], atol=3e-7, rtol=0)
+
+
+@pytest.mark.parametrize("B,T", SHAPES)
+def test_pgd_l2_vs_oracle(ops, cuda, B, T):
+    x = rand01((B, T), 11 + T)
+    a = np.clip(x + randn((B, T), 12 + T, 1e-3), 0, 1).astype(np.float32)
+    g = randn((B, T), 13 + T, 1e-4)
+    for alpha, eps in ((0.2, 0.1), (0.2, 1.0), (0.01, 0.2)):
+        got, gn, dn = ops.pgd_l2_step(dev(a, cuda), dev(g, cuda), dev(x, cuda), alpha, eps, return_norms=True)
+        want, wgn, wdn = K.pgd_l2_step(a, g, x, alpha, eps)
+        np.testing.assert_allclose(host(gn), wgn, rtol=2e-6)
+        np.testing.assert_allclose(host(dn), wdn, rtol=2e-6)
+        np.testing.assert_allclose(host(got), want, atol=3e-7, rtol=0)
+        # the L2-ball invariant, with float slack
+        assert (np.linalg.norm((host(got) - x).astype(np.float64), axis=1) <= eps * (1 + 1e-5) + 1e-6).all()
+    normal, r = randn((B, T), 14 + T), rand01((B,), 15 + T)
+    got = ops.pgd_l2_init(dev(x, cuda), 0.1, draws=(dev(normal, cuda), dev(r, cuda)))
+    np.testing.assert_allclose(host(got), K.pgd_l2_init_noise(x, normal, r, 0.1), atol=3e-7, rtol=0)
+    got = ops.pgd_l2_init(dev(x, cuda), 0.1, seed=424242, offset=3)
+    np.testing.assert_allclose(host(got), K.pgd_l2_init_philox(x, 0.1, 424242, 3), atol=1e-6, rtol=0)
+
+
+def test_pgd_l2_zero_gradient_and_zero_delta(ops, cuda):
+    """g = 0 -> g / (0 + 1e-10) = 0; a == x -> dn = 0 -> (1/0)*eps = inf -> min(inf, 1) = 1 (pgdl2.py:78-86)."""
+    x = rand01((2, 4096), 1)
+    g = np.zeros_like(x)
+    got, gn, dn = ops.pgd_l2_step(dev(x, cuda), dev(g, cuda), dev(x, cuda), 0.2, 0.1, return_norms=True)
+    assert same(host(got), x) and (host(gn) == 0).all() and (host(dn) == 0).all()
+
+
+@pytest.mark.parametrize("B,T", [(2, 3), (3, 4099), (2, T_FULL)])
+def test_cw_vs_oracle(ops, cuda, B, T):
+    x = rand01((B, T), 21 + T)
+    x[0, 0], x[0, 1 % T] = 0.0, 1.0  # after to_minmax every row holds an exact 0 and 1 -> w = -+inf (cw.py:117-122)
+    w = host(ops.cw_init_w(dev(x, cuda)))
+    ww = K.cw_init_w(x)
+    assert np.isneginf(w[0, 0]) and np.isposinf(w[0, 1 % T])
+    fin = np.isfinite(ww)
+    np.testing.assert_allclose(w[fin], ww[fin], rtol=2e-6, atol=1e-6)
+    wv = randn((B, T), 22 + T, 2.0)
+    adv, l2 = ops.cw_tanh_sqdist(dev(wv, cuda), dev(x, cuda))
+    wadv, wl2 = K.cw_tanh_sqdist(wv, x)
+    np.testing.assert_allclose(host(adv), wadv, atol=2e-7, rtol=0)
+    np.testing.assert_allclose(host(l2), wl2, rtol=1e-5)
+    m, v, gm = randn((B, T), 23 + T, 0.1), np.abs(randn((B, T), 24 + T, 0.01)), randn((B, T), 25 + T, 0.5)
+    dw, dm, dv = dev(wv, cuda), dev(m, cuda), dev(v, cuda)
+    ops.cw_adam_step(dw, dm, dv, dev(x, cuda), dev(gm, cuda), 3, lr=0.01)
+    ow, om, ov = K.cw_adam_step(wv, m, v, x, gm, 3, lr=0.01)
+    np.testing.assert_allclose(host(dm), om, rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(host(dv), ov, rtol=2e-5, atol=1e-9)
+    np.testing.assert_allclose(host(dw), ow, atol=2e-6, rtol=0)
+    mask = (np.arange(B) % 2).astype(np.float32)
+    best = rand01((B, T), 26 + T)
+    db = dev(best, cuda)
+    ops.cw_best_update(adv, dev(mask, cuda), db)
+    assert same(host(db), K.cw_best_update(host(adv), mask, best))
+
+
+@pytest.mark.parametrize("B", [1, 2, 64, 128, 1000])
+def test_ce2_loss_grad_vs_oracle_and_torch(ops, cuda, B):
+    z = randn((B, 1), 31 + B, 3.0)
+    y = (np.random.default_rng(B).integers(0, 2, B)).astype(np.int64)
+    for scale in (1.0, -1.0):
+        dz, loss = ops.ce2_loss_grad(dev(z, cuda), dev(y, cuda), scale)
+        wdz, wloss = K.ce2_loss_grad(z, y, scale)
+        np.testing.assert_allclose(host(dz).ravel(), wdz, rtol=1e-5, atol=1e-9)
+        np.testing.assert_allclose(host(loss)[0], wloss, rtol=1e-5, atol=1e-7)
+    # and against the reference's formulation, torch fp32: CE(cat([-z, z], 1), y)   (pgd.py:62,50,68)
+    zt = torch.from_numpy(z).requires_grad_(True)
+    cost = torch.nn.CrossEntropyLoss()(torch.cat([-zt, zt], dim=1), torch.from_numpy(y))
+    (gz,) = torch.autograd.grad(cost, zt)
+    dz, loss = ops.ce2_loss_grad(dev(z, cuda), dev(y, cuda), 1.0)
+    # torch forms softmax - onehot in f32 (cancellation at saturated logits): absolute tolerance there
+    np.testing.assert_allclose(host(dz), gz.numpy(), rtol=1e-4, atol=3e-8)
+    np.testing.assert_allclose(host(loss)[0], cost.item(), rtol=1e-5)
+
+
+# ---- full benchmark size: size-independent properties --------------------------------------------------------------------
+
+def test_full_size_properties(ops, cuda):
+    """B = 128, T = 64 600 (BASELINE.json config 2): idempotence, ball / box invariants, revert round trip, and
+    equality with the oracle on a strided sample of rows."""
+    B, T = 128, T_FULL
+    gen = torch.Generator(device="cpu").manual_seed(1234)
+    x = (torch.randn(B, T, generator=gen) * 0.05).clamp_(-1, 1).to(cuda)
+    x01, mn, mx = ops.to_minmax(x)
+    assert x01.min().item() == 0.0 and x01.max().item() == 1.0
+    assert (x01.min(dim=1)[0] == 0).all() and (x01.max(dim=1)[0] == 1).all()
+    back = ops.revert_minmax(x01, mn, mx)
+    assert (back - x).abs().max().item() <= 1e-7                              # 4.5e-8 observed
+    g = torch.randn(B, T, generator=gen).to(cuda)
+    eps, alpha = 0.003, 2 / 255
+    adv = ops.pgd_linf_init(x01, eps, seed=99)
+    for _ in range(3):
+        adv = ops.pgd_linf_step(adv, g, x01, alpha, eps)
+    assert (adv - x01).abs().max().item() <= eps + 1e-7
+    assert adv.min().item() >= 0.0 and adv.max().item() <= 1.0
+    # alpha > eps: one step saturates the ball, so a second step with the same gradient is a fixed point
+    assert torch.equal(ops.pgd_linf_step(adv, g, x01, alpha, eps), adv)
+    rows = [0, 1, 63, 64, 127]
+    sub = lambda t: host(t[rows])
+    assert same(sub(adv), K.pgd_linf_step(sub(adv), sub(g), sub(x01), alpha, eps))
+    assert same(sub(x01), K.minmax_normalize(sub(x))[0])
+    l2 = ops.pgd_l2_step(x01, g, x01, 0.2, 0.1)
+    assert ((l2 - x01).norm(dim=1) <= 0.1 * (1 + 1e-5)).all()
+
+
+def test_error_behaviour(ops, cuda):
+    from audio_deepfake_adversarial_attacks_amd._lib import AdvstepError
+    x = torch.rand(2, 100)
+    with pytest.raises(AdvstepError, match="no CPU fallback"):
+        ops.to_minmax(x)                                   # CPU tensor: refused, never silently computed
+    with pytest.raises(TypeError):
+        ops.fgsm_step(x.double().to(cuda), x.double().to(cuda), 0.1)
+    with pytest.raises(ValueError):
+        ops.pgd_linf_step(x.to(cuda), x.to(cuda)[:, :50], x.to(cuda), 0.1, 0.1)
+    with pytest.raises(ValueError):
+        ops.fgsm_step(x.to(cuda).t(), x.to(cuda).t(), 0.1)  # non-contiguous
+    # empty batch is a no-op, not an error
+    e = torch.empty(0, 100, device=cuda)
+    assert ops.pgd_linf_step(e, e, e, 0.1, 0.1).shape == (0, 100)

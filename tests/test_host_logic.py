@@ -1,0 +1,255 @@
+"""CPU: host logic of the product package — Attack plugin API, registry, metrics, sharding — with the oracle's op
+table injected where waveform arithmetic is needed (the product itself has no CPU path)."""
+import numpy as np
+import pytest
+import torch
+
+from audio_deepfake_adversarial_attacks_amd import metrics, torchattacks
+from audio_deepfake_adversarial_attacks_amd.aa.aa_types import AttackEnum
+from audio_deepfake_adversarial_attacks_amd.evaluation import ShardedBatchSampler, format_report, shard_bounds
+from oracle import torch_ops
+from tests.helpers import Surrogate, surrogate_from
+
+T = torch.from_numpy
+
+
+@pytest.fixture(autouse=True)
+def one_thread():
+    n = torch.get_num_threads()
+    torch.set_num_threads(1)
+    yield
+    torch.set_num_threads(n)
+
+
+def armed(cls, model, **kw):
+    atk = cls(model, **kw)
+    atk.ops = torch_ops
+    atk.set_training_mode(model_training=True, batchnorm_training=False)
+    return atk
+
+
+# ---- the plugin API ----------------------------------------------------------------------------------------------
+
+def test_constructor_signatures_and_defaults():
+    m = Surrogate()
+    a = torchattacks.FGSM(m)
+    assert (a.eps, a.attack) == (0.007, "FGSM")
+    a = torchattacks.PGD(m)
+    assert (a.eps, a.alpha, a.steps, a.random_start) == (0.3, 2 / 255, 40, True)
+    a = torchattacks.PGDL2(m)
+    assert (a.eps, a.alpha, a.steps, a.random_start, a.eps_for_division) == (1.0, 0.2, 40, True, 1e-10)
+    a = torchattacks.CW(m)
+    assert (a.c, a.kappa, a.steps, a.lr) == (1e-4, 0, 1000, 0.01)
+    assert a.device == next(m.parameters()).device and a.model is m and a.model_name == "Surrogate"
+    assert str(torchattacks.PGD(m, eps=0.003)) == ("PGD(model_name=Surrogate, device=cpu, eps=0.003, "
+                                                   "alpha=0.00784313725490196, steps=40, random_start=True, "
+                                                   "attack_mode=default, return_type=float)")
+
+
+def test_mode_and_return_type_errors():
+    m = Surrogate()
+    base = torchattacks.Attack("X", m)
+    with pytest.raises(NotImplementedError):
+        base.forward(None, None)
+    with pytest.raises(ValueError, match="Targeted mode is not supported"):
+        base.set_mode_targeted_by_function(None)
+    with pytest.raises(ValueError, match="not a valid type"):
+        base.set_return_type("uint8")
+    a = torchattacks.PGD(m)
+    a.set_mode_targeted_by_function(lambda images, labels: 1 - labels)
+    assert a.get_mode() == "targeted" and a._targeted
+    a.set_mode_default()
+    assert a.get_mode() == "default" and not a._targeted
+    a.set_return_type("int")
+    assert a._return_type == "int"
+
+
+def test_call_juggles_training_mode_like_the_reference():
+    """attack.py:308-331: train() for the attack, BatchNorm/Dropout forced to eval, previous mode restored."""
+    seen = {}
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.conv = torch.nn.Conv1d(1, 2, 5)
+            self.bn = torch.nn.BatchNorm1d(2)
+            self.drop = torch.nn.Dropout(0.5)
+            self.rnn = torch.nn.GRU(2, 2, batch_first=True)
+            self.fc = torch.nn.Linear(2, 1)
+
+        def forward(self, x):
+            seen.update(net=self.training, bn=self.bn.training, drop=self.drop.training, rnn=self.rnn.training)
+            h = self.drop(self.bn(self.conv(x.unsqueeze(1))))
+            o, _ = self.rnn(h.transpose(1, 2))
+            return self.fc(o.mean(1))
+
+    net = Net().eval()
+    x, y = torch.rand(2, 64), torch.tensor([0, 1])
+    atk = armed(torchattacks.FGSM, net, eps=0.01)
+    atk(x, y)
+    assert seen == {"net": True, "bn": False, "drop": False, "rnn": True}
+    # reference quirk kept (attack.py:325-326 only restores TRAIN mode): a model that was in eval mode is left in
+    # train mode with its BatchNorm / Dropout layers in eval
+    assert net.training and not net.bn.training and not net.drop.training
+    atk.set_training_mode(model_training=True, batchnorm_training=True, dropout_training=True)
+    atk(x, y)
+    assert seen == {"net": True, "bn": True, "drop": True, "rnn": True}
+    atk.set_training_mode(model_training=False)
+    net.train()
+    atk(x, y)
+    assert seen["net"] is False and net.training  # eval during the attack, caller's train mode restored
+
+
+def test_inputs_are_not_mutated_and_output_is_detached():
+    m = Surrogate()
+    x, y = torch.rand(3, 256), torch.tensor([0, 1, 1])
+    x0 = x.clone()
+    for cls, kw in ((torchattacks.FGSM, {"eps": 0.01}), (torchattacks.PGD, {"eps": 0.01, "steps": 2}),
+                    (torchattacks.PGDL2, {"eps": 0.1, "steps": 2}), (torchattacks.CW, {"c": 1.0, "steps": 3})):
+        adv = armed(cls, m, **kw)(x, y)
+        assert torch.equal(x, x0) and not adv.requires_grad and adv.shape == x.shape and adv.dtype == torch.float32
+        assert adv.data_ptr() != x.data_ptr()
+        assert adv.min() >= 0 and adv.max() <= 1
+
+
+def test_return_type_int():
+    m = Surrogate()
+    atk = armed(torchattacks.FGSM, m, eps=0.01)
+    atk.set_return_type("int")
+    assert atk(torch.rand(2, 64), torch.tensor([0, 1])).dtype == torch.uint8
+
+
+def test_product_attacks_with_oracle_ops_reproduce_reference(golden):
+    """Host logic + oracle kernels == reference outputs: bit-exact for the sign attacks, norm tolerance for PGDL2,
+    stated tolerance for CW."""
+    g = golden("fgsm")
+    m = surrogate_from(g)
+    for e, eps in (("e0005", 0.0005), ("e001", 0.001)):
+        adv = armed(torchattacks.FGSM, m, eps=eps)(T(g[f"ragged_{e}_x"]), T(g[f"ragged_{e}_y"]))
+        assert torch.equal(adv, T(g[f"ragged_{e}_adv"]))  # north-star bound for FGSM: 1e-5 max-abs; we get 0
+    g = golden("pgd_linf")
+    m = surrogate_from(g)
+    for tag in ("ragged_rs", "small_nors", "full_rs"):
+        atk = armed(torchattacks.PGD, m, eps=float(g[tag + "_eps"]), steps=int(g[tag + "_steps"]),
+                    random_start=tag.endswith("_rs"))
+        if tag + "_noise" in g:
+            atk.set_init_noise(T(g[tag + "_noise"]))
+        assert torch.equal(atk(T(g[tag + "_x"]), T(g[tag + "_y"])), T(g[tag + "_adv"])), tag
+    g = golden("pgd_l2")
+    m = surrogate_from(g)
+    for tag in ("ragged_rs", "small_nors"):
+        atk = armed(torchattacks.PGDL2, m, eps=float(g[tag + "_eps"]), steps=int(g[tag + "_steps"]),
+                    random_start=tag.endswith("_rs"))
+        if tag + "_normal" in g:
+            atk.set_init_noise((T(g[tag + "_normal"]), T(g[tag + "_r"])))
+        adv = atk(T(g[tag + "_x"]), T(g[tag + "_y"]))
+        assert (adv - T(g[tag + "_adv"])).abs().max() <= 3e-7, tag
+    g = golden("cw")
+    m = surrogate_from(g)
+    best = armed(torchattacks.CW, m, c=float(g["c"]), steps=int(g["steps"]), lr=float(g["lr"]))(T(g["x"]), T(g["y"]))
+    err = (best - T(g["best"])).abs()
+    # CW tolerance: Adam turns rounding-level gradients into +-lr moves on a handful of coordinates
+    assert err.mean() <= 1e-6 and (err > 1e-4).float().mean() <= 1e-3 and err.max() <= 0.02
+    unchanged = T(g["best"]) == T(g["x"])
+    assert torch.equal(best == T(g["x"]), unchanged) or (best == T(g["x"])).float().mean() > 0.2
+
+
+def test_random_start_uses_global_generator_and_stays_in_ball():
+    m = Surrogate()
+    x, y = torch.rand(2, 500), torch.tensor([1, 0])
+    atk = armed(torchattacks.PGD, m, eps=0.01, steps=1)
+    torch.manual_seed(5)
+    a = atk(x, y)
+    torch.manual_seed(5)
+    b = atk(x, y)
+    c = atk(x, y)
+    assert torch.equal(a, b) and not torch.equal(a, c) and (a - x).abs().max() <= 0.01 + 1e-7
+
+
+def test_targeted_mode_flips_the_gradient_sign():
+    m = Surrogate()
+    x, y = torch.rand(2, 300) * 0.5 + 0.25, torch.tensor([1, 0])
+    plain = armed(torchattacks.FGSM, m, eps=0.01)(x, y)
+    atk = armed(torchattacks.FGSM, m, eps=0.01)
+    atk.set_mode_targeted_by_function(lambda images, labels: labels)  # target == label -> cost = -CE -> opposite step
+    tgt = atk(x, y)
+    assert torch.allclose((plain - x), -(tgt - x), atol=1e-7)
+
+
+def test_attack_without_library_or_gpu_fails_loudly():
+    """The default op table is the HIP one: on a CPU model it must refuse, never fall back."""
+    from audio_deepfake_adversarial_attacks_amd._lib import AdvstepError
+    atk = torchattacks.FGSM(Surrogate(), eps=0.01)
+    with pytest.raises(AdvstepError, match="no CPU fallback"):
+        atk(torch.rand(2, 64), torch.tensor([0, 1]))
+
+
+# ---- registry --------------------------------------------------------------------------------------------------------
+
+def test_attack_enum_keeps_reference_members_and_adds_baseline_configs():
+    ref = {  # src/aa/aa_types.py:8-18,24
+        "PGD": ("PGD", {"eps": 0.0005, "steps": 10}), "PGD_eps00075": ("PGD", {"eps": 0.00075, "steps": 10}),
+        "PGD_eps001": ("PGD", {"eps": 0.001, "steps": 10}), "PGDL2": ("PGDL2", {"eps": 0.1, "steps": 10}),
+        "PGDL2_eps15": ("PGDL2", {"eps": 0.15, "steps": 10}), "PGDL2_eps20": ("PGDL2", {"eps": 0.20, "steps": 10}),
+        "FGSM": ("FGSM", {"eps": 0.0005}), "FGSM_eps00075": ("FGSM", {"eps": 0.00075}),
+        "FGSM_eps001": ("FGSM", {"eps": 0.001}),
+    }
+    for name, (cls, kw) in ref.items():
+        got_cls, got_kw = AttackEnum[name].value
+        assert got_cls.__name__ == cls and got_kw == kw
+    assert AttackEnum.NO_ATTACK.value == (None, {})
+    cls, kw = AttackEnum.PGD40_eps003.value
+    assert cls is torchattacks.PGD and kw == {"eps": 0.003, "steps": 40}
+    assert AttackEnum.PGDL2_40.value[1]["steps"] == 40 and AttackEnum.CW.value[0] is torchattacks.CW
+
+
+# ---- metrics -----------------------------------------------------------------------------------------------------------
+
+def test_metrics_match_the_reference_calls(golden):
+    g = golden("metrics")
+    for tag in ("random", "separable", "tiny"):
+        y, s = g[tag + "_y"], g[tag + "_score"]
+        thresh, eer, fpr, tpr = metrics.calculate_eer(1 - y, s)
+        assert abs(eer - g[tag + "_eer"]) <= 1e-12 and abs(thresh - g[tag + "_thresh"]) <= 1e-12
+        rep = metrics.adversarial_report(y, s, (s + 0.5).astype(np.int32))
+        for k in ("precision", "recall", "f1", "auc", "accuracy"):
+            key = "adv_eval/" + ("f1_score" if k == "f1" else k)
+            assert abs(rep[key] - g[f"{tag}_{k}"]) <= 1e-12, (tag, k)
+    line = format_report(rep)
+    assert line.startswith("adv_eval/eer: ") and line.count("adv_eval/") == 6 and "adv_eval/auc" in line
+
+
+def test_metrics_edge_cases():
+    with pytest.raises(ValueError):
+        metrics.roc_auc_score(np.ones(4), np.arange(4.0))
+    assert metrics.precision_recall_f1_binary([0, 0], [0, 0]) == (0.0, 0.0, 0.0)
+    y = np.array([0, 0, 1, 1])
+    _, eer, _, _ = metrics.calculate_eer(1 - y, np.array([0.1, 0.2, 0.8, 0.9], np.float32))
+    assert eer == 0.0
+    assert metrics.roc_auc_score(y, [0.1, 0.2, 0.8, 0.9]) == 1.0
+
+
+# ---- sharding ------------------------------------------------------------------------------------------------------------
+
+def test_shard_bounds_match_torch_chunk():
+    for n in (1, 7, 8, 64, 128, 1000, 1024):
+        for world in (1, 2, 3, 4, 8):
+            chunks = torch.arange(n).chunk(world)
+            for r in range(world):
+                lo, hi = shard_bounds(n, r, world)
+                want = chunks[r].tolist() if r < len(chunks) else []
+                assert list(range(lo, hi)) == want, (n, world, r)
+
+
+def test_sharded_sampler_partitions_every_global_batch():
+    n, gb, world = 1000, 64, 4
+    per_rank = [list(ShardedBatchSampler(n, gb, r, world, shuffle=True, seed=3)) for r in range(world)]
+    assert all(len(p) == n // gb for p in per_rank)
+    ref = list(ShardedBatchSampler(n, gb, 0, 1, shuffle=True, seed=3))
+    for b in range(n // gb):
+        glued = sum((per_rank[r][b] for r in range(world)), [])
+        assert glued == ref[b] and len(set(glued)) == gb           # contiguous chunks, in rank order
+    assert sorted(sum(ref, [])) != sum(ref, [])                     # shuffled
+    assert len(set(sum(ref, []))) == (n // gb) * gb                 # drop_last, no repeats
+    with pytest.raises(ValueError):
+        ShardedBatchSampler(n, 65, 0, 4)

@@ -1,0 +1,132 @@
+"""CPU: the detector restatements against logits / input-gradients produced by the reference's own BaseLCNN and
+BaseSpecRNet (tests/golden/*_body.npz), plus structure checks for RawNet3 (whose first layer is parity-unpinned)."""
+import pytest
+import torch
+
+from audio_deepfake_adversarial_attacks_amd.models import lcnn, models, rawnet3, sincfb, specrnet
+
+T = torch.from_numpy
+
+
+@pytest.fixture(autouse=True)
+def one_thread():
+    n = torch.get_num_threads()
+    torch.set_num_threads(1)
+    yield
+    torch.set_num_threads(n)
+
+
+def sd_of(fixture):
+    return {k[3:]: T(v) for k, v in fixture.items() if k.startswith("sd_")}
+
+
+def attack_mode(model):
+    model.train()
+    for m in model.modules():
+        if "BatchNorm" in m.__class__.__name__ or "Dropout" in m.__class__.__name__:
+            m.eval()
+    return model
+
+
+def test_lcnn_body_equals_reference(golden):
+    g = golden("lcnn_body")
+    body = lcnn.BaseLCNN(input_channels=1, num_coefficients=80).eval()
+    body.load_state_dict(sd_of(g), strict=True)           # the reference's key names
+    spec = T(g["spec"])
+    with torch.no_grad():
+        assert torch.equal(body(spec), T(g["logits"]))
+    s = spec.clone().requires_grad_(True)
+    out = attack_mode(body)(s)
+    assert torch.equal(out, T(g["logits_attackmode"]))
+    (grad,) = torch.autograd.grad(out.sum(), s)
+    assert torch.equal(grad, T(g["grad_spec"]))
+
+
+def test_lcnn_state_dict_layout():
+    m = models.get_model("lcnn", {"frontend_algorithm": ["lfcc"], "input_channels": 1}, "cpu")
+    keys = set(m.state_dict())
+    for i in (0, 3, 6, 10, 13, 16, 19, 22, 25):                       # SURVEY.md section 5 (checkpoint key names)
+        assert f"m_transform.{i}.weight" in keys and f"m_transform.{i}.bias" in keys
+    for i in (5, 9, 12, 18, 21, 24):
+        assert f"m_transform.{i}.running_mean" in keys and f"m_transform.{i}.weight" not in keys  # affine=False
+    assert {"m_before_pooling.0.l_blstm.weight_ih_l0", "m_before_pooling.1.l_blstm.weight_hh_l0_reverse",
+            "m_output_act.weight", "frontend.filter_mat", "frontend.dct_mat", "frontend.Spectrogram.window"} <= keys
+    assert sum(p.numel() for p in m.parameters()) == 467_425
+    out = m(torch.rand(2, 64_600))
+    assert out.shape == (2, 1)
+
+
+def test_specrnet_body_equals_reference(golden):
+    g = golden("specrnet_body")
+    body = specrnet.BaseSpecRNet(specrnet.get_config(2), device="cpu").eval()
+    body.load_state_dict(sd_of(g), strict=True)
+    with torch.no_grad():
+        assert torch.equal(body(T(g["spec"])), T(g["logits"]))
+    assert sum(p.numel() for p in body.parameters()) == 278_165       # SURVEY.md section 2 (2 input channels)
+
+
+def test_specrnet_full_model_and_registry():
+    m = models.get_model("specrnet", {"frontend_algorithm": ["mel_spec"], "input_channels": 2}, "cpu")
+    assert m(torch.rand(2, 64_600)).shape == (2, 1)
+    assert not any(k.startswith("frontend") for k in m.state_dict())
+    with pytest.raises(ValueError, match="not supported"):
+        models.get_model("frontend_specrnet", {}, "cpu")              # the reference's own broken config name
+
+
+def test_mfm_validates_its_input():
+    mfm = lcnn.MaxFeatureMap2D()
+    x = torch.rand(2, 6, 3, 3)
+    assert torch.equal(mfm(x), torch.maximum(x[:, :3], x[:, 3:]))
+    with pytest.raises(ValueError):
+        mfm(torch.rand(2, 5, 3, 3))
+    with pytest.raises(ValueError):
+        lcnn.MaxFeatureMap2D(max_dim=4)(x)
+    with pytest.raises(ValueError):
+        lcnn.BLSTMLayer(8, 7)
+
+
+def test_sinc_filterbank_properties():
+    fb = sincfb.ParamSincFB(256, 251, stride=10)
+    filt = fb.filters()
+    assert filt.shape == (256, 1, 251) and torch.isfinite(filt).all()
+    cos, sin = filt[:128, 0], filt[128:, 0]
+    assert torch.allclose(cos, cos.flip(1), atol=1e-6)                # even filters
+    assert torch.allclose(sin, -sin.flip(1), atol=1e-6)               # odd filters
+    assert torch.allclose(cos[:, 125], torch.ones(128), atol=1e-6)    # centre tap 2*band / (2*band)
+    assert sorted(fb.state_dict()) == ["band_hz_", "low_hz_", "n_", "window_"]
+    low = 50 + fb.low_hz_.abs().squeeze()
+    assert (low[1:] > low[:-1]).all() and low[0] >= 80 - 1e-3          # mel-spaced from 30 Hz + min_low_hz
+    # pass-band check: filter k responds to a tone inside its band far more than to one outside
+    t = torch.arange(251) / 16_000.0
+    k = 40
+    lo_hz = float(low[k])
+    hi_hz = lo_hz + 50 + float(fb.band_hz_.abs()[k])
+    inside = torch.cos(2 * torch.pi * (lo_hz + hi_hz) / 2 * t)
+    outside = torch.cos(2 * torch.pi * (hi_hz + 1500) * t)
+    assert (cos[k] * inside).sum().abs() > 10 * (cos[k] * outside).sum().abs()
+    enc = sincfb.Encoder(fb)
+    assert enc(torch.rand(2, 64_600)).shape == (2, 256, 6435)
+
+
+def test_rawnet3_structure_and_forward():
+    m = rawnet3.prepare_model().eval()
+    n_params = sum(p.numel() for p in m.parameters())
+    assert 15_000_000 < n_params < 16_500_000                         # "~15.5 M params" 
+    keys = set(m.state_dict())
+    assert {"preprocess.0.flipped_filter", "preprocess.1.weight", "conv1.filterbank.low_hz_", "bn1.weight",
+            "layer1.conv1.weight", "layer1.convs.6.weight", "layer1.afms.alpha", "layer1.residual.0.weight",
+            "layer4.weight", "attention.0.weight", "attention.3.weight", "bn5.running_mean", "fc6.weight"} <= keys
+    x = torch.rand(2, 16_000, requires_grad=True)
+    out = m(x)
+    assert out.shape == (2, 1) and torch.isfinite(out).all()
+    (g,) = torch.autograd.grad(out.sum(), x)
+    assert torch.isfinite(g).all() and g.abs().max() > 0
+
+
+def test_preemphasis_matches_definition():
+    x = torch.rand(2, 50)
+    y = rawnet3.PreEmphasis()(x)
+    want = x.clone()
+    want[:, 1:] = x[:, 1:] - 0.97 * x[:, :-1]
+    want[:, 0] = x[:, 0] - 0.97 * x[:, 1]       # reflect padding on the left
+    assert torch.allclose(y.squeeze(1), want, atol=1e-6)
