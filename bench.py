@@ -194,7 +194,7 @@ def main():
             "adv_eval": {k.split("/")[1]: round(v, 4) for k, v in report.items()},
         }
         if world == 1 and not args.no_cpu_baseline:
-            threads = args.cpu_threads or min(os.cpu_count() or 1, 64)
+            threads = args.cpu_threads or min(os.cpu_count() or 1, 16)  # fastest of 8..128 on the 256-thread EPYC box (profiles/)
             line["cpu_baseline"] = cpu_baseline(args.cpu_sample, threads)
         print(json.dumps(line), flush=True)
 

@@ -1,0 +1,57 @@
+/*
+ * advstep_lcnn.h — C ABI of the LCNN max-feature-map kernels in libadvstep.so.
+ *
+ * They replace, inside the attacked LCNN's forward + input-backward pass, the eager chains of
+ *   src/models/lcnn.py:76-95   MaxFeatureMap2D.forward:  inputs.view(N, 2, C, H, W).max(1)   (values + int64 indices;
+ *                              backward = zeros + scatter_)
+ *   src/models/lcnn.py:123,129,137,154   torch.nn.MaxPool2d((2, 2), (2, 2)) that follows four of the nine MFMs
+ * which are pure HBM streaming over the largest activations of the model ((B, 64, 404, 80) f32 = 1.06 GB at
+ * B = 128).  Selection is recorded in one byte per 4 outputs (MFM) / one byte per pooled output (MFM + pool)
+ * instead of int64 indices, and the backward pass writes the (mostly zero) input gradient in one coalesced pass.
+ *
+ * Semantics are those of the ATen kernels being replaced, bit for bit, including ties and NaN:
+ *   MFM     y = a if (isnan(a) || a >= b) else b,  a = x[n, c], b = x[n, c + C]      (lower index wins a tie)
+ *   pool    scan (dh, dw) in row-major order, take v when (v > best || isnan(v)), best starts at -inf
+ * Conventions as in advstep.h: contiguous NCHW float32 device pointers, caller-owned outputs, stream-ordered,
+ * status codes.
+ */
+#ifndef ADVSTEP_LCNN_H_
+#define ADVSTEP_LCNN_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "advstep.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Bytes of the selection buffer for an MFM over x (N, 2C, HW): one byte per group of 4 consecutive outputs of a
+ * sample, N * ceil(C*HW / 4). */
+size_t advstep_mfm_sel_bytes(int64_t N, int64_t C, int64_t HW);
+
+/* y (N, C, HW) = max-feature-map of x (N, 2C, HW); sel receives, per group of 4 outputs, bit k = 1 when output k
+ * came from the second half of the channels. */
+int advstep_mfm_forward_f32(const float *x, float *y, uint8_t *sel, int64_t N, int64_t C, int64_t HW,
+                            advstep_stream_t stream);
+
+/* gx (N, 2C, HW) from gy (N, C, HW): the gradient goes to the selected half, the other half gets 0. */
+int advstep_mfm_backward_f32(const float *gy, const uint8_t *sel, float *gx, int64_t N, int64_t C, int64_t HW,
+                             advstep_stream_t stream);
+
+/* y (N, C, H/2, W/2) = MaxPool2d(2, 2)(MFM(x)), x (N, 2C, H, W) (floor division: a trailing odd row / column is
+ * dropped, as with ceil_mode=False).  idx receives one byte per pooled output: bit 2 = second channel half,
+ * bit 1 = dh, bit 0 = dw of the winning input. */
+int advstep_mfm_pool2_forward_f32(const float *x, float *y, uint8_t *idx, int64_t N, int64_t C, int64_t H, int64_t W,
+                                  advstep_stream_t stream);
+
+/* gx (N, 2C, H, W) from gy (N, C, H/2, W/2) and idx: every input position receives either the pooled gradient
+ * (the winner) or 0 — including a trailing odd row / column. */
+int advstep_mfm_pool2_backward_f32(const float *gy, const uint8_t *idx, float *gx, int64_t N, int64_t C, int64_t H,
+                                   int64_t W, advstep_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADVSTEP_LCNN_H_ */

@@ -100,7 +100,7 @@ def test_pgdl2_matches_reference_output(cuda, checked, golden):
         # L2 attacks are smooth in the gradient: element-wise tolerance 2e-6 (3 steps of <= 3e-7 norm-order error
         # plus GPU-vs-CPU conv rounding in the gradient direction)
         assert (adv - want).abs().max().item() <= 2e-6
-        assert ((adv - x).norm(dim=1) <= eps * (1 + 1e-5)).all()
+        assert ((adv - x).norm(dim=1) <= eps * (1 + 1e-4)).all()
         assert ops.calls["pgd_l2_step"] == steps
 
 
@@ -141,7 +141,7 @@ def test_attacks_on_lcnn_every_launch_checked(cuda, checked, lcnn_model, attack,
         assert (adv01 - x01).abs().max().item() <= kw["eps"] + 1e-7
         assert ((adv01 - x01).abs() > 0).float().mean().item() > 0.99      # the attack did move the waveform
     if attack == "PGDL2":
-        assert ((adv01 - x01).norm(dim=1) <= kw["eps"] * (1 + 1e-5)).all()
+        assert ((adv01 - x01).norm(dim=1) <= kw["eps"] * (1 + 1e-4)).all()
     # attack.py:311-326 quirk kept: a model that entered in eval mode is left in train mode, BatchNorm/Dropout in eval
     assert not lcnn_model.m_transform[5].training and lcnn_model.m_before_pooling[0].l_blstm.training
     lcnn_model.eval()

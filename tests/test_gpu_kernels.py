@@ -179,7 +179,7 @@ def test_pgd_l2_vs_oracle(ops, cuda, B, T):
         np.testing.assert_allclose(host(dn), wdn, rtol=2e-6)
         np.testing.assert_allclose(host(got), want, atol=3e-7, rtol=0)
         # the L2-ball invariant, with float slack
-        assert (np.linalg.norm((host(got) - x).astype(np.float64), axis=1) <= eps * (1 + 1e-5) + 1e-6).all()
+        assert (np.linalg.norm((host(got) - x).astype(np.float64), axis=1) <= eps * (1 + 1e-4) + 1e-6).all()
     normal, r = randn((B, T), 14 + T), rand01((B,), 15 + T)
     got = ops.pgd_l2_init(dev(x, cuda), 0.1, draws=(dev(normal, cuda), dev(r, cuda)))
     np.testing.assert_allclose(host(got), K.pgd_l2_init_noise(x, normal, r, 0.1), atol=3e-7, rtol=0)
@@ -269,7 +269,7 @@ def test_full_size_properties(ops, cuda):
     assert same(sub(adv), K.pgd_linf_step(sub(adv), sub(g), sub(x01), alpha, eps))
     assert same(sub(x01), K.minmax_normalize(sub(x))[0])
     l2 = ops.pgd_l2_step(x01, g, x01, 0.2, 0.1)
-    assert ((l2 - x01).norm(dim=1) <= 0.1 * (1 + 1e-5)).all()
+    assert ((l2 - x01).norm(dim=1) <= 0.1 * (1 + 1e-4)).all()  # f32 rounding of x + d*f moves the norm by ~1e-5 relative
 
 
 def test_error_behaviour(ops, cuda):
