@@ -13,7 +13,7 @@ ABI_VERSION = 1
 _p, _i64, _f32, _f64, _u64, _sz = (ctypes.c_void_p, ctypes.c_int64, ctypes.c_float, ctypes.c_double,
                                    ctypes.c_uint64, ctypes.c_size_t)
 
-# name -> (restype, argtypes); one entry per symbol declared in include/advstep.h
+# name -> (restype, argtypes); one entry per symbol declared in include/advstep.h and include/advstep_lcnn.h
 SIGNATURES = {
     "advstep_abi_version": (ctypes.c_int, []),
     "advstep_status_string": (ctypes.c_char_p, [ctypes.c_int]),
@@ -34,6 +34,12 @@ SIGNATURES = {
     "advstep_cw_adam_step_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _i64, _f64, _f64, _f64, _f64, _p]),
     "advstep_cw_best_update_f32": (ctypes.c_int, [_p, _p, _p, _i64, _i64, _p]),
     "advstep_ce2_loss_grad_f32": (ctypes.c_int, [_p, _p, _p, _p, _i64, _f32, _p]),
+    # include/advstep_lcnn.h
+    "advstep_mfm_sel_bytes": (_sz, [_i64, _i64, _i64]),
+    "advstep_mfm_forward_f32": (ctypes.c_int, [_p, _p, _p, _p, _i64, _i64, _i64, _p]),
+    "advstep_mfm_backward_f32": (ctypes.c_int, [_p, _p, _p, _i64, _i64, _i64, _p]),
+    "advstep_mfm_pool2_forward_f32": (ctypes.c_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _p]),
+    "advstep_mfm_pool2_backward_f32": (ctypes.c_int, [_p, _p, _p, _i64, _i64, _i64, _i64, _p]),
 }
 
 

@@ -1,4 +1,4 @@
-"""Compile csrc/advstep.hip into libadvstep.so for gfx950 (hipcc cross-compiles without a GPU)."""
+"""Compile csrc/*.hip into libadvstep.so for gfx950 (hipcc cross-compiles without a GPU)."""
 from __future__ import annotations
 
 import shutil
@@ -7,8 +7,8 @@ from pathlib import Path
 
 PKG = Path(__file__).resolve().parent
 ROOT = PKG.parent
-SRC = PKG / "csrc" / "advstep.hip"
-HDR = ROOT / "include" / "advstep.h"
+SOURCES = [PKG / "csrc" / "advstep.hip", PKG / "csrc" / "lcnn_mfm.hip"]
+HEADERS = [ROOT / "include" / "advstep.h", ROOT / "include" / "advstep_lcnn.h"]
 LIB = PKG / "libadvstep.so"
 
 # -ffp-contract=off: the kernels must round exactly like the reference's one-ATen-op-per-expression chains
@@ -17,11 +17,11 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
 
 
 def build(force: bool = False, verbose: bool = False) -> Path:
-    newest_src = max(SRC.stat().st_mtime, HDR.stat().st_mtime)
+    newest_src = max(p.stat().st_mtime for p in SOURCES + HEADERS)
     if not force and LIB.exists() and LIB.stat().st_mtime >= newest_src:
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc, *HIPCC_FLAGS, f"-I{ROOT / 'include'}", str(SRC), "-o", str(LIB)]
+    cmd = [hipcc, *HIPCC_FLAGS, f"-I{ROOT / 'include'}", *map(str, SOURCES), "-o", str(LIB)]
     if verbose:
         print(" ".join(cmd))
     proc = subprocess.run(cmd, capture_output=True, text=True)

@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "advstep.h"
 
@@ -165,17 +166,17 @@ __device__ __forceinline__ float reduce_partials(const float *__restrict__ part,
 // flat elementwise kernels: n = B*T samples, tile-strided, float4 when all pointers are 16-byte aligned
 // ---------------------------------------------------------------------------------------------------------
 
-// Generic driver: NIN input streams, one output stream, Op applied per sample.
-template <int NIN, class Op>
+// Generic driver: NIN input streams, one output stream, Op applied per sample; VECS float4 per thread per stream.
+template <int NIN, int VECS, class Op>
 __global__ __launch_bounds__(kBlock) void flat_vec_kernel(const float4 *__restrict__ in0,
                                                           const float4 *__restrict__ in1,
                                                           const float4 *__restrict__ in2, float4 *out, int64_t n4,
                                                           int64_t ntiles, Op op) {
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int64_t base = tile * kTileVec + threadIdx.x;
-        float4 a[kVecs] = {}, b[kVecs] = {}, c[kVecs] = {};
+        const int64_t base = tile * (kBlock * VECS) + threadIdx.x;
+        float4 a[VECS] = {}, b[VECS] = {}, c[VECS] = {};
 #pragma unroll
-        for (int j = 0; j < kVecs; ++j) {
+        for (int j = 0; j < VECS; ++j) {
             const int64_t i = base + (int64_t)j * kBlock;
             if (i < n4) {
                 a[j] = in0[i];
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(kBlock) void flat_vec_kernel(const float4 *__restri
             }
         }
 #pragma unroll
-        for (int j = 0; j < kVecs; ++j) {
+        for (int j = 0; j < VECS; ++j) {
             const int64_t i = base + (int64_t)j * kBlock;
             if (i < n4) {
                 float4 o;
@@ -750,6 +751,29 @@ inline bool carve_ws(void *ws, size_t ws_bytes, int64_t B, int64_t T, RowWs *out
 // grid.y is limited to 65535 rows per launch; batches beyond that are launched in slabs.
 constexpr int64_t kMaxRowsPerLaunch = 65535;
 
+// float4 per thread per stream of the flat kernels.  Measured on MI355X at B = 128, T = 64 600 (tools/tune_pgd_step.hip,
+// profiles/): one float4 per stream per thread (8 076 workgroups) beats 4 (2 019 workgroups) by 3 % hot / 7 % cold.
+// ADVSTEP_FLAT_VECS = 1 | 2 | 4 overrides it for experiments.
+inline int flat_vecs() {
+    static const int v = [] {
+        const char *e = getenv("ADVSTEP_FLAT_VECS");
+        const int x = e ? atoi(e) : 1;
+        return (x == 1 || x == 2 || x == 4) ? x : 1;
+    }();
+    return v;
+}
+
+template <int NIN, int VECS, class Op>
+void launch_flat_vec(const float *in0, const float *in1, const float *in2, float *out, int64_t n4, Op op,
+                     hipStream_t st) {
+    const int64_t ntiles = ceil_div(n4, kBlock * VECS);
+    const int64_t cap = (int64_t)kMaxGrid * (4 / VECS);
+    const int grid = (int)(ntiles < cap ? ntiles : cap);
+    hipLaunchKernelGGL((flat_vec_kernel<NIN, VECS, Op>), dim3(grid), dim3(kBlock), 0, st,
+                       reinterpret_cast<const float4 *>(in0), reinterpret_cast<const float4 *>(in1),
+                       reinterpret_cast<const float4 *>(in2), reinterpret_cast<float4 *>(out), n4, ntiles, op);
+}
+
 template <int NIN, class Op>
 int launch_flat(const float *in0, const float *in1, const float *in2, float *out, int64_t n, Op op,
                 hipStream_t st) {
@@ -757,11 +781,11 @@ int launch_flat(const float *in0, const float *in1, const float *in2, float *out
     const bool vec = aligned16(in0) && aligned16(out) && (NIN < 2 || aligned16(in1)) && (NIN < 3 || aligned16(in2));
     const int64_t n4 = vec ? n / 4 : 0;
     if (n4 > 0) {
-        const int64_t ntiles = ceil_div(n4, kTileVec);
-        const int grid = (int)(ntiles < kMaxGrid ? ntiles : kMaxGrid);
-        hipLaunchKernelGGL((flat_vec_kernel<NIN, Op>), dim3(grid), dim3(kBlock), 0, st,
-                           reinterpret_cast<const float4 *>(in0), reinterpret_cast<const float4 *>(in1),
-                           reinterpret_cast<const float4 *>(in2), reinterpret_cast<float4 *>(out), n4, ntiles, op);
+        switch (flat_vecs()) {
+            case 4: launch_flat_vec<NIN, 4>(in0, in1, in2, out, n4, op, st); break;
+            case 2: launch_flat_vec<NIN, 2>(in0, in1, in2, out, n4, op, st); break;
+            default: launch_flat_vec<NIN, 1>(in0, in1, in2, out, n4, op, st); break;
+        }
     }
     const int64_t begin = n4 * 4;
     if (begin < n) {

@@ -37,9 +37,13 @@ __device__ __forceinline__ bool mfm_takes_b(float a, float b) { return !(a != a)
 // MFM alone: per sample, P = C*HW outputs, G = ceil(P / 4) groups; thread = one group of 4 outputs
 // ---------------------------------------------------------------------------------------------------------
 
+// bias (2C) may be null; when given, a = x[n, c] + bias[c], b = x[n, c + C] + bias[c + C] (the conv's bias add,
+// evaluate_... conv -> add_(bias) -> max, folded into this pass; one rounding, like ATen's separate add kernel).
 template <bool VEC>
-__global__ __launch_bounds__(kBlock) void mfm_forward_kernel(const float *__restrict__ x, float *__restrict__ y,
-                                                             uint8_t *__restrict__ sel, int64_t P, int64_t G) {
+__global__ __launch_bounds__(kBlock) void mfm_forward_kernel(const float *__restrict__ x,
+                                                             const float *__restrict__ bias, float *__restrict__ y,
+                                                             uint8_t *__restrict__ sel, int64_t P, int64_t G,
+                                                             int64_t HW, int64_t C) {
     const int64_t n = blockIdx.y;
     const float *xa = x + n * 2 * P;
     const float *xb = xa + P;
@@ -64,6 +68,27 @@ __global__ __launch_bounds__(kBlock) void mfm_forward_kernel(const float *__rest
                 b[k].z = (i + 2 < P) ? xb[i + 2] : 0.0f;
                 a[k].w = (i + 3 < P) ? xa[i + 3] : 0.0f;
                 b[k].w = (i + 3 < P) ? xb[i + 3] : 0.0f;
+            }
+        }
+    }
+    if (bias) {
+#pragma unroll
+        for (int k = 0; k < kGroupsPerThread; ++k) {
+            const int64_t g = g0 + (int64_t)k * kBlock;
+            if (g < G) {
+                const int64_t i = g * 4;
+                const int64_t c0 = i / HW, c3 = (i + 3 < P ? i + 3 : P - 1) / HW;
+                if (c0 == c3) {  // the usual case: the 4 outputs share a channel
+                    const float ba = bias[c0], bb = bias[c0 + C];
+                    a[k].x += ba; a[k].y += ba; a[k].z += ba; a[k].w += ba;
+                    b[k].x += bb; b[k].y += bb; b[k].z += bb; b[k].w += bb;
+                } else {
+                    const int64_t c1 = (i + 1 < P ? i + 1 : P - 1) / HW, c2 = (i + 2 < P ? i + 2 : P - 1) / HW;
+                    a[k].x += bias[c0]; b[k].x += bias[c0 + C];
+                    a[k].y += bias[c1]; b[k].y += bias[c1 + C];
+                    a[k].z += bias[c2]; b[k].z += bias[c2 + C];
+                    a[k].w += bias[c3]; b[k].w += bias[c3 + C];
+                }
             }
         }
     }
@@ -166,6 +191,7 @@ __device__ __forceinline__ float pool_select(float a00, float b00, float a01, fl
 
 // VEC path (W % 4 == 0, 16-byte aligned planes): thread = (c, ho, wq) -> two pooled outputs from four float4 loads.
 __global__ __launch_bounds__(kBlock) void mfm_pool2_forward_vec_kernel(const float *__restrict__ x,
+                                                                       const float *__restrict__ bias,
                                                                        float *__restrict__ y,
                                                                        uint8_t *__restrict__ idx, int C, int H, int W) {
     const int Ho = H >> 1, W4 = W >> 2, Wo = W >> 1;
@@ -185,8 +211,13 @@ __global__ __launch_bounds__(kBlock) void mfm_pool2_forward_vec_kernel(const flo
         const int c = (int)(t / Ho);
         const float *pa = xn + c * plane + (int64_t)(2 * ho) * W + 4 * wq;
         const float *pb = pa + (int64_t)C * plane;
-        const float4 a0 = *reinterpret_cast<const float4 *>(pa), a1 = *reinterpret_cast<const float4 *>(pa + W);
-        const float4 b0 = *reinterpret_cast<const float4 *>(pb), b1 = *reinterpret_cast<const float4 *>(pb + W);
+        float4 a0 = *reinterpret_cast<const float4 *>(pa), a1 = *reinterpret_cast<const float4 *>(pa + W);
+        float4 b0 = *reinterpret_cast<const float4 *>(pb), b1 = *reinterpret_cast<const float4 *>(pb + W);
+        if (bias) {
+            const float ba = bias[c], bb = bias[c + C];
+            a0.x += ba; a0.y += ba; a0.z += ba; a0.w += ba; a1.x += ba; a1.y += ba; a1.z += ba; a1.w += ba;
+            b0.x += bb; b0.y += bb; b0.z += bb; b0.w += bb; b1.x += bb; b1.y += bb; b1.z += bb; b1.w += bb;
+        }
         int c0, c1;
         float2 o;
         o.x = pool_select(a0.x, b0.x, a0.y, b0.y, a1.x, b1.x, a1.y, b1.y, c0);
@@ -198,6 +229,7 @@ __global__ __launch_bounds__(kBlock) void mfm_pool2_forward_vec_kernel(const flo
 
 // generic path: thread = one pooled output
 __global__ __launch_bounds__(kBlock) void mfm_pool2_forward_scalar_kernel(const float *__restrict__ x,
+                                                                          const float *__restrict__ bias,
                                                                           float *__restrict__ y,
                                                                           uint8_t *__restrict__ idx, int C, int H, int W) {
     const int Ho = H >> 1, Wo = W >> 1;
@@ -213,7 +245,12 @@ __global__ __launch_bounds__(kBlock) void mfm_pool2_forward_scalar_kernel(const 
     const float *pa = x + n * 2 * C * plane + c * plane + (int64_t)(2 * ho) * W + 2 * wo;
     const float *pb = pa + (int64_t)C * plane;
     int code;
-    y[n * items + i] = pool_select(pa[0], pb[0], pa[1], pb[1], pa[W], pb[W], pa[W + 1], pb[W + 1], code);
+    const float ba = bias ? bias[c] : 0.0f, bb = bias ? bias[c + C] : 0.0f;
+    if (bias)
+        y[n * items + i] = pool_select(pa[0] + ba, pb[0] + bb, pa[1] + ba, pb[1] + bb, pa[W] + ba, pb[W] + bb,
+                                       pa[W + 1] + ba, pb[W + 1] + bb, code);
+    else
+        y[n * items + i] = pool_select(pa[0], pb[0], pa[1], pb[1], pa[W], pb[W], pa[W + 1], pb[W + 1], code);
     idx[n * items + i] = (uint8_t)code;
 }
 
@@ -240,23 +277,23 @@ __global__ __launch_bounds__(kBlock) void mfm_pool2_backward_vec_kernel(const fl
         const int c = (int)(t / Ho);
         const float2 g = reinterpret_cast<const float2 *>(gn)[i];
         const uchar2 code = reinterpret_cast<const uchar2 *>(in)[i];
-        float va[8], vb[8];  // [dh*4 + column] for the a / b half
-#pragma unroll
-        for (int k = 0; k < 8; ++k) va[k] = vb[k] = 0.0f;
-        {
-            const int p = code.x & 3, slot = (p >> 1) * 4 + (p & 1);
-            if (code.x & 4) vb[slot] = g.x; else va[slot] = g.x;
-        }
-        {
-            const int p = code.y & 3, slot = (p >> 1) * 4 + 2 + (p & 1);
-            if (code.y & 4) vb[slot] = g.y; else va[slot] = g.y;
-        }
+        // window of output 0 = columns 0-1, of output 1 = columns 2-3; rows dh = 0, 1; halves a / b
+        const int p0 = code.x & 3, p1 = code.y & 3;
+        const bool h0 = code.x & 4, h1 = code.y & 4;
+        const float a0x = (!h0 && p0 == 0) ? g.x : 0.0f, a0y = (!h0 && p0 == 1) ? g.x : 0.0f;
+        const float a1x = (!h0 && p0 == 2) ? g.x : 0.0f, a1y = (!h0 && p0 == 3) ? g.x : 0.0f;
+        const float b0x = (h0 && p0 == 0) ? g.x : 0.0f, b0y = (h0 && p0 == 1) ? g.x : 0.0f;
+        const float b1x = (h0 && p0 == 2) ? g.x : 0.0f, b1y = (h0 && p0 == 3) ? g.x : 0.0f;
+        const float a0z = (!h1 && p1 == 0) ? g.y : 0.0f, a0w = (!h1 && p1 == 1) ? g.y : 0.0f;
+        const float a1z = (!h1 && p1 == 2) ? g.y : 0.0f, a1w = (!h1 && p1 == 3) ? g.y : 0.0f;
+        const float b0z = (h1 && p1 == 0) ? g.y : 0.0f, b0w = (h1 && p1 == 1) ? g.y : 0.0f;
+        const float b1z = (h1 && p1 == 2) ? g.y : 0.0f, b1w = (h1 && p1 == 3) ? g.y : 0.0f;
         float *pa = xn + c * plane + (int64_t)(2 * ho) * W + 4 * wq;
         float *pb = pa + (int64_t)C * plane;
-        *reinterpret_cast<float4 *>(pa) = make_float4(va[0], va[1], va[2], va[3]);
-        *reinterpret_cast<float4 *>(pa + W) = make_float4(va[4], va[5], va[6], va[7]);
-        *reinterpret_cast<float4 *>(pb) = make_float4(vb[0], vb[1], vb[2], vb[3]);
-        *reinterpret_cast<float4 *>(pb + W) = make_float4(vb[4], vb[5], vb[6], vb[7]);
+        *reinterpret_cast<float4 *>(pa) = make_float4(a0x, a0y, a0z, a0w);
+        *reinterpret_cast<float4 *>(pa + W) = make_float4(a1x, a1y, a1z, a1w);
+        *reinterpret_cast<float4 *>(pb) = make_float4(b0x, b0y, b0z, b0w);
+        *reinterpret_cast<float4 *>(pb + W) = make_float4(b1x, b1y, b1z, b1w);
         if ((H & 1) && ho == Ho - 1) {
             *reinterpret_cast<float4 *>(pa + 2 * W) = zero;
             *reinterpret_cast<float4 *>(pb + 2 * W) = zero;
@@ -300,17 +337,17 @@ size_t advstep_mfm_sel_bytes(int64_t N, int64_t C, int64_t HW) {
     return (size_t)N * (size_t)ceil_div(C * HW, 4);
 }
 
-int advstep_mfm_forward_f32(const float *x, float *y, uint8_t *sel, int64_t N, int64_t C, int64_t HW,
-                            advstep_stream_t stream) {
+int advstep_mfm_forward_f32(const float *x, const float *bias, float *y, uint8_t *sel, int64_t N, int64_t C,
+                            int64_t HW, advstep_stream_t stream) {
     LCNN_REQUIRE(N >= 0 && C >= 0 && HW >= 0);
     if (N == 0 || C == 0 || HW == 0) return ADVSTEP_OK;
     LCNN_REQUIRE(x && y && sel && N <= kMaxGridY);
     const int64_t P = C * HW, G = ceil_div(P, 4);
     const dim3 grid((unsigned)ceil_div(G, kBlock * kGroupsPerThread), (unsigned)N);
     if (P % 4 == 0 && aligned16(x) && aligned16(y))
-        hipLaunchKernelGGL(mfm_forward_kernel<true>, grid, dim3(kBlock), 0, as_stream(stream), x, y, sel, P, G);
+        hipLaunchKernelGGL(mfm_forward_kernel<true>, grid, dim3(kBlock), 0, as_stream(stream), x, bias, y, sel, P, G, HW, C);
     else
-        hipLaunchKernelGGL(mfm_forward_kernel<false>, grid, dim3(kBlock), 0, as_stream(stream), x, y, sel, P, G);
+        hipLaunchKernelGGL(mfm_forward_kernel<false>, grid, dim3(kBlock), 0, as_stream(stream), x, bias, y, sel, P, G, HW, C);
     return status_after_launch();
 }
 
@@ -328,8 +365,8 @@ int advstep_mfm_backward_f32(const float *gy, const uint8_t *sel, float *gx, int
     return status_after_launch();
 }
 
-int advstep_mfm_pool2_forward_f32(const float *x, float *y, uint8_t *idx, int64_t N, int64_t C, int64_t H, int64_t W,
-                                  advstep_stream_t stream) {
+int advstep_mfm_pool2_forward_f32(const float *x, const float *bias, float *y, uint8_t *idx, int64_t N, int64_t C,
+                                  int64_t H, int64_t W, advstep_stream_t stream) {
     LCNN_REQUIRE(N >= 0 && C >= 0 && H >= 0 && W >= 0);
     const int64_t Ho = H / 2, Wo = W / 2;
     if (N == 0 || C == 0 || Ho == 0 || Wo == 0) return ADVSTEP_OK;
@@ -339,10 +376,10 @@ int advstep_mfm_pool2_forward_f32(const float *x, float *y, uint8_t *idx, int64_
         ((reinterpret_cast<uintptr_t>(idx) & 1u) == 0)) {
         const int64_t items = C * Ho * (W / 4);
         const dim3 grid((unsigned)ceil_div(items, 2 * kBlock), (unsigned)N);
-        hipLaunchKernelGGL(mfm_pool2_forward_vec_kernel, grid, dim3(kBlock), 0, st, x, y, idx, (int)C, (int)H, (int)W);
+        hipLaunchKernelGGL(mfm_pool2_forward_vec_kernel, grid, dim3(kBlock), 0, st, x, bias, y, idx, (int)C, (int)H, (int)W);
     } else {
         const dim3 grid((unsigned)ceil_div(C * Ho * Wo, kBlock), (unsigned)N);
-        hipLaunchKernelGGL(mfm_pool2_forward_scalar_kernel, grid, dim3(kBlock), 0, st, x, y, idx, (int)C, (int)H, (int)W);
+        hipLaunchKernelGGL(mfm_pool2_forward_scalar_kernel, grid, dim3(kBlock), 0, st, x, bias, y, idx, (int)C, (int)H, (int)W);
     }
     return status_after_launch();
 }

@@ -1,0 +1,102 @@
+"""Max-feature-map (+ 2x2 max-pool) of LCNN as differentiable ops backed by the HIP kernels of
+include/advstep_lcnn.h.
+
+`mfm(x, bias=None)` replaces  `(x + bias[None, :, None, None]).view(N, 2, C, H, W).max(1)[0]`
+(reference: src/models/lcnn.py:76-95 after the Conv2d's bias add) and `mfm_pool2(x, bias=None)` additionally the
+`MaxPool2d((2, 2), (2, 2))` that follows it (lcnn.py:123,129,137,154).  Forward values and input gradients are
+bit-identical to the ATen ops they replace, ties and NaN included (tests/test_gpu_lcnn_ops.py).
+HIP tensors only: these functions raise on CPU tensors (the model keeps its plain torch path for CPU runs)."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+from .hip_ops import _Launch, _require, _stream
+
+
+def _check_input(x: torch.Tensor, bias: Optional[torch.Tensor]):
+    _require(x, "x")
+    if x.dim() != 4 or x.shape[1] % 2 != 0:
+        raise ValueError(f"expected a contiguous (N, 2C, H, W) tensor, got {tuple(x.shape)}")
+    if bias is not None:
+        _require(bias, "bias")
+        if bias.numel() != x.shape[1]:
+            raise ValueError(f"bias must have {x.shape[1]} entries, got {bias.numel()}")
+
+
+def _bias_grad(gx: torch.Tensor, needed: bool):
+    # only for training-style use (parameters that require grad); the attacks freeze the parameters
+    return gx.sum(dim=(0, 2, 3)) if needed else None
+
+
+class _Mfm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, bias):
+        _check_input(x, bias)
+        N, C2, H, W = x.shape
+        C, HW = C2 // 2, H * W
+        y = torch.empty((N, C, H, W), dtype=x.dtype, device=x.device)
+        lib = _lib.load()
+        sel = torch.empty(max(lib.advstep_mfm_sel_bytes(N, C, HW), 1), dtype=torch.uint8, device=x.device)
+        with _Launch("mfm_forward", x.device):
+            st = lib.advstep_mfm_forward_f32(x.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(),
+                                             sel.data_ptr(), N, C, HW, _stream(x.device))
+        _lib.check(st, "advstep_mfm_forward_f32")
+        ctx.save_for_backward(sel)
+        ctx.shape = (N, C, H, W)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (sel,) = ctx.saved_tensors
+        N, C, H, W = ctx.shape
+        gy = gy.contiguous()
+        gx = torch.empty((N, 2 * C, H, W), dtype=gy.dtype, device=gy.device)
+        with _Launch("mfm_backward", gy.device):
+            st = _lib.load().advstep_mfm_backward_f32(gy.data_ptr(), sel.data_ptr(), gx.data_ptr(), N, C, H * W,
+                                                      _stream(gy.device))
+        _lib.check(st, "advstep_mfm_backward_f32")
+        return gx, _bias_grad(gx, ctx.has_bias and ctx.needs_input_grad[1])
+
+
+class _MfmPool2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, bias):
+        _check_input(x, bias)
+        N, C2, H, W = x.shape
+        C = C2 // 2
+        y = torch.empty((N, C, H // 2, W // 2), dtype=x.dtype, device=x.device)
+        idx = torch.empty(max(y.numel(), 2), dtype=torch.uint8, device=x.device)
+        with _Launch("mfm_pool2_forward", x.device):
+            st = _lib.load().advstep_mfm_pool2_forward_f32(x.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                                           y.data_ptr(), idx.data_ptr(), N, C, H, W, _stream(x.device))
+        _lib.check(st, "advstep_mfm_pool2_forward_f32")
+        ctx.save_for_backward(idx)
+        ctx.shape = (N, C, H, W)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (idx,) = ctx.saved_tensors
+        N, C, H, W = ctx.shape
+        gy = gy.contiguous()
+        gx = torch.empty((N, 2 * C, H, W), dtype=gy.dtype, device=gy.device)
+        with _Launch("mfm_pool2_backward", gy.device):
+            st = _lib.load().advstep_mfm_pool2_backward_f32(gy.data_ptr(), idx.data_ptr(), gx.data_ptr(), N, C, H, W,
+                                                            _stream(gy.device))
+        _lib.check(st, "advstep_mfm_pool2_backward_f32")
+        return gx, _bias_grad(gx, ctx.has_bias and ctx.needs_input_grad[1])
+
+
+def mfm(x: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """(N, 2C, H, W) -> (N, C, H, W): max(x[:, :C] + bias[:C], x[:, C:] + bias[C:])."""
+    return _Mfm.apply(x.contiguous(), bias)
+
+
+def mfm_pool2(x: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """(N, 2C, H, W) -> (N, C, H//2, W//2): MaxPool2d(2, 2) of the max-feature-map."""
+    return _MfmPool2.apply(x.contiguous(), bias)

@@ -6,10 +6,18 @@ under PyTorch-ROCm (MIOpen convolutions / RNN); tests/test_models.py pins `BaseL
 gradients produced by the reference's own BaseLCNN (tests/golden/lcnn_body.npz)."""
 from __future__ import annotations
 
+import os
+
 import torch
+import torch.nn.functional as F
 from torch import nn
 
 from .. import frontends
+
+
+def _fused_mfm_enabled() -> bool:
+    """ADVSTEP_LCNN_FUSED=0 switches the HIP max-feature-map kernels off (A/B measurements); default on."""
+    return os.environ.get("ADVSTEP_LCNN_FUSED", "1") != "0"
 
 
 class BLSTMLayer(nn.Module):
@@ -78,6 +86,15 @@ def _make_transform(input_channels: int) -> nn.Sequential:
     return nn.Sequential(*layers)
 
 
+def _pair(v):
+    return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
+
+
+def _is_pool2(pool: nn.MaxPool2d) -> bool:
+    return (_pair(pool.kernel_size) == (2, 2) and _pair(pool.stride) == (2, 2) and _pair(pool.padding) == (0, 0)
+            and _pair(pool.dilation) == (1, 1) and not pool.ceil_mode and not pool.return_indices)
+
+
 class BaseLCNN(nn.Module):
     """Spectrogram (B, C, n_coeff, frames) -> logit (B, 1)   (lcnn.py:102-217)."""
 
@@ -92,10 +109,41 @@ class BaseLCNN(nn.Module):
         self.m_before_pooling = nn.Sequential(BLSTMLayer(width, width), BLSTMLayer(width, width))
         self.m_output_act = nn.Linear(width, self.v_emd_dim)
 
+    def _transform(self, x):
+        """`self.m_transform(x)`.  On a HIP device every Conv2d -> MaxFeatureMap2D [-> MaxPool2d(2, 2)] run of the
+        Sequential goes through the fused kernels of lcnn_ops: one pass over the conv
+        output instead of ATen's max-reduce (+ int64 indices) and pool kernels, and — when the bias needs no gradient,
+        which is the case inside an attack — the conv's bias add is folded in as well.  Bit-identical to the plain path.
+        CPU tensors (oracle / CPU-baseline runs) take the plain Sequential."""
+        if not (x.is_cuda and _fused_mfm_enabled()):
+            return self.m_transform(x)
+        from .. import lcnn_ops
+        mods = list(self.m_transform)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            nxt = mods[i + 1] if i + 1 < len(mods) else None
+            if (isinstance(m, nn.Conv2d) and m.padding_mode == "zeros" and isinstance(nxt, MaxFeatureMap2D)
+                    and nxt.max_dim == 1):
+                fold_bias = m.bias is not None and not (torch.is_grad_enabled() and m.bias.requires_grad)
+                h = F.conv2d(x, m.weight, None if fold_bias else m.bias, m.stride, m.padding, m.dilation, m.groups)
+                bias = m.bias if fold_bias else None
+                after = mods[i + 2] if i + 2 < len(mods) else None
+                if isinstance(after, nn.MaxPool2d) and _is_pool2(after):
+                    x = lcnn_ops.mfm_pool2(h, bias)
+                    i += 3
+                else:
+                    x = lcnn_ops.mfm(h, bias)
+                    i += 2
+            else:
+                x = m(x)
+                i += 1
+        return x
+
     def _compute_embedding(self, x):
         batch_size = x.shape[0]
         # (B, C, coeff, frames) -> (B, C, frames, coeff) -> conv trunk -> (B, frames', C' * coeff')   (:190-199)
-        hidden = self.m_transform(x.permute(0, 1, 3, 2))
+        hidden = self._transform(x.permute(0, 1, 3, 2))
         hidden = hidden.permute(0, 2, 1, 3).contiguous()
         hidden = hidden.view(batch_size, hidden.shape[1], -1)
         # two BLSTMs with a skip connection, mean over frames, linear read-out   (:202-205)

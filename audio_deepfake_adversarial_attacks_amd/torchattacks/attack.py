@@ -247,7 +247,17 @@ class Attack(object):
         else:
             self.model.eval()
 
-        images = self.forward(*input, **kwargs)
+        # Not in the reference (no observable difference: the attacks only ever differentiate w.r.t. the input):
+        # parameters are frozen for the duration of the call, so no parameter-gradient bookkeeping is built and the
+        # model's fused kernels may fold bias adds (models/lcnn.py::_transform).
+        frozen = [p for p in self.model.parameters() if p.requires_grad]
+        for p in frozen:
+            p.requires_grad_(False)
+        try:
+            images = self.forward(*input, **kwargs)
+        finally:
+            for p in frozen:
+                p.requires_grad_(True)
 
         if was_training:
             self.model.train()

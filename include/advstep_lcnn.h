@@ -31,20 +31,21 @@ extern "C" {
  * sample, N * ceil(C*HW / 4). */
 size_t advstep_mfm_sel_bytes(int64_t N, int64_t C, int64_t HW);
 
-/* y (N, C, HW) = max-feature-map of x (N, 2C, HW); sel receives, per group of 4 outputs, bit k = 1 when output k
- * came from the second half of the channels. */
-int advstep_mfm_forward_f32(const float *x, float *y, uint8_t *sel, int64_t N, int64_t C, int64_t HW,
-                            advstep_stream_t stream);
+/* y (N, C, HW) = max-feature-map of x (N, 2C, HW) [+ bias (2C) when bias != NULL: the convolution's bias add
+ * (one rounding per element, as ATen's separate add kernel) is folded into this pass]; sel receives, per group of 4
+ * outputs, bit k = 1 when output k came from the second half of the channels. */
+int advstep_mfm_forward_f32(const float *x, const float *bias, float *y, uint8_t *sel, int64_t N, int64_t C,
+                            int64_t HW, advstep_stream_t stream);
 
 /* gx (N, 2C, HW) from gy (N, C, HW): the gradient goes to the selected half, the other half gets 0. */
 int advstep_mfm_backward_f32(const float *gy, const uint8_t *sel, float *gx, int64_t N, int64_t C, int64_t HW,
                              advstep_stream_t stream);
 
 /* y (N, C, H/2, W/2) = MaxPool2d(2, 2)(MFM(x)), x (N, 2C, H, W) (floor division: a trailing odd row / column is
- * dropped, as with ceil_mode=False).  idx receives one byte per pooled output: bit 2 = second channel half,
+ * dropped, as with ceil_mode=False); bias (2C) as above, may be NULL.  idx receives one byte per pooled output: bit 2 = second channel half,
  * bit 1 = dh, bit 0 = dw of the winning input. */
-int advstep_mfm_pool2_forward_f32(const float *x, float *y, uint8_t *idx, int64_t N, int64_t C, int64_t H, int64_t W,
-                                  advstep_stream_t stream);
+int advstep_mfm_pool2_forward_f32(const float *x, const float *bias, float *y, uint8_t *idx, int64_t N, int64_t C,
+                                  int64_t H, int64_t W, advstep_stream_t stream);
 
 /* gx (N, 2C, H, W) from gy (N, C, H/2, W/2) and idx: every input position receives either the pooled gradient
  * (the winner) or 0 — including a trailing odd row / column. */

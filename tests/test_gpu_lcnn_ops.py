@@ -1,0 +1,141 @@
+"""`-m gpu`: the LCNN max-feature-map kernels (include/advstep_lcnn.h) against the ATen ops they replace, on the GPU,
+bit for bit — values, input gradients, ties, NaN, odd sizes — and the fused LCNN against the plain one."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def L(cuda):
+    from audio_deepfake_adversarial_attacks_amd import lcnn_ops
+    return lcnn_ops
+
+
+def ref_mfm(x, bias=None):
+    if bias is not None:
+        x = x + bias.view(1, -1, 1, 1)
+    n, c2, h, w = x.shape
+    return x.view(n, 2, c2 // 2, h, w).max(1)[0]
+
+
+def ref_mfm_pool(x, bias=None):
+    return torch.nn.functional.max_pool2d(ref_mfm(x, bias), (2, 2), (2, 2))
+
+
+def make(shape, cuda, seed, ties=False, nans=False):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(shape, generator=g)
+    if ties:
+        x = (x * 2).round() / 2          # many exact ties, between channel halves and inside pooling windows
+    if nans:
+        flat = x.view(-1)
+        flat[torch.randint(0, flat.numel(), (max(flat.numel() // 50, 1),), generator=g)] = float("nan")
+    return x.to(cuda)
+
+
+def same(a, b):
+    return torch.equal(torch.nan_to_num(a, nan=1234.5), torch.nan_to_num(b, nan=1234.5)) and \
+        torch.equal(torch.isnan(a), torch.isnan(b))
+
+
+SHAPES = [(2, 4, 6, 8), (3, 2, 1, 4), (2, 6, 5, 7), (1, 2, 3, 3), (2, 8, 101, 20), (2, 64, 404, 80), (3, 10, 7, 12),
+          (1, 2, 2, 2), (2, 4, 9, 16)]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("mode", ["plain", "ties", "nans"])
+@pytest.mark.parametrize("with_bias", [False, True])
+def test_mfm_matches_aten(L, cuda, shape, mode, with_bias):
+    x = make(shape, cuda, 1, ties=mode == "ties", nans=mode == "nans").requires_grad_(True)
+    bias = (torch.randn(shape[1], generator=torch.Generator().manual_seed(2)).to(cuda) if with_bias else None)
+    if with_bias and mode == "ties":
+        bias = (bias * 2).round() / 2
+    y_ref = ref_mfm(x, bias)
+    gy = make(tuple(y_ref.shape), cuda, 3)
+    (gx_ref,) = torch.autograd.grad(y_ref, x, gy)
+    y = L.mfm(x, bias)
+    (gx,) = torch.autograd.grad(y, x, gy)
+    assert same(y, y_ref)
+    assert same(gx, gx_ref)
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("mode", ["plain", "ties", "nans"])
+@pytest.mark.parametrize("with_bias", [False, True])
+def test_mfm_pool2_matches_aten(L, cuda, shape, mode, with_bias):
+    if shape[2] < 2 or shape[3] < 2:
+        pytest.skip("ATen rejects an empty pooled output")
+    x = make(shape, cuda, 4, ties=mode == "ties", nans=mode == "nans").requires_grad_(True)
+    bias = (torch.randn(shape[1], generator=torch.Generator().manual_seed(5)).to(cuda) if with_bias else None)
+    if with_bias and mode == "ties":
+        bias = (bias * 2).round() / 2
+    y_ref = ref_mfm_pool(x, bias)
+    gy = make(tuple(y_ref.shape), cuda, 6)
+    (gx_ref,) = torch.autograd.grad(y_ref, x, gy)
+    y = L.mfm_pool2(x, bias)
+    (gx,) = torch.autograd.grad(y, x, gy)
+    assert y.shape == y_ref.shape and same(y, y_ref)
+    assert same(gx, gx_ref)
+
+
+def test_bias_gradient_when_requested(L, cuda):
+    x = make((2, 6, 8, 8), cuda, 7).requires_grad_(True)
+    bias = torch.randn(6, device=cuda, requires_grad=True)
+    for fn, ref in ((L.mfm, ref_mfm), (L.mfm_pool2, ref_mfm_pool)):
+        gy = torch.randn_like(ref(x, bias))
+        gx_ref, gb_ref = torch.autograd.grad(ref(x, bias), (x, bias), gy)
+        gx, gb = torch.autograd.grad(fn(x, bias), (x, bias), gy)
+        assert torch.equal(gx, gx_ref) and torch.allclose(gb, gb_ref, rtol=1e-5, atol=1e-6)
+
+
+def test_input_validation(L, cuda):
+    from audio_deepfake_adversarial_attacks_amd._lib import AdvstepError
+    with pytest.raises(AdvstepError, match="no CPU fallback"):
+        L.mfm(torch.rand(1, 2, 4, 4))
+    with pytest.raises(ValueError):
+        L.mfm(torch.rand(1, 3, 4, 4, device=cuda))
+    with pytest.raises(ValueError):
+        L.mfm(torch.rand(1, 4, 4, 4, device=cuda), torch.rand(3, device=cuda))
+    assert L.mfm(torch.rand(0, 4, 4, 4, device=cuda)).shape == (0, 2, 4, 4)
+
+
+def test_fused_lcnn_is_bit_identical_to_plain_lcnn(cuda, monkeypatch):
+    """Same weights, same input: logits and input-gradient of the attack-mode model with and without the kernels.
+    Compared at the spectrogram (the LFCC backward uses atomic index_add, so waveform gradients are not run-to-run
+    reproducible even for the plain model; they are compared against that noise floor instead)."""
+    from audio_deepfake_adversarial_attacks_amd.models.models import get_model
+    torch.manual_seed(0)
+    model = get_model("lcnn", {"frontend_algorithm": ["lfcc"], "input_channels": 1}, str(cuda)).to(cuda)
+    model.train()
+    for m in model.modules():
+        if "BatchNorm" in m.__class__.__name__ or "Dropout" in m.__class__.__name__:
+            m.eval()
+    x = (torch.randn(4, 64_600, generator=torch.Generator().manual_seed(1)) * 0.05).to(cuda)
+    spec = model._compute_frontend(x).detach()
+
+    def run(fused, frozen, waveform=False):
+        monkeypatch.setenv("ADVSTEP_LCNN_FUSED", "1" if fused else "0")
+        for p in model.parameters():
+            p.requires_grad_(not frozen)
+        a = (x if waveform else spec).clone().requires_grad_(True)
+        z = model(a) if waveform else model._compute_embedding(a)
+        (g,) = torch.autograd.grad(z.sum(), a)
+        return z.detach(), g
+
+    z0, g0 = run(False, False)
+    for fused, frozen in ((True, False), (True, True)):     # without and with the bias add folded in
+        z, g = run(fused, frozen)
+        assert torch.equal(z, z0), (fused, frozen)
+        assert torch.equal(g, g0), (fused, frozen)
+    zw0, gw0 = run(False, False, waveform=True)
+    zw1, gw1 = run(False, False, waveform=True)
+    zw2, gw2 = run(True, True, waveform=True)
+    assert torch.equal(zw0, zw2)
+    noise = (gw0 - gw1).abs().max().item()
+    assert (gw0 - gw2).abs().max().item() <= max(4 * noise, 1e-6 * gw0.abs().max().item())
+    for p in model.parameters():
+        p.requires_grad_(True)

@@ -60,7 +60,56 @@ def main():
         "cw_adam_step": (lambda i: ops.cw_adam_step(w[i], m[i], v[i], x[i], grad[i], 3), 32),
         "cw_best_update": (lambda i: ops.cw_best_update(adv[i], mask, best[i]), 12),
     }
+    # LCNN max-feature-map kernels at the first (largest) layer's shape: conv output (B, 64, 404, 80)
+    from audio_deepfake_adversarial_attacks_amd import _lib, lcnn_ops  # noqa: F401
+    lib = _lib.load()
+    C, H, W = 32, 404, 80
+    nsets2 = 2  # 1.06 GB per conv-output tensor: two sets already exceed the Infinity Cache
+    cx = [torch.randn(B, 2 * C, H, W, device=dev, generator=g) for _ in range(nsets2)]
+    cbias = torch.randn(2 * C, device=dev)
+    y_m = torch.empty(B, C, H, W, device=dev)
+    sel = torch.empty(lib.advstep_mfm_sel_bytes(B, C, H * W), dtype=torch.uint8, device=dev)
+    y_p = torch.empty(B, C, H // 2, W // 2, device=dev)
+    idx = torch.empty(y_p.numel(), dtype=torch.uint8, device=dev)
+    gxb = [torch.empty(B, 2 * C, H, W, device=dev) for _ in range(nsets2)]
+    stream = torch.cuda.current_stream().cuda_stream
+    lib.advstep_mfm_forward_f32(cx[0].data_ptr(), None, y_m.data_ptr(), sel.data_ptr(), B, C, H * W, stream)
+    lib.advstep_mfm_pool2_forward_f32(cx[0].data_ptr(), None, y_p.data_ptr(), idx.data_ptr(), B, C, H, W, stream)
+    nm, npool = y_m.numel(), y_p.numel()
+    lcnn_cases = {
+        "mfm_forward(+bias)": (lambda i: lib.advstep_mfm_forward_f32(cx[i % nsets2].data_ptr(), cbias.data_ptr(), y_m.data_ptr(),
+                                                                     sel.data_ptr(), B, C, H * W, stream), nm * 12.25),
+        "mfm_backward": (lambda i: lib.advstep_mfm_backward_f32(y_m.data_ptr(), sel.data_ptr(), gxb[i % nsets2].data_ptr(), B, C,
+                                                                H * W, stream), nm * 12.25),
+        "mfm_pool2_forward(+bias)": (lambda i: lib.advstep_mfm_pool2_forward_f32(cx[i % nsets2].data_ptr(), cbias.data_ptr(),
+                                                                                 y_p.data_ptr(), idx.data_ptr(), B, C, H, W,
+                                                                                 stream), npool * 37.0),
+        "mfm_pool2_backward": (lambda i: lib.advstep_mfm_pool2_backward_f32(y_p.data_ptr(), idx.data_ptr(),
+                                                                            gxb[i % nsets2].data_ptr(), B, C, H, W, stream),
+                               npool * 37.0),
+    }
     results = {}
+    for name, (fn, total_bytes) in lcnn_cases.items():
+        if a.only and a.only != name:
+            continue
+        row = {"algorithmic_bytes_per_launch": total_bytes}
+        for regime, sets in (("hot", 1), ("cold", nsets2)):
+            for i in range(2):
+                fn(i % sets)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for i in range(20):
+                fn(i % sets)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 20
+            row[regime + "_us"] = 1e3 * ms
+            row[regime + "_GBps"] = total_bytes / (ms * 1e-3) / 1e9
+        results[name] = row
+        print(f"{name:24s} hot {row['hot_us']:8.1f} us {row['hot_GBps']:7.0f} GB/s | cold {row['cold_us']:8.1f} us "
+              f"{row['cold_GBps']:7.0f} GB/s  (B x 64 x 404 x 80 conv output; {total_bytes / 1e6:.0f} MB algorithmic)", flush=True)
+    del cx, gxb, y_m, y_p
     for name, (fn, bytes_per_sample) in cases.items():
         if a.only and a.only != name:
             continue
