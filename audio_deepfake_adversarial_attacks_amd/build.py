@@ -7,13 +7,17 @@ from pathlib import Path
 
 PKG = Path(__file__).resolve().parent
 ROOT = PKG.parent
-SOURCES = [PKG / "csrc" / "advstep.hip", PKG / "csrc" / "lcnn_mfm.hip"]
+SOURCES = [PKG / "csrc" / "advstep.hip", PKG / "csrc" / "lcnn_mfm.hip", PKG / "csrc" / "lcnn_conv0.hip",
+           PKG / "csrc" / "lcnn_conv1x1.hip"]
 HEADERS = [ROOT / "include" / "advstep.h", ROOT / "include" / "advstep_lcnn.h"]
 LIB = PKG / "libadvstep.so"
 
 # -ffp-contract=off: the kernels must round exactly like the reference's one-ATen-op-per-expression chains
 # (bit-exactness rules); f32 division/sqrt stay IEEE (hipcc default).
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+# -fno-slp-vectorize: keeps the first-block convolution on v_fmac_f32 with scalar (SGPR) weight operands instead of
+# v_pk_fma_f32 + per-operand v_mov broadcasts (3x the VALU instructions); the streaming kernels do not care.
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC",
+               "-shared"]
 
 
 def build(force: bool = False, verbose: bool = False) -> Path:

@@ -92,6 +92,105 @@ class _MfmPool2(torch.autograd.Function):
         return gx, _bias_grad(gx, ctx.has_bias and ctx.needs_input_grad[1])
 
 
+class _Conv5MfmPool2(torch.autograd.Function):
+    """First LCNN block in one kernel; differentiable w.r.t. the input only (weights must not require grad)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _require(x, "x"), _require(weight, "weight")
+        if bias is not None:
+            _require(bias, "bias")
+        if x.dim() != 4 or x.shape[1] != 1 or weight.dim() != 4 or tuple(weight.shape[1:]) != (1, 5, 5) \
+                or weight.shape[0] % 2 != 0 or (bias is not None and bias.numel() != weight.shape[0]):
+            raise ValueError(f"expected x (N, 1, H, W), weight (2C, 1, 5, 5), bias (2C); got {tuple(x.shape)}, "
+                             f"{tuple(weight.shape)}")
+        N, _, H, W = x.shape
+        C = weight.shape[0] // 2
+        y = torch.empty((N, C, H // 2, W // 2), dtype=x.dtype, device=x.device)
+        idx = torch.empty(max(y.numel(), 1), dtype=torch.uint8, device=x.device)
+        with _Launch("conv5_mfm_pool2_forward", x.device):
+            st = _lib.load().advstep_conv5_mfm_pool2_forward_f32(
+                x.data_ptr(), weight.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(),
+                idx.data_ptr(), N, C, H, W, _stream(x.device))
+        _lib.check(st, "advstep_conv5_mfm_pool2_forward_f32")
+        ctx.save_for_backward(idx, weight)
+        ctx.shape = (N, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        if ctx.needs_input_grad[1] or (len(ctx.needs_input_grad) > 2 and ctx.needs_input_grad[2]):
+            raise RuntimeError("conv5_mfm_pool2 provides the input gradient only; call it with frozen weights "
+                               "(the model falls back to Conv2d + mfm_pool2 otherwise)")
+        idx, weight = ctx.saved_tensors
+        N, C, H, W = ctx.shape
+        gy = gy.contiguous()
+        gx = torch.empty((N, 1, H, W), dtype=gy.dtype, device=gy.device)
+        with _Launch("conv5_mfm_pool2_backward", gy.device):
+            st = _lib.load().advstep_conv5_mfm_pool2_backward_f32(gy.data_ptr(), idx.data_ptr(), weight.data_ptr(),
+                                                                  gx.data_ptr(), N, C, H, W, _stream(gy.device))
+        _lib.check(st, "advstep_conv5_mfm_pool2_backward_f32")
+        return gx, None, None
+
+
+def conv5_mfm_pool2(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """MaxPool2d(2,2)(MFM(conv2d(x, weight, bias, stride 1, padding 2))) for a one-channel input, one kernel."""
+    return _Conv5MfmPool2.apply(x.contiguous(), weight.contiguous(), bias)
+
+
+class _Conv1x1Mfm(torch.autograd.Function):
+    """Conv2d(Cin, 2C, 1x1) + bias + MFM in one kernel; differentiable w.r.t. the input only."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _require(x, "x"), _require(weight, "weight")
+        if bias is not None:
+            _require(bias, "bias")
+        if x.dim() != 4 or weight.dim() != 4 or tuple(weight.shape[2:]) != (1, 1) or weight.shape[1] != x.shape[1] \
+                or weight.shape[0] % 2 != 0 or (bias is not None and bias.numel() != weight.shape[0]):
+            raise ValueError(f"expected x (N, Cin, H, W), weight (2C, Cin, 1, 1), bias (2C); got {tuple(x.shape)}, "
+                             f"{tuple(weight.shape)}")
+        N, Cin, H, W = x.shape
+        C, P = weight.shape[0] // 2, H * W
+        lib = _lib.load()
+        if not lib.advstep_conv1x1_mfm_supported(Cin):
+            raise ValueError(f"conv1x1_mfm supports Cin in (32, 48, 64), got {Cin}")
+        y = torch.empty((N, C, H, W), dtype=x.dtype, device=x.device)
+        sel = torch.empty(max(lib.advstep_conv1x1_mfm_sel_bytes(N, C, P) // 8, 1), dtype=torch.int64, device=x.device)
+        with _Launch("conv1x1_mfm_forward", x.device):
+            st = lib.advstep_conv1x1_mfm_forward_f32(x.data_ptr(), weight.data_ptr(),
+                                                     bias.data_ptr() if bias is not None else None, y.data_ptr(),
+                                                     sel.data_ptr(), N, Cin, C, P, _stream(x.device))
+        _lib.check(st, "advstep_conv1x1_mfm_forward_f32")
+        ctx.save_for_backward(sel, weight)
+        ctx.shape = (N, Cin, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        if ctx.needs_input_grad[1] or (len(ctx.needs_input_grad) > 2 and ctx.needs_input_grad[2]):
+            raise RuntimeError("conv1x1_mfm provides the input gradient only; call it with frozen weights "
+                               "(the model falls back to Conv2d + mfm otherwise)")
+        sel, weight = ctx.saved_tensors
+        N, Cin, C, H, W = ctx.shape
+        gy = gy.contiguous()
+        gx = torch.empty((N, Cin, H, W), dtype=gy.dtype, device=gy.device)
+        with _Launch("conv1x1_mfm_backward", gy.device):
+            st = _lib.load().advstep_conv1x1_mfm_backward_f32(gy.data_ptr(), sel.data_ptr(), weight.data_ptr(),
+                                                              gx.data_ptr(), N, Cin, C, H * W, _stream(gy.device))
+        _lib.check(st, "advstep_conv1x1_mfm_backward_f32")
+        return gx, None, None
+
+
+def conv1x1_mfm_supported(in_channels: int) -> bool:
+    return bool(_lib.load().advstep_conv1x1_mfm_supported(in_channels))
+
+
+def conv1x1_mfm(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """MFM(conv2d(x, weight (2C, Cin, 1, 1), bias)) in one kernel (Cin in 32/48/64)."""
+    return _Conv1x1Mfm.apply(x.contiguous(), weight.contiguous(), bias)
+
+
 def mfm(x: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
     """(N, 2C, H, W) -> (N, C, H, W): max(x[:, :C] + bias[:C], x[:, C:] + bias[C:])."""
     return _Mfm.apply(x.contiguous(), bias)

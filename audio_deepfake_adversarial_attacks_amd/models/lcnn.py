@@ -86,6 +86,27 @@ def _make_transform(input_channels: int) -> nn.Sequential:
     return nn.Sequential(*layers)
 
 
+def _fused_conv0_enabled() -> bool:
+    """ADVSTEP_LCNN_CONV0=0 keeps MIOpen's convolution for the first block (A/B measurements); default on."""
+    return os.environ.get("ADVSTEP_LCNN_CONV0", "1") != "0"
+
+
+def _fused_conv1x1_enabled() -> bool:
+    """ADVSTEP_LCNN_CONV1X1=0 keeps MIOpen's GEMM for the 1x1 blocks (A/B measurements); default on."""
+    return os.environ.get("ADVSTEP_LCNN_CONV1X1", "1") != "0"
+
+
+def _is_pointwise_conv(conv: nn.Conv2d) -> bool:
+    return (_pair(conv.kernel_size) == (1, 1) and _pair(conv.stride) == (1, 1) and _pair(conv.padding) == (0, 0)
+            and _pair(conv.dilation) == (1, 1) and conv.groups == 1 and conv.out_channels % 2 == 0)
+
+
+def _is_first_block_conv(conv: nn.Conv2d) -> bool:
+    return (conv.in_channels == 1 and _pair(conv.kernel_size) == (5, 5) and _pair(conv.stride) == (1, 1)
+            and _pair(conv.padding) == (2, 2) and _pair(conv.dilation) == (1, 1) and conv.groups == 1
+            and conv.out_channels % 2 == 0)
+
+
 def _pair(v):
     return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
 
@@ -125,10 +146,24 @@ class BaseLCNN(nn.Module):
             nxt = mods[i + 1] if i + 1 < len(mods) else None
             if (isinstance(m, nn.Conv2d) and m.padding_mode == "zeros" and isinstance(nxt, MaxFeatureMap2D)
                     and nxt.max_dim == 1):
+                after = mods[i + 2] if i + 2 < len(mods) else None
+                params_frozen = not (torch.is_grad_enabled() and (m.weight.requires_grad or
+                                                                  (m.bias is not None and m.bias.requires_grad)))
+                if (params_frozen and _is_first_block_conv(m) and isinstance(after, nn.MaxPool2d) and _is_pool2(after)
+                        and _fused_conv0_enabled()):
+                    # one-channel 5x5 conv + MFM + pool in ONE kernel: the (B, 64, 404, 80) conv output never exists
+                    x = lcnn_ops.conv5_mfm_pool2(x, m.weight, m.bias)
+                    i += 3
+                    continue
+                if (params_frozen and _is_pointwise_conv(m) and lcnn_ops.conv1x1_mfm_supported(m.in_channels)
+                        and not (isinstance(after, nn.MaxPool2d)) and _fused_conv1x1_enabled()):
+                    # 1x1 conv + bias + MFM in ONE kernel: the 2C-channel conv output never exists
+                    x = lcnn_ops.conv1x1_mfm(x, m.weight, m.bias)
+                    i += 2
+                    continue
                 fold_bias = m.bias is not None and not (torch.is_grad_enabled() and m.bias.requires_grad)
                 h = F.conv2d(x, m.weight, None if fold_bias else m.bias, m.stride, m.padding, m.dilation, m.groups)
                 bias = m.bias if fold_bias else None
-                after = mods[i + 2] if i + 2 < len(mods) else None
                 if isinstance(after, nn.MaxPool2d) and _is_pool2(after):
                     x = lcnn_ops.mfm_pool2(h, bias)
                     i += 3

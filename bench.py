@@ -130,10 +130,14 @@ def main():
     t0 = time.perf_counter()
     preds, labels, ys = [], [], []
     correct = torch.zeros((), dtype=torch.int64, device=device)
+    marks = [torch.cuda.Event(enable_timing=True)]
+    marks[0].record()
     for i in range(args.warmup, n_batches):
         p, l, by = one_step(i)
         preds.append(p), labels.append(l), ys.append(by)
         correct += (l == by.int()).sum()
+        marks.append(torch.cuda.Event(enable_timing=True))
+        marks[-1].record()
     total = torch.tensor(B * args.steps, dtype=torch.int64, device=device)
     all_pred, all_label, all_y, n_correct, n_total = aggregate_across_ranks(
         torch.cat(preds), torch.cat(labels), torch.cat(ys), correct, total)
@@ -191,6 +195,7 @@ def main():
                 "launches_timed": len(step_ms),
             },
             "attack_kernel_ms_per_step": {k: (sum(v) / args.steps if v else 0.0) for k, v in kernel_ms.items()},
+            "ms_each_step": [round(a.elapsed_time(b), 2) for a, b in zip(marks[:-1], marks[1:])],
             "adv_eval": {k.split("/")[1]: round(v, 4) for k, v in report.items()},
         }
         if world == 1 and not args.no_cpu_baseline:

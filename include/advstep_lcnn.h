@@ -52,6 +52,33 @@ int advstep_mfm_pool2_forward_f32(const float *x, const float *bias, float *y, u
 int advstep_mfm_pool2_backward_f32(const float *gy, const uint8_t *idx, float *gx, int64_t N, int64_t C, int64_t H,
                                    int64_t W, advstep_stream_t stream);
 
+/* ---- first block fused: Conv2d(1, 2C, (5,5), stride 1, padding 2) -> MaxFeatureMap2D -> MaxPool2d(2, 2) -----------
+ * (src/models/lcnn.py:121-123).  With ONE input channel the convolution is not a GEMM (K = 25): it is a 1.06 GB
+ * write whose only consumer is the max-feature-map + pool, so the three are one kernel and the conv output never
+ * exists.  x (N, 1, H, W), weight (2C, 1, 5, 5), bias (2C) or NULL -> y (N, C, H/2, W/2) and one selection byte per
+ * output (same encoding as advstep_mfm_pool2_forward_f32).  Convolution sums are formed tap by tap in row-major
+ * order with fma (deterministic; within float rounding of MIOpen's result, not bit-equal to it). */
+int advstep_conv5_mfm_pool2_forward_f32(const float *x, const float *weight, const float *bias, float *y, uint8_t *idx,
+                                        int64_t N, int64_t C, int64_t H, int64_t W, advstep_stream_t stream);
+
+/* Input gradient of the block above: gx (N, 1, H, W) from gy (N, C, H/2, W/2), idx and the weights (no atomics:
+ * every 2x2 input patch gathers from the <= 9 pooled cells whose winner can reach it). */
+int advstep_conv5_mfm_pool2_backward_f32(const float *gy, const uint8_t *idx, const float *weight, float *gx, int64_t N,
+                                         int64_t C, int64_t H, int64_t W, advstep_stream_t stream);
+
+/* ---- 1x1 blocks fused: Conv2d(Cin, 2C, (1,1)) -> MaxFeatureMap2D  (src/models/lcnn.py:125-126,132-133,139-140,146-147)
+ * x (N, Cin, P) with P = H*W, weight (2C, Cin), bias (2C) or NULL -> y (N, C, P); sel gets ONE bit per output
+ * (N * C * ceil(P/64) 64-bit words, bit = pixel % 64, set when the second channel half won).  The 2C-channel conv
+ * output is never written.  Cin must be one advstep_conv1x1_mfm_supported() accepts (32, 48, 64: LCNN's). */
+int advstep_conv1x1_mfm_supported(int64_t Cin);
+size_t advstep_conv1x1_mfm_sel_bytes(int64_t N, int64_t C, int64_t P);
+int advstep_conv1x1_mfm_forward_f32(const float *x, const float *weight, const float *bias, float *y, uint64_t *sel,
+                                    int64_t N, int64_t Cin, int64_t C, int64_t P, advstep_stream_t stream);
+
+/* Input gradient of the block above: gx (N, Cin, P) = sum_c gy[n, c, p] * weight[selected half of pair c, :]. */
+int advstep_conv1x1_mfm_backward_f32(const float *gy, const uint64_t *sel, const float *weight, float *gx, int64_t N,
+                                     int64_t Cin, int64_t C, int64_t P, advstep_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

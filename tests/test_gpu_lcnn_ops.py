@@ -117,6 +117,10 @@ def test_fused_lcnn_is_bit_identical_to_plain_lcnn(cuda, monkeypatch):
     x = (torch.randn(4, 64_600, generator=torch.Generator().manual_seed(1)) * 0.05).to(cuda)
     spec = model._compute_frontend(x).detach()
 
+    # the convolution-fusing kernels round differently from MIOpen; this test isolates the max-feature-map kernels
+    monkeypatch.setenv("ADVSTEP_LCNN_CONV0", "0")
+    monkeypatch.setenv("ADVSTEP_LCNN_CONV1X1", "0")
+
     def run(fused, frozen, waveform=False):
         monkeypatch.setenv("ADVSTEP_LCNN_FUSED", "1" if fused else "0")
         for p in model.parameters():
@@ -139,3 +143,113 @@ def test_fused_lcnn_is_bit_identical_to_plain_lcnn(cuda, monkeypatch):
     assert (gw0 - gw2).abs().max().item() <= max(4 * noise, 1e-6 * gw0.abs().max().item())
     for p in model.parameters():
         p.requires_grad_(True)
+
+
+# ---- fused first block: Conv2d(1, 2C, 5x5, pad 2) -> MFM -> MaxPool2d(2, 2) ------------------------------------------------
+
+def ref_block0(x, weight, bias):
+    return ref_mfm_pool(torch.nn.functional.conv2d(x, weight, bias, stride=1, padding=2))
+
+
+@pytest.mark.parametrize("shape", [(2, 1, 12, 16), (3, 1, 9, 7), (1, 1, 2, 2), (2, 1, 101, 20), (4, 1, 404, 80), (2, 1, 5, 33)])
+@pytest.mark.parametrize("C,with_bias", [(32, True), (3, False), (8, True)])
+def test_conv5_mfm_pool2_matches_float64_reference(L, cuda, shape, C, with_bias):
+    g = torch.Generator().manual_seed(shape[2] * 131 + shape[3] + C)
+    x = torch.randn(shape, generator=g).to(cuda)
+    weight = (torch.randn(2 * C, 1, 5, 5, generator=g) * 0.3).to(cuda)
+    bias = torch.randn(2 * C, generator=g).to(cuda) if with_bias else None
+    xr = x.double().requires_grad_(True)
+    y_ref = ref_block0(xr, weight.double(), bias.double() if with_bias else None)
+    gy = torch.randn(y_ref.shape, generator=g).to(cuda)
+    (gx_ref,) = torch.autograd.grad(y_ref, xr, gy.double())
+    xa = x.clone().requires_grad_(True)
+    y = L.conv5_mfm_pool2(xa, weight, bias)
+    (gx,) = torch.autograd.grad(y, xa, gy)
+    assert y.shape == y_ref.shape
+    # the same winners must be selected unless two candidates are within float rounding of each other (not at these seeds)
+    assert (y.double() - y_ref).abs().max().item() <= 2e-5
+    assert (gx.double() - gx_ref).abs().max().item() <= 2e-4 * max(gx_ref.abs().max().item(), 1.0)
+    # and against the float32 ATen composition it replaces
+    xf = x.clone().requires_grad_(True)
+    yf = ref_block0(xf, weight, bias)
+    (gxf,) = torch.autograd.grad(yf, xf, gy)
+    assert (y - yf).abs().max().item() <= 2e-5
+    close = (gx - gxf).abs() <= 2e-4 * max(gxf.abs().max().item(), 1.0)
+    assert close.float().mean().item() >= 0.999       # MIOpen's own rounding may flip a near-tie winner
+
+
+def test_conv5_mfm_pool2_requires_frozen_weights(L, cuda):
+    x = torch.randn(1, 1, 8, 8, device=cuda, requires_grad=True)
+    w = torch.randn(4, 1, 5, 5, device=cuda, requires_grad=True)
+    y = L.conv5_mfm_pool2(x, w, None)
+    with pytest.raises(RuntimeError, match="input gradient only"):
+        y.sum().backward()
+    with pytest.raises(ValueError):
+        L.conv5_mfm_pool2(torch.randn(1, 2, 8, 8, device=cuda), w.detach(), None)
+
+
+def test_lcnn_with_fused_first_block_agrees_with_miopen_path(cuda, monkeypatch):
+    """Whole LCNN, attack mode, frozen parameters: fused first block + fused 1x1 blocks vs MIOpen convolutions.  The two
+    convolutions round differently, so logits agree to float tolerance and input gradients to a small relative error."""
+    from audio_deepfake_adversarial_attacks_amd.models.models import get_model
+    torch.manual_seed(0)
+    model = get_model("lcnn", {"frontend_algorithm": ["lfcc"], "input_channels": 1}, str(cuda)).to(cuda)
+    model.train()
+    for m in model.modules():
+        if "BatchNorm" in m.__class__.__name__ or "Dropout" in m.__class__.__name__:
+            m.eval()
+    for p in model.parameters():
+        p.requires_grad_(False)
+    x = (torch.randn(4, 64_600, generator=torch.Generator().manual_seed(1)) * 0.05).to(cuda)
+    spec = model._compute_frontend(x).detach()
+
+    def run(conv0):
+        monkeypatch.setenv("ADVSTEP_LCNN_CONV0", "1" if conv0 else "0")
+        monkeypatch.setenv("ADVSTEP_LCNN_CONV1X1", "1" if conv0 else "0")
+        a = spec.clone().requires_grad_(True)
+        z = model._compute_embedding(a)
+        (g,) = torch.autograd.grad(z.sum(), a)
+        return z.detach(), g
+
+    z0, g0 = run(False)
+    z1, g1 = run(True)
+    assert (z0 - z1).abs().max().item() <= 1e-5 * max(z0.abs().max().item(), 1.0)
+    # different (equally valid) float rounding inside the convolution flips a handful of near-tie winners among the
+    # 33 M max-feature-map / pool decisions; each flip re-routes one gradient entry.  Sparse, bounded differences:
+    off = (g0 - g1).abs() > 1e-3 * g0.abs().max()
+    assert off.float().mean().item() <= 1e-3
+    assert (g0 - g1).norm().item() / g0.norm().item() <= 2e-2
+    for p in model.parameters():
+        p.requires_grad_(True)
+
+
+# ---- fused 1x1 blocks: Conv2d(Cin, 2C, 1x1) -> MFM -----------------------------------------------------------------------------
+
+@pytest.mark.parametrize("N,Cin,C,H,W", [(2, 32, 32, 12, 10), (3, 48, 48, 7, 9), (2, 64, 64, 50, 10), (1, 32, 5, 1, 1),
+                                         (2, 32, 32, 202, 40), (2, 48, 7, 3, 67)])
+@pytest.mark.parametrize("with_bias", [True, False])
+def test_conv1x1_mfm_matches_float64_reference(L, cuda, N, Cin, C, H, W, with_bias):
+    g = torch.Generator().manual_seed(N * 1000 + Cin * 10 + C + H)
+    x = torch.randn(N, Cin, H, W, generator=g).to(cuda)
+    weight = (torch.randn(2 * C, Cin, 1, 1, generator=g) * 0.2).to(cuda)
+    bias = torch.randn(2 * C, generator=g).to(cuda) if with_bias else None
+    xr = x.double().requires_grad_(True)
+    y_ref = ref_mfm(torch.nn.functional.conv2d(xr, weight.double(), bias.double() if with_bias else None))
+    gy = torch.randn(y_ref.shape, generator=g).to(cuda)
+    (gx_ref,) = torch.autograd.grad(y_ref, xr, gy.double())
+    xa = x.clone().requires_grad_(True)
+    y = L.conv1x1_mfm(xa, weight, bias)
+    (gx,) = torch.autograd.grad(y, xa, gy)
+    assert y.shape == y_ref.shape
+    assert (y.double() - y_ref).abs().max().item() <= 2e-5
+    assert (gx.double() - gx_ref).abs().max().item() <= 2e-5 * max(gx_ref.abs().max().item(), 1.0)
+
+
+def test_conv1x1_mfm_rejects_unsupported_and_unfrozen(L, cuda):
+    w = torch.randn(8, 16, 1, 1, device=cuda)
+    with pytest.raises(ValueError, match="Cin"):
+        L.conv1x1_mfm(torch.randn(1, 16, 4, 4, device=cuda), w, None)
+    x = torch.randn(1, 32, 4, 4, device=cuda, requires_grad=True)
+    w = torch.randn(8, 32, 1, 1, device=cuda, requires_grad=True)
+    with pytest.raises(RuntimeError, match="input gradient only"):
+        L.conv1x1_mfm(x, w, None).sum().backward()
