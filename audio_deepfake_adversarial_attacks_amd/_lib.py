@@ -46,6 +46,9 @@ SIGNATURES = {
     "advstep_conv1x1_mfm_sel_bytes": (_sz, [_i64, _i64, _i64]),
     "advstep_conv1x1_mfm_forward_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p]),
     "advstep_conv1x1_mfm_backward_f32": (ctypes.c_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _p]),
+    "advstep_lstm_supported": (ctypes.c_int, [_i64]),
+    "advstep_lstm_forward_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p]),
+    "advstep_lstm_backward_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p]),
 }
 
 

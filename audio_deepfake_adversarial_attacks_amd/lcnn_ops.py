@@ -191,6 +191,55 @@ def conv1x1_mfm(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tens
     return _Conv1x1Mfm.apply(x.contiguous(), weight.contiguous(), bias)
 
 
+class _LstmLayer(torch.autograd.Function):
+    """One (bi)directional LSTM layer, sequence-first, zero initial state; input gradient only."""
+
+    @staticmethod
+    def forward(ctx, x, w_ih, w_hh, bias):
+        # x (T, B, I); w_ih (D*4H, I); w_hh (D, 4H, H); bias (D*4H) = b_ih + b_hh
+        _require(x, "x"), _require(w_ih, "w_ih"), _require(w_hh, "w_hh"), _require(bias, "bias")
+        T, B, I = x.shape
+        D, H4, H = w_hh.shape
+        if H4 != 4 * H or tuple(w_ih.shape) != (D * H4, I) or bias.numel() != D * H4:
+            raise ValueError("inconsistent LSTM parameter shapes")
+        gx = torch.addmm(bias, x.reshape(T * B, I), w_ih.t())            # one GEMM for all steps and directions
+        out = torch.empty((T, B, D * H), dtype=x.dtype, device=x.device)
+        gates = torch.empty((T, B, D, H4), dtype=x.dtype, device=x.device)
+        cell = torch.empty((T, B, D, H), dtype=x.dtype, device=x.device)
+        with _Launch("lstm_forward", x.device):
+            st = _lib.load().advstep_lstm_forward_f32(gx.data_ptr(), w_hh.data_ptr(), out.data_ptr(), gates.data_ptr(),
+                                                      cell.data_ptr(), T, B, D, H, _stream(x.device))
+        _lib.check(st, "advstep_lstm_forward_f32")
+        ctx.save_for_backward(gates, cell, w_hh, w_ih)
+        ctx.dims = (T, B, I, D, H)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        if any(ctx.needs_input_grad[1:]):
+            raise RuntimeError("lstm_layer provides the input gradient only; call it with frozen weights "
+                               "(the model falls back to torch.nn.LSTM otherwise)")
+        gates, cell, w_hh, w_ih = ctx.saved_tensors
+        T, B, I, D, H = ctx.dims
+        dout = dout.contiguous()
+        dgx = torch.empty((T, B, D, 4 * H), dtype=dout.dtype, device=dout.device)
+        with _Launch("lstm_backward", dout.device):
+            st = _lib.load().advstep_lstm_backward_f32(dout.data_ptr(), w_hh.data_ptr(), gates.data_ptr(),
+                                                       cell.data_ptr(), dgx.data_ptr(), T, B, D, H, _stream(dout.device))
+        _lib.check(st, "advstep_lstm_backward_f32")
+        dx = torch.mm(dgx.view(T * B, D * 4 * H), w_ih).view(T, B, I)
+        return dx, None, None, None
+
+
+def lstm_supported(hidden_size: int) -> bool:
+    return bool(_lib.load().advstep_lstm_supported(hidden_size))
+
+
+def lstm_layer(x: torch.Tensor, w_ih: torch.Tensor, w_hh: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """x (T, B, I) -> (T, B, D*H) for one LSTM layer with D directions (parameters packed per direction)."""
+    return _LstmLayer.apply(x.contiguous(), w_ih, w_hh, bias)
+
+
 def mfm(x: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
     """(N, 2C, H, W) -> (N, C, H, W): max(x[:, :C] + bias[:C], x[:, C:] + bias[C:])."""
     return _Mfm.apply(x.contiguous(), bias)

@@ -29,8 +29,32 @@ class BLSTMLayer(nn.Module):
             raise ValueError(f"BLSTMLayer expects an even layer size, got {output_dim}")
         self.l_blstm = nn.LSTM(input_dim, output_dim // 2, bidirectional=True)
 
+    def _packed(self):
+        """Per-direction parameters packed for lcnn_ops.lstm_layer, cached until a parameter changes."""
+        lstm = self.l_blstm
+        names = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"]
+        params = [getattr(lstm, n + s) for s in ("", "_reverse") for n in names]
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        if getattr(self, "_pack_key", None) != key:
+            with torch.no_grad():
+                w_ih = torch.cat([lstm.weight_ih_l0, lstm.weight_ih_l0_reverse], dim=0).contiguous()
+                w_hh = torch.stack([lstm.weight_hh_l0, lstm.weight_hh_l0_reverse], dim=0).contiguous()
+                bias = torch.cat([lstm.bias_ih_l0 + lstm.bias_hh_l0,
+                                  lstm.bias_ih_l0_reverse + lstm.bias_hh_l0_reverse], dim=0).contiguous()
+            self._pack_key, self._pack = key, (w_ih, w_hh, bias)
+        return self._pack
+
     def forward(self, x):
-        out, _ = self.l_blstm(x.permute(1, 0, 2))  # the LSTM is sequence-first
+        lstm = self.l_blstm
+        frozen = not (torch.is_grad_enabled() and any(p.requires_grad for p in lstm.parameters()))
+        if x.is_cuda and frozen and _fused_lstm_enabled() and lstm.num_layers == 1 and lstm.bidirectional \
+                and lstm.bias and lstm.proj_size == 0:
+            from .. import lcnn_ops
+            if lcnn_ops.lstm_supported(lstm.hidden_size):
+                # one workgroup per (utterance, direction) instead of MIOpen's per-time-step kernel chain
+                out = lcnn_ops.lstm_layer(x.permute(1, 0, 2), *self._packed())
+                return out.permute(1, 0, 2)
+        out, _ = lstm(x.permute(1, 0, 2))  # the LSTM is sequence-first
         return out.permute(1, 0, 2)
 
 
@@ -89,6 +113,11 @@ def _make_transform(input_channels: int) -> nn.Sequential:
 def _fused_conv0_enabled() -> bool:
     """ADVSTEP_LCNN_CONV0=0 keeps MIOpen's convolution for the first block (A/B measurements); default on."""
     return os.environ.get("ADVSTEP_LCNN_CONV0", "1") != "0"
+
+
+def _fused_lstm_enabled() -> bool:
+    """ADVSTEP_LCNN_LSTM=0 keeps MIOpen's RNN path (A/B measurements); default on."""
+    return os.environ.get("ADVSTEP_LCNN_LSTM", "1") != "0"
 
 
 def _fused_conv1x1_enabled() -> bool:

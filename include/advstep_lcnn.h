@@ -79,6 +79,22 @@ int advstep_conv1x1_mfm_forward_f32(const float *x, const float *weight, const f
 int advstep_conv1x1_mfm_backward_f32(const float *gy, const uint64_t *sel, const float *weight, float *gx, int64_t N,
                                      int64_t Cin, int64_t C, int64_t P, advstep_stream_t stream);
 
+/* ---- recurrent part of a (bi)directional LSTM layer  (src/models/lcnn.py:24-46: nn.LSTM(160, 80, bidirectional)) ------
+ * The input projections are computed by the caller with one GEMM:
+ *   gx (T, B, D, 4H) = W_ih x_t + b_ih + b_hh per direction d (D = 1 or 2; d = 1 runs over time in reverse),
+ * w_hh (D, 4H, H) as torch stores weight_hh_l0 / weight_hh_l0_reverse (gate order i, f, g, o).
+ * out (T, B, D*H) receives h_t (direction d in columns [d*H, (d+1)*H)); gates (T, B, D, 4H) the ACTIVATED gates and
+ * cell (T, B, D, H) the cell states, both kept for the backward pass.  One workgroup per (utterance, direction).
+ * H must satisfy advstep_lstm_supported() (80: LCNN's). */
+int advstep_lstm_supported(int64_t H);
+int advstep_lstm_forward_f32(const float *gx, const float *w_hh, float *out, float *gates, float *cell, int64_t T,
+                             int64_t B, int64_t D, int64_t H, advstep_stream_t stream);
+
+/* dgx (T, B, D, 4H): gradient w.r.t. the gate pre-activations, from dout (T, B, D*H); the caller maps it back to
+ * the layer input with one GEMM (dgx . W_ih). */
+int advstep_lstm_backward_f32(const float *dout, const float *w_hh, const float *gates, const float *cell, float *dgx,
+                              int64_t T, int64_t B, int64_t D, int64_t H, advstep_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

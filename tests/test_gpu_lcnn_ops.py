@@ -120,6 +120,7 @@ def test_fused_lcnn_is_bit_identical_to_plain_lcnn(cuda, monkeypatch):
     # the convolution-fusing kernels round differently from MIOpen; this test isolates the max-feature-map kernels
     monkeypatch.setenv("ADVSTEP_LCNN_CONV0", "0")
     monkeypatch.setenv("ADVSTEP_LCNN_CONV1X1", "0")
+    monkeypatch.setenv("ADVSTEP_LCNN_LSTM", "0")
 
     def run(fused, frozen, waveform=False):
         monkeypatch.setenv("ADVSTEP_LCNN_FUSED", "1" if fused else "0")
@@ -206,6 +207,7 @@ def test_lcnn_with_fused_first_block_agrees_with_miopen_path(cuda, monkeypatch):
     def run(conv0):
         monkeypatch.setenv("ADVSTEP_LCNN_CONV0", "1" if conv0 else "0")
         monkeypatch.setenv("ADVSTEP_LCNN_CONV1X1", "1" if conv0 else "0")
+        monkeypatch.setenv("ADVSTEP_LCNN_LSTM", "1" if conv0 else "0")
         a = spec.clone().requires_grad_(True)
         z = model._compute_embedding(a)
         (g,) = torch.autograd.grad(z.sum(), a)
@@ -253,3 +255,50 @@ def test_conv1x1_mfm_rejects_unsupported_and_unfrozen(L, cuda):
     w = torch.randn(8, 32, 1, 1, device=cuda, requires_grad=True)
     with pytest.raises(RuntimeError, match="input gradient only"):
         L.conv1x1_mfm(x, w, None).sum().backward()
+
+
+# ---- LSTM layer --------------------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("T,B,I", [(25, 6, 160), (1, 2, 160), (7, 128, 160), (3, 1, 32)])
+def test_lstm_layer_matches_torch_lstm(L, cuda, T, B, I):
+    torch.manual_seed(T * 100 + B)
+    H = 80
+    ref = torch.nn.LSTM(I, H, bidirectional=True).double()
+    x = torch.randn(T, B, I, dtype=torch.float64, requires_grad=True)
+    out_ref, _ = ref(x)
+    dout = torch.randn_like(out_ref)
+    (dx_ref,) = torch.autograd.grad(out_ref, x, dout)
+
+    w_ih = torch.cat([ref.weight_ih_l0, ref.weight_ih_l0_reverse]).float().to(cuda).contiguous()
+    w_hh = torch.stack([ref.weight_hh_l0, ref.weight_hh_l0_reverse]).float().to(cuda).contiguous()
+    bias = torch.cat([ref.bias_ih_l0 + ref.bias_hh_l0, ref.bias_ih_l0_reverse + ref.bias_hh_l0_reverse]).float().to(cuda)
+    xg = x.detach().float().to(cuda).requires_grad_(True)
+    out = L.lstm_layer(xg, w_ih.detach(), w_hh.detach(), bias.detach())
+    (dx,) = torch.autograd.grad(out, xg, dout.float().to(cuda))
+    assert out.shape == (T, B, 2 * H)
+    assert (out.double().cpu() - out_ref).abs().max().item() <= 2e-6
+    assert (dx.double().cpu() - dx_ref).abs().max().item() <= 2e-5 * max(dx_ref.abs().max().item(), 1.0)
+
+
+def test_blstm_layer_uses_kernel_when_frozen_and_matches_miopen(cuda, monkeypatch):
+    from audio_deepfake_adversarial_attacks_amd.models.lcnn import BLSTMLayer
+    torch.manual_seed(3)
+    layer = BLSTMLayer(160, 160).to(cuda).train()
+    x = torch.randn(16, 25, 160, device=cuda)
+
+    def run(kernel, frozen):
+        monkeypatch.setenv("ADVSTEP_LCNN_LSTM", "1" if kernel else "0")
+        for p in layer.parameters():
+            p.requires_grad_(not frozen)
+        a = x.clone().requires_grad_(True)
+        y = layer(a)
+        (g,) = torch.autograd.grad(y, a, torch.ones_like(y))
+        return y.detach(), g
+
+    y0, g0 = run(False, False)          # MIOpen
+    y1, g1 = run(True, True)            # HIP kernel
+    y2, g2 = run(True, False)           # parameters need grad -> falls back to MIOpen, identical to y0
+    assert torch.equal(y2, y0)
+    assert (y1 - y0).abs().max().item() <= 2e-6 and (g1 - g0).abs().max().item() <= 2e-5 * max(g0.abs().max().item(), 1.0)
+    for p in layer.parameters():
+        p.requires_grad_(True)
