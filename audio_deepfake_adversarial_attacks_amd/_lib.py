@@ -13,7 +13,7 @@ ABI_VERSION = 1
 _p, _i64, _f32, _f64, _u64, _sz = (ctypes.c_void_p, ctypes.c_int64, ctypes.c_float, ctypes.c_double,
                                    ctypes.c_uint64, ctypes.c_size_t)
 
-# name -> (restype, argtypes); one entry per symbol declared in include/advstep.h and include/advstep_lcnn.h
+# name -> (restype, argtypes); one entry per symbol declared in include/advstep.h, advstep_lcnn.h and advstep_frontend.h
 SIGNATURES = {
     "advstep_abi_version": (ctypes.c_int, []),
     "advstep_status_string": (ctypes.c_char_p, [ctypes.c_int]),
@@ -49,6 +49,14 @@ SIGNATURES = {
     "advstep_lstm_supported": (ctypes.c_int, [_i64]),
     "advstep_lstm_forward_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p]),
     "advstep_lstm_backward_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p]),
+    # include/advstep_frontend.h
+    "advstep_lfcc_block_count": (_sz, [_i64, _i64, _i64]),
+    "advstep_lfcc_bands_f32": (ctypes.c_int, [_p, _p, _p, _i64, _p, _p, _i64, _i64, _i64, _i64, _p]),
+    "advstep_lfcc_reduce_max_f32": (ctypes.c_int, [_p, _i64, _p, _p]),
+    "advstep_lfcc_project_f32": (ctypes.c_int, [_p, _p, _p, _f32, _p, _i64, _i64, _i64, _i64, _p]),
+    "advstep_lfcc_project_backward_f32": (ctypes.c_int, [_p, _p, _p, _p, _f32, _p, _i64, _i64, _i64, _i64, _p]),
+    "advstep_lfcc_floor_fixup_f32": (ctypes.c_int, [_p, _p, _p, _i64, _p]),
+    "advstep_lfcc_bands_backward_f32": (ctypes.c_int, [_p, _p, _p, _p, _i64, _p, _i64, _i64, _i64, _i64, _p]),
 }
 
 

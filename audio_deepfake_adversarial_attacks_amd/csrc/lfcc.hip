@@ -1,0 +1,315 @@
+// lfcc.hip — the LFCC frontend after the STFT, fused for gfx950 (C ABI: include/advstep_frontend.h).
+// See the header for the op chain it replaces.  All kernels stream (B, 128..257, 404) f32 planes with the frame
+// index fastest (coalesced), the DCT / its transpose run on the VALU with wave-uniform (scalar) coefficient operands.
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "advstep_frontend.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kFrames = 64;   // frames per projection tile (one wave per coefficient chunk)
+constexpr float kAmin = 1e-10f;
+constexpr float kDbScale = 4.342944819032518f;  // 10 / ln(10)
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+inline hipStream_t as_stream(advstep_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+inline int status_after_launch() { return hipGetLastError() == hipSuccess ? ADVSTEP_OK : ADVSTEP_ELAUNCH; }
+
+__device__ __forceinline__ float max_nan(float a, float b) {
+    if (a != a) return a;
+    if (b != b) return b;
+    return a > b ? a : b;
+}
+
+__device__ __forceinline__ float block_max(float v, float *lds) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = max_nan(v, __shfl_xor(v, off, 64));
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = lds[0];
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r = max_nan(r, lds[w]);
+    return r;
+}
+
+__device__ __forceinline__ float block_sum(float v, float *lds) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = lds[0];
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r += lds[w];
+    return r;
+}
+
+// d/d band of 10*log10(clamp(band, amin)), band recovered from its dB value
+__device__ __forceinline__ float dlog_of_db(float db) {
+    return (db > -100.0f) ? kDbScale / expf(db * 0.23025850929940457f) : 0.0f;
+}
+
+// Layouts (the STFT's native one: torch.stft returns a (B, F, NF) VIEW of a (B, NF, F) buffer): everything here is
+// frame-major with the spectral index fastest — spec (B, NF, F) complex, band_db / dband (B, NF, M), out / dout (B, NF, K).
+
+// thread = (frame t, band m), m fastest: neighbouring lanes read neighbouring bins
+__global__ __launch_bounds__(kBlock) void lfcc_bands_kernel(const float2 *__restrict__ spec,
+                                                            const int32_t *__restrict__ fb_start,
+                                                            const float *__restrict__ fb_w, int span,
+                                                            float *__restrict__ band_db, float *__restrict__ bmax, int F,
+                                                            int M, int NF) {
+    __shared__ float lds[kBlock / 64];
+    const int64_t b = blockIdx.y;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    float db = -INFINITY;
+    if (i < M * NF) {
+        const int t = i / M, m = i - t * M;
+        const int f0 = fb_start[m];
+        const float2 *row = spec + (b * NF + t) * F;
+        float band = 0.0f;
+        for (int j = 0; j < span; ++j) {
+            const int f = f0 + j;
+            if (f < F) {
+                const float2 z = row[f];
+                band = fmaf(fb_w[m * span + j], fmaf(z.x, z.x, z.y * z.y), band);
+            }
+        }
+        db = 10.0f * log10f(band > kAmin ? band : (band != band ? band : kAmin));
+        band_db[(b * NF) * M + i] = db;
+    }
+    const float r = block_max(db, lds);
+    if (threadIdx.x == 0) bmax[b * gridDim.x + blockIdx.x] = r;
+}
+
+__global__ __launch_bounds__(kBlock) void lfcc_reduce_max_kernel(const float *__restrict__ bmax, int64_t n,
+                                                                 float *__restrict__ stats) {
+    __shared__ float lds[kBlock / 64];
+    float v = -INFINITY;
+    for (int64_t i = threadIdx.x; i < n; i += kBlock) v = max_nan(v, bmax[i]);
+    v = block_max(v, lds);
+    if (threadIdx.x == 0) {
+        stats[0] = v;
+        stats[1] = 0.0f;
+        stats[2] = 0.0f;
+        stats[3] = 0.0f;
+    }
+}
+
+constexpr int kMaxBands = 128;
+
+// grid (ceil(NF / 64), B), block 256 = 64 frames x 4 coefficient chunks (one wave per chunk: uniform DCT operands).
+// The 64 x M band tile is contiguous in memory: staged through LDS (floor applied on the way in), rows padded by one
+// word so the per-frame reads of a wave hit 32 different banks.
+template <int KC>  // coefficients per chunk (K = 4 * KC)
+__global__ __launch_bounds__(kBlock) void lfcc_project_kernel(const float *__restrict__ band_db,
+                                                              const float *__restrict__ dct, float *stats, float top_db,
+                                                              float *__restrict__ out, int M, int NF) {
+    constexpr int K = 4 * KC;
+    __shared__ float band_s[kFrames][kMaxBands + 1];
+    __shared__ float tile[kFrames][K + 1];
+    const int64_t b = blockIdx.y;
+    const int t0 = blockIdx.x * kFrames;
+    const int nfr = NF - t0 < kFrames ? NF - t0 : kFrames;
+    const int tl = threadIdx.x & 63, kc = threadIdx.x >> 6;
+    const float gmax = stats[0];
+    const float floor_db = gmax - top_db;
+    const float *src = band_db + (b * NF + t0) * M;
+    int ties = 0;
+    for (int i = threadIdx.x; i < nfr * M; i += kBlock) {
+        float v = src[i];
+        ties += (v == gmax) ? 1 : 0;
+        v = (v != v) ? v : ((floor_db != floor_db) ? floor_db : (v > floor_db ? v : floor_db));  // torch.max, NaN kept
+        band_s[i / M][i % M] = v;
+    }
+    if (ties) atomicAdd(&stats[1], (float)ties);
+    __syncthreads();
+    float acc[KC];
+#pragma unroll
+    for (int k = 0; k < KC; ++k) acc[k] = 0.0f;
+    if (tl < nfr) {
+        for (int m = 0; m < M; ++m) {
+            const float v = band_s[tl][m];
+            const float *dr = dct + m * K + kc * KC;
+#pragma unroll
+            for (int k = 0; k < KC; ++k) acc[k] = fmaf(v, dr[k], acc[k]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < KC; ++k) tile[tl][kc * KC + k] = acc[k];
+    __syncthreads();
+    float *dst = out + (b * NF + t0) * K;
+    for (int i = threadIdx.x; i < nfr * K; i += kBlock) dst[i] = tile[i / K][i % K];
+}
+
+// grid (ceil(NF / 64), B), block 256 = 64 frames x 4 band chunks; band tile staged in LDS and overwritten in place
+template <int KC>
+__global__ __launch_bounds__(kBlock) void lfcc_project_backward_kernel(const float *__restrict__ dout,
+                                                                       const float *__restrict__ dct,
+                                                                       const float *__restrict__ band_db, float *stats,
+                                                                       float top_db, float *__restrict__ dband, int M,
+                                                                       int NF) {
+    constexpr int K = 4 * KC;
+    __shared__ float tile[kFrames][K + 1];
+    __shared__ float band_s[kFrames][kMaxBands + 1];
+    __shared__ float lds[kBlock / 64];
+    const int64_t b = blockIdx.y;
+    const int t0 = blockIdx.x * kFrames;
+    const int nfr = NF - t0 < kFrames ? NF - t0 : kFrames;
+    const int tl = threadIdx.x & 63, mc = threadIdx.x >> 6;
+    const float *src = dout + (b * NF + t0) * K;
+    for (int i = threadIdx.x; i < nfr * K; i += kBlock) tile[i / K][i % K] = src[i];
+    const float *bsrc = band_db + (b * NF + t0) * M;
+    for (int i = threadIdx.x; i < nfr * M; i += kBlock) band_s[i / M][i % M] = bsrc[i];
+    __syncthreads();
+    float g[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) g[k] = tile[tl][k];
+    const float floor_db = stats[0] - top_db;
+    const int mper = (M + 3) / 4;
+    float floored = 0.0f;
+    if (tl < nfr) {
+        for (int m = mc * mper; m < (mc + 1) * mper && m < M; ++m) {
+            const float *dr = dct + m * K;
+            float s = 0.0f;
+#pragma unroll
+            for (int k = 0; k < K; ++k) s = fmaf(g[k], dr[k], s);
+            const float db = band_s[tl][m];
+            const float wgt = db > floor_db ? 1.0f : (db == floor_db ? 0.5f : 0.0f);  // torch.max(a, b) backward
+            floored += (1.0f - wgt) * s;
+            band_s[tl][m] = (wgt * s) * dlog_of_db(db);
+        }
+    }
+    floored = block_sum(floored, lds);  // (contains the barrier that orders the in-place tile writes)
+    if (threadIdx.x == 0 && floored != 0.0f) atomicAdd(&stats[2], floored);
+    float *dst = dband + (b * NF + t0) * M;
+    for (int i = threadIdx.x; i < nfr * M; i += kBlock) dst[i] = band_s[i / M][i % M];
+}
+
+__global__ __launch_bounds__(kBlock) void lfcc_floor_fixup_kernel(const float *__restrict__ band_db,
+                                                                  const float *__restrict__ stats,
+                                                                  float *__restrict__ dband, int64_t n) {
+    const float s = stats[2];
+    if (s == 0.0f) return;  // nothing was floored: the usual case
+    const float gmax = stats[0];
+    const float share = s / (stats[1] > 0.0f ? stats[1] : 1.0f);
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const float db = band_db[i];
+        if (db == gmax) dband[i] += share * dlog_of_db(db);
+    }
+}
+
+// thread = (frame t, bin f), f fastest
+__global__ __launch_bounds__(kBlock) void lfcc_bands_backward_kernel(const float *__restrict__ dband,
+                                                                     const float2 *__restrict__ spec,
+                                                                     const int32_t *__restrict__ fbt_start,
+                                                                     const float *__restrict__ fbt_w, int span_t,
+                                                                     float2 *__restrict__ dspec, int F, int M, int NF) {
+    const int64_t b = blockIdx.y;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= F * NF) return;
+    const int t = i / F, f = i - t * F;
+    const int m0 = fbt_start[f];
+    const float *row = dband + (b * NF + t) * M;
+    float dp = 0.0f;
+    for (int j = 0; j < span_t; ++j) {
+        const int m = m0 + j;
+        if (m < M) dp = fmaf(fbt_w[f * span_t + j], row[m], dp);
+    }
+    const float2 z = spec[(b * NF) * F + i];
+    dspec[(b * NF) * F + i] = make_float2(2.0f * z.x * dp, 2.0f * z.y * dp);
+}
+
+constexpr int64_t kMaxGridY = 65535;
+
+}  // namespace
+
+#define LFCC_REQUIRE(cond) \
+    do {                   \
+        if (!(cond)) return ADVSTEP_EINVAL; \
+    } while (0)
+
+extern "C" {
+
+size_t advstep_lfcc_block_count(int64_t B, int64_t M, int64_t NF) {
+    if (B <= 0 || M <= 0 || NF <= 0) return 0;
+    return (size_t)B * (size_t)ceil_div(M * NF, kBlock);
+}
+
+int advstep_lfcc_bands_f32(const float *spec, const int32_t *fb_start, const float *fb_w, int64_t span, float *band_db,
+                           float *block_max, int64_t B, int64_t F, int64_t M, int64_t NF, advstep_stream_t stream) {
+    LFCC_REQUIRE(B >= 0 && F >= 0 && M >= 0 && NF >= 0 && span >= 1);
+    if (B == 0 || M == 0 || NF == 0) return ADVSTEP_OK;
+    LFCC_REQUIRE(spec && fb_start && fb_w && band_db && block_max && B <= kMaxGridY && M * NF <= INT32_MAX &&
+                 F * NF <= INT32_MAX);
+    const dim3 grid((unsigned)ceil_div(M * NF, kBlock), (unsigned)B);
+    hipLaunchKernelGGL(lfcc_bands_kernel, grid, dim3(kBlock), 0, as_stream(stream),
+                       reinterpret_cast<const float2 *>(spec), fb_start, fb_w, (int)span, band_db, block_max, (int)F,
+                       (int)M, (int)NF);
+    return status_after_launch();
+}
+
+int advstep_lfcc_reduce_max_f32(const float *block_max, int64_t n, float *stats, advstep_stream_t stream) {
+    LFCC_REQUIRE(n >= 1 && block_max && stats);
+    hipLaunchKernelGGL(lfcc_reduce_max_kernel, dim3(1), dim3(kBlock), 0, as_stream(stream), block_max, n, stats);
+    return status_after_launch();
+}
+
+int advstep_lfcc_project_f32(const float *band_db, const float *dct, float *stats, float top_db, float *out, int64_t B,
+                             int64_t M, int64_t NF, int64_t K, advstep_stream_t stream) {
+    LFCC_REQUIRE(B >= 0 && M >= 0 && M <= kMaxBands && NF >= 0 && (K == 80 || K == 40 || K == 20));
+    if (B == 0 || NF == 0) return ADVSTEP_OK;
+    LFCC_REQUIRE(band_db && dct && stats && out && B <= kMaxGridY && M <= INT32_MAX && NF <= INT32_MAX);
+    const dim3 grid((unsigned)ceil_div(NF, kFrames), (unsigned)B);
+    hipStream_t st = as_stream(stream);
+    if (K == 80)
+        hipLaunchKernelGGL(lfcc_project_kernel<20>, grid, dim3(kBlock), 0, st, band_db, dct, stats, top_db, out, (int)M, (int)NF);
+    else if (K == 40)
+        hipLaunchKernelGGL(lfcc_project_kernel<10>, grid, dim3(kBlock), 0, st, band_db, dct, stats, top_db, out, (int)M, (int)NF);
+    else
+        hipLaunchKernelGGL(lfcc_project_kernel<5>, grid, dim3(kBlock), 0, st, band_db, dct, stats, top_db, out, (int)M, (int)NF);
+    return status_after_launch();
+}
+
+int advstep_lfcc_project_backward_f32(const float *dout, const float *dct, const float *band_db, float *stats,
+                                      float top_db, float *dband, int64_t B, int64_t M, int64_t NF, int64_t K,
+                                      advstep_stream_t stream) {
+    LFCC_REQUIRE(B >= 0 && M >= 0 && M <= kMaxBands && NF >= 0 && (K == 80 || K == 40 || K == 20));
+    if (B == 0 || NF == 0 || M == 0) return ADVSTEP_OK;
+    LFCC_REQUIRE(dout && dct && band_db && stats && dband && B <= kMaxGridY && M <= INT32_MAX && NF <= INT32_MAX);
+    const dim3 grid((unsigned)ceil_div(NF, kFrames), (unsigned)B);
+    hipStream_t st = as_stream(stream);
+    if (K == 80)
+        hipLaunchKernelGGL(lfcc_project_backward_kernel<20>, grid, dim3(kBlock), 0, st, dout, dct, band_db, stats, top_db, dband, (int)M, (int)NF);
+    else if (K == 40)
+        hipLaunchKernelGGL(lfcc_project_backward_kernel<10>, grid, dim3(kBlock), 0, st, dout, dct, band_db, stats, top_db, dband, (int)M, (int)NF);
+    else
+        hipLaunchKernelGGL(lfcc_project_backward_kernel<5>, grid, dim3(kBlock), 0, st, dout, dct, band_db, stats, top_db, dband, (int)M, (int)NF);
+    return status_after_launch();
+}
+
+int advstep_lfcc_floor_fixup_f32(const float *band_db, const float *stats, float *dband, int64_t n,
+                                 advstep_stream_t stream) {
+    LFCC_REQUIRE(n >= 0);
+    if (n == 0) return ADVSTEP_OK;
+    LFCC_REQUIRE(band_db && stats && dband);
+    const int64_t blocks = ceil_div(n, kBlock);
+    hipLaunchKernelGGL(lfcc_floor_fixup_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(kBlock), 0,
+                       as_stream(stream), band_db, stats, dband, n);
+    return status_after_launch();
+}
+
+int advstep_lfcc_bands_backward_f32(const float *dband, const float *spec, const int32_t *fbt_start, const float *fbt_w,
+                                    int64_t span_t, float *dspec, int64_t B, int64_t F, int64_t M, int64_t NF,
+                                    advstep_stream_t stream) {
+    LFCC_REQUIRE(B >= 0 && F >= 0 && M >= 0 && NF >= 0 && span_t >= 1);
+    if (B == 0 || F == 0 || NF == 0) return ADVSTEP_OK;
+    LFCC_REQUIRE(dband && spec && fbt_start && fbt_w && dspec && B <= kMaxGridY && F * NF <= INT32_MAX);
+    const dim3 grid((unsigned)ceil_div(F * NF, kBlock), (unsigned)B);
+    hipLaunchKernelGGL(lfcc_bands_backward_kernel, grid, dim3(kBlock), 0, as_stream(stream), dband,
+                       reinterpret_cast<const float2 *>(spec), fbt_start, fbt_w, (int)span_t,
+                       reinterpret_cast<float2 *>(dspec), (int)F, (int)M, (int)NF);
+    return status_after_launch();
+}
+
+}  // extern "C"

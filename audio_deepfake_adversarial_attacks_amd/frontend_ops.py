@@ -1,0 +1,109 @@
+"""The LFCC frontend after the STFT as one differentiable op backed by the HIP kernels of include/advstep_frontend.h
+(SURVEY.md section 8-f2): power -> sparse linear filterbank -> dB with the batch-wide floor -> DCT, forward and
+backward, written frame-major so LCNN's first block reads it without a transpose copy.
+
+`lfcc_tail(spec, tables, dct, top_db)` takes torch.stft's complex output (B, F, NF) and returns (B, K, NF) — a view of
+a contiguous (B, NF, K) buffer.  Numerically it follows frontends.LFCC (this repository's restatement of torchaudio's
+LFCC) to float rounding, including torchaudio's gradient path through `amax` (floored gradients flow to the batch
+maximum); tests/test_gpu_frontend_ops.py.  HIP tensors only."""
+from __future__ import annotations
+
+from typing import NamedTuple
+
+import torch
+
+from . import _lib
+from .hip_ops import _Launch, _stream
+
+
+class FilterbankTables(NamedTuple):
+    """Sparse form of a (F, M) triangular filterbank: per band the first bin + `span` weights, and the transpose."""
+    fb_start: torch.Tensor   # (M,) int32
+    fb_w: torch.Tensor       # (M, span) float32
+    span: int
+    fbt_start: torch.Tensor  # (F,) int32
+    fbt_w: torch.Tensor      # (F, span_t) float32
+    span_t: int
+
+
+def filterbank_tables(filter_mat: torch.Tensor) -> FilterbankTables:
+    fb = filter_mat.detach().float().cpu()
+    F, M = fb.shape
+
+    def pack(mat):  # rows of `mat` are the outputs; gather each row's non-zero run
+        n_out = mat.shape[0]
+        starts, spans = [], []
+        for r in range(n_out):
+            nz = torch.nonzero(mat[r]).flatten()
+            starts.append(int(nz.min()) if nz.numel() else 0)
+            spans.append(int(nz.max()) - int(nz.min()) + 1 if nz.numel() else 1)
+        span = max(spans)
+        w = torch.zeros(n_out, span)
+        for r in range(n_out):
+            hi = min(starts[r] + span, mat.shape[1])
+            w[r, : hi - starts[r]] = mat[r, starts[r]:hi]
+        return torch.tensor(starts, dtype=torch.int32), w, span
+
+    fb_start, fb_w, span = pack(fb.t().contiguous())      # per band over bins
+    fbt_start, fbt_w, span_t = pack(fb)                    # per bin over bands
+    dev = filter_mat.device
+    return FilterbankTables(fb_start.to(dev), fb_w.to(dev).contiguous(), span, fbt_start.to(dev),
+                            fbt_w.to(dev).contiguous(), span_t)
+
+
+class _LfccTail(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, spec, tables: FilterbankTables, dct, top_db: float):
+        if not spec.is_cuda or spec.dtype != torch.complex64 or spec.dim() != 3:
+            raise _lib.AdvstepError("lfcc_tail needs a complex64 (B, F, NF) STFT on a HIP device (no CPU fallback)")
+        B, F, NF = spec.shape
+        sn = spec.transpose(1, 2)
+        if not sn.is_contiguous():       # torch.stft's native layout is already (B, NF, F)
+            sn = sn.contiguous()
+        sr = torch.view_as_real(sn)      # (B, NF, F, 2) float32
+        M, K = dct.shape
+        dev = spec.device
+        lib = _lib.load()
+        band_db = torch.empty((B, NF, M), dtype=torch.float32, device=dev)
+        nblk = lib.advstep_lfcc_block_count(B, M, NF)
+        block_max = torch.empty(max(nblk, 1), dtype=torch.float32, device=dev)
+        stats = torch.empty(4, dtype=torch.float32, device=dev)
+        out = torch.empty((B, NF, K), dtype=torch.float32, device=dev)
+        with _Launch("lfcc_forward", dev):
+            st = lib.advstep_lfcc_bands_f32(sr.data_ptr(), tables.fb_start.data_ptr(), tables.fb_w.data_ptr(), tables.span,
+                                            band_db.data_ptr(), block_max.data_ptr(), B, F, M, NF, _stream(dev))
+            _lib.check(st, "advstep_lfcc_bands_f32")
+            st = lib.advstep_lfcc_reduce_max_f32(block_max.data_ptr(), nblk, stats.data_ptr(), _stream(dev))
+            _lib.check(st, "advstep_lfcc_reduce_max_f32")
+            st = lib.advstep_lfcc_project_f32(band_db.data_ptr(), dct.data_ptr(), stats.data_ptr(), top_db, out.data_ptr(),
+                                              B, M, NF, K, _stream(dev))
+            _lib.check(st, "advstep_lfcc_project_f32")
+        ctx.save_for_backward(sr, band_db, stats, dct, tables.fbt_start, tables.fbt_w)
+        ctx.meta = (B, F, NF, M, K, tables.span_t, float(top_db))
+        return out.transpose(1, 2)
+
+    @staticmethod
+    def backward(ctx, gout):
+        sr, band_db, stats, dct, fbt_start, fbt_w = ctx.saved_tensors
+        B, F, NF, M, K, span_t, top_db = ctx.meta
+        dev = gout.device
+        go = gout.transpose(1, 2).contiguous()     # (B, NF, K); a no-op when the consumer is frame-major
+        lib = _lib.load()
+        dband = torch.empty((B, NF, M), dtype=torch.float32, device=dev)
+        dspec = torch.empty((B, NF, F, 2), dtype=torch.float32, device=dev)
+        with _Launch("lfcc_backward", dev):
+            st = lib.advstep_lfcc_project_backward_f32(go.data_ptr(), dct.data_ptr(), band_db.data_ptr(), stats.data_ptr(),
+                                                       top_db, dband.data_ptr(), B, M, NF, K, _stream(dev))
+            _lib.check(st, "advstep_lfcc_project_backward_f32")
+            st = lib.advstep_lfcc_floor_fixup_f32(band_db.data_ptr(), stats.data_ptr(), dband.data_ptr(), band_db.numel(),
+                                                  _stream(dev))
+            _lib.check(st, "advstep_lfcc_floor_fixup_f32")
+            st = lib.advstep_lfcc_bands_backward_f32(dband.data_ptr(), sr.data_ptr(), fbt_start.data_ptr(),
+                                                     fbt_w.data_ptr(), span_t, dspec.data_ptr(), B, F, M, NF, _stream(dev))
+            _lib.check(st, "advstep_lfcc_bands_backward_f32")
+        return torch.view_as_complex(dspec).transpose(1, 2), None, None, None
+
+
+def lfcc_tail(spec: torch.Tensor, tables: FilterbankTables, dct: torch.Tensor, top_db: float = 80.0) -> torch.Tensor:
+    """Complex STFT (B, F, NF) -> LFCC (B, K, NF) (view of a frame-major buffer)."""
+    return _LfccTail.apply(spec, tables, dct, top_db)

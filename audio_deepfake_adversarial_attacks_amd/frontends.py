@@ -26,6 +26,12 @@ from typing import Callable, List, Union
 import torch
 from torch import nn
 
+def _fused_lfcc_enabled() -> bool:
+    """ADVSTEP_FUSED_LFCC=0 keeps the plain torch op chain on the GPU (A/B measurements); default on."""
+    import os
+    return os.environ.get("ADVSTEP_FUSED_LFCC", "1") != "0"
+
+
 # values from FakeAVCeleb paper (frontends.py:6-9)
 SAMPLING_RATE = 16_000
 win_length = 400  # int((25 / 1_000) * SAMPLING_RATE)
@@ -121,7 +127,25 @@ class LFCC(nn.Module):
                                                          sample_rate))
         self.register_buffer("dct_mat", create_dct(n_lfcc, n_filter, "ortho"))
 
+    def _tables(self):
+        """Sparse filterbank tables for the fused kernels, cached until `filter_mat` moves or changes."""
+        key = (self.filter_mat.data_ptr(), self.filter_mat._version, str(self.filter_mat.device))
+        if getattr(self, "_tables_key", None) != key:
+            from . import frontend_ops
+            self._tables_key, self._tables_val = key, frontend_ops.filterbank_tables(self.filter_mat)
+        return self._tables_val
+
     def forward(self, waveform: torch.Tensor) -> torch.Tensor:
+        if (waveform.is_cuda and waveform.dim() == 2 and waveform.dtype == torch.float32 and _fused_lfcc_enabled()
+                and self.dct_mat.shape[0] <= 128 and self.dct_mat.shape[1] in (20, 40, 80)):
+            # STFT by PyTorch (reflect pad + framing + rocFFT); everything after it in two kernels (+3 backward),
+            # written frame-major for LCNN's first block (SURVEY.md section 8-f2)
+            from . import frontend_ops
+            sg = self.Spectrogram
+            spec = torch.stft(waveform, n_fft=sg.n_fft, hop_length=sg.hop_length, win_length=sg.win_length,
+                              window=sg.window, center=True, pad_mode="reflect", normalized=False, onesided=True,
+                              return_complex=True)
+            return frontend_ops.lfcc_tail(spec, self._tables(), self.dct_mat, self.top_db)
         spec = self.Spectrogram(waveform)                                               # (B, 257, frames)
         bands = torch.matmul(spec.transpose(-1, -2), self.filter_mat).transpose(-1, -2)   # (B, 128, frames)
         bands = amplitude_to_db_power(bands, self.top_db)

@@ -1,0 +1,69 @@
+/*
+ * advstep_frontend.h — C ABI of the fused LFCC tail in libadvstep.so.
+ *
+ * Reference: src/frontends.py:24-32 `LFCC_FN` = torchaudio.transforms.LFCC(n_lfcc=80, n_filter=128, n_fft=512,
+ * win 400, hop 160), called inside `model(adv)` on every attack step (src/models/lcnn.py:233-237).  torchaudio's forward
+ * after the STFT is:  |X|^2 -> matmul(linear filterbank 257x128) -> 10*log10(clamp(., 1e-10)) -> max(., batch_max - 80)
+ * -> matmul(DCT 128x80), with four transposes in between; under autograd that is ~25 small kernels per direction.
+ * Here the STFT (reflect pad + framing + rocFFT) stays with PyTorch and everything after it is two kernels forward and
+ * three backward:
+ *   bands   : power + SPARSE triangular filterbank (each band touches <= `span` bins) + dB, per-block maxima
+ *   project : batch-wide floor + DCT, written FRAME-MAJOR (B, frames, n_lfcc) — the layout LCNN's first block reads,
+ *             so the (B, 80, 404) -> (B, 404, 80) transpose copy disappears
+ *   backward: DCT^T + floor mask (+ the floored gradients, which torchaudio routes to the batch maximum through
+ *             `amax`) + d(dB); then filterbank^T and d|X|^2 back to the complex spectrum.
+ * PARITY UNPINNED against torchaudio (absent from the reference tree); pinned against this repository's own torch
+ * restatement (frontends.LFCC) within float tolerance (tests/test_gpu_frontend_ops.py).
+ * Conventions as in advstep.h.  Layouts are frame-major with the spectral index fastest — the STFT's native one
+ * (torch.stft returns a (B, F, NF) view of a (B, NF, F) buffer): spec (B, NF, F) complex64 as float pairs,
+ * band_db / dband (B, NF, M), out / dout (B, NF, K).  M <= 128.
+ */
+#ifndef ADVSTEP_FRONTEND_H_
+#define ADVSTEP_FRONTEND_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "advstep.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Number of per-block maxima `advstep_lfcc_bands_f32` writes (size of `block_max`, floats). */
+size_t advstep_lfcc_block_count(int64_t B, int64_t M, int64_t NF);
+
+/* band_db[b, t, m] = 10*log10(max(sum_j fb_w[m, j] * |spec[b, t, fb_start[m] + j]|^2, 1e-10));
+ * block_max[i] = maximum of band_db over workgroup i (NaN propagates). fb_w is (M, span), zero padded. */
+int advstep_lfcc_bands_f32(const float *spec, const int32_t *fb_start, const float *fb_w, int64_t span, float *band_db,
+                           float *block_max, int64_t B, int64_t F, int64_t M, int64_t NF, advstep_stream_t stream);
+
+/* stats[0] = max(block_max[0..n)), stats[1] = 0 (tie counter, filled by the projection), stats[2] = 0 (floored-gradient
+ * sum, filled by the backward pass).  stats holds 4 floats. */
+int advstep_lfcc_reduce_max_f32(const float *block_max, int64_t n, float *stats, advstep_stream_t stream);
+
+/* out[b, t, k] = sum_m max(band_db[b, t, m], stats[0] - top_db) * dct[m, k]  (dct is (M, K)); also counts, in
+ * stats[1], the elements equal to the batch maximum (normally 1).  K must be a multiple of 4 and <= 128. */
+int advstep_lfcc_project_f32(const float *band_db, const float *dct, float *stats, float top_db, float *out, int64_t B,
+                             int64_t M, int64_t NF, int64_t K, advstep_stream_t stream);
+
+/* dband[b, t, m] = d loss / d (band power) from dout (B, NF, K): DCT^T, floor mask of torch.max (1 / 0.5 / 0), and
+ * d(10 log10 clamp) ; the floored share of the gradient is summed into stats[2]. */
+int advstep_lfcc_project_backward_f32(const float *dout, const float *dct, const float *band_db, float *stats,
+                                      float top_db, float *dband, int64_t B, int64_t M, int64_t NF, int64_t K,
+                                      advstep_stream_t stream);
+
+/* torchaudio's floor is `amax(x_db) - top_db`, so the floored gradients flow to the batch maximum: adds
+ * stats[2] / stats[1] * d(dB) at every element of band_db equal to stats[0].  No-op when stats[2] == 0. */
+int advstep_lfcc_floor_fixup_f32(const float *band_db, const float *stats, float *dband, int64_t n,
+                                 advstep_stream_t stream);
+
+/* dspec[b, t, f] = 2 * spec[b, t, f] * sum_j fbt_w[f, j] * dband[b, t, fbt_start[f] + j]  (complex, as float pairs). */
+int advstep_lfcc_bands_backward_f32(const float *dband, const float *spec, const int32_t *fbt_start, const float *fbt_w,
+                                    int64_t span_t, float *dspec, int64_t B, int64_t F, int64_t M, int64_t NF,
+                                    advstep_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADVSTEP_FRONTEND_H_ */
