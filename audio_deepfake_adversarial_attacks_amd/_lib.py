@@ -56,7 +56,9 @@ SIGNATURES = {
     "advstep_lfcc_project_f32": (ctypes.c_int, [_p, _p, _p, _f32, _p, _i64, _i64, _i64, _i64, _p]),
     "advstep_lfcc_project_backward_f32": (ctypes.c_int, [_p, _p, _p, _p, _f32, _p, _i64, _i64, _i64, _i64, _p]),
     "advstep_lfcc_floor_fixup_f32": (ctypes.c_int, [_p, _p, _p, _i64, _p]),
-    "advstep_lfcc_bands_backward_f32": (ctypes.c_int, [_p, _p, _p, _p, _i64, _p, _i64, _i64, _i64, _i64, _p]),
+    "advstep_lfcc_bands_backward_f32": (ctypes.c_int, [_p, _p, _p, _p, _i64, _p, _i64, _i64, _i64, _i64, ctypes.c_int, _p]),
+    "advstep_stft_frames_f32": (ctypes.c_int, [_p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p]),
+    "advstep_stft_overlap_add_f32": (ctypes.c_int, [_p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p]),
 }
 
 

@@ -204,7 +204,8 @@ __global__ __launch_bounds__(kBlock) void lfcc_bands_backward_kernel(const float
                                                                      const float2 *__restrict__ spec,
                                                                      const int32_t *__restrict__ fbt_start,
                                                                      const float *__restrict__ fbt_w, int span_t,
-                                                                     float2 *__restrict__ dspec, int F, int M, int NF) {
+                                                                     float2 *__restrict__ dspec, int F, int M, int NF,
+                                                                     int hermitian_half) {
     const int64_t b = blockIdx.y;
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= F * NF) return;
@@ -217,7 +218,62 @@ __global__ __launch_bounds__(kBlock) void lfcc_bands_backward_kernel(const float
         if (m < M) dp = fmaf(fbt_w[f * span_t + j], row[m], dp);
     }
     const float2 z = spec[(b * NF) * F + i];
-    dspec[(b * NF) * F + i] = make_float2(2.0f * z.x * dp, 2.0f * z.y * dp);
+    float2 g = make_float2(2.0f * z.x * dp, 2.0f * z.y * dp);
+    if (hermitian_half) {
+        // hand the gradient of a one-sided real FFT to a c2r transform: interior bins are counted twice there
+        if (f == 0 || f == F - 1) g.y = 0.0f; else { g.x *= 0.5f; g.y *= 0.5f; }
+    }
+    dspec[(b * NF) * F + i] = g;
+}
+
+// frames[b, f, n] = w[n] * x[b, reflect(f * hop + n - pad)]   (torch.stft(center=True, pad_mode="reflect") framing)
+__global__ __launch_bounds__(kBlock) void stft_frames_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                             float *__restrict__ frames, int T, int NF, int hop,
+                                                             int nfft, int pad) {
+    const int64_t b = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;   // over NF * nfft / 4 float4 groups
+    const int per_frame = nfft >> 2;
+    if (i >= (int64_t)NF * per_frame) return;
+    const int f = (int)(i / per_frame), n0 = (int)(i - (int64_t)f * per_frame) * 4;
+    const float *xb = x + b * T;
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int q = f * hop + n0 + k - pad;
+        q = q < 0 ? -q : q;
+        q = q >= T ? 2 * (T - 1) - q : q;
+        v[k] = w[n0 + k] * xb[q];
+    }
+    reinterpret_cast<float4 *>(frames + (b * NF + f) * nfft)[n0 >> 2] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+// transpose of the framing: dx[b, t] = sum over padded positions q that read sample t, over frames covering q
+__global__ __launch_bounds__(kBlock) void stft_overlap_add_kernel(const float *__restrict__ dframes,
+                                                                  const float *__restrict__ w, float *__restrict__ dx,
+                                                                  int T, int NF, int hop, int nfft, int pad) {
+    const int64_t b = blockIdx.y;
+    const int t = blockIdx.x * kBlock + threadIdx.x;
+    if (t >= T) return;
+    const float *db = dframes + b * (int64_t)NF * nfft;
+    // padded coordinates p = q + pad of the (at most three) positions that read sample t
+    int ps[3];
+    int np = 0;
+    ps[np++] = t + pad;
+    if (t >= 1 && t <= pad) ps[np++] = pad - t;                       // left reflection
+    if (t <= T - 2 && t >= T - 1 - pad) ps[np++] = 2 * (T - 1) - t + pad;  // right reflection
+    float acc = 0.0f;
+    for (int k = 0; k < np; ++k) {
+        const int p = ps[k];
+        int f_hi = p / hop;
+        if (f_hi > NF - 1) f_hi = NF - 1;
+        int f_lo = (p - nfft + hop) / hop;   // ceil((p - nfft + 1) / hop)
+        if (f_lo < 0) f_lo = 0;
+        for (int f = f_lo; f <= f_hi; ++f) {
+            const int n = p - f * hop;
+            if (n >= 0 && n < nfft) acc = fmaf(w[n], db[(int64_t)f * nfft + n], acc);
+        }
+    }
+    dx[b * T + t] = acc;
 }
 
 constexpr int64_t kMaxGridY = 65535;
@@ -301,14 +357,39 @@ int advstep_lfcc_floor_fixup_f32(const float *band_db, const float *stats, float
 
 int advstep_lfcc_bands_backward_f32(const float *dband, const float *spec, const int32_t *fbt_start, const float *fbt_w,
                                     int64_t span_t, float *dspec, int64_t B, int64_t F, int64_t M, int64_t NF,
-                                    advstep_stream_t stream) {
+                                    int hermitian_half, advstep_stream_t stream) {
     LFCC_REQUIRE(B >= 0 && F >= 0 && M >= 0 && NF >= 0 && span_t >= 1);
     if (B == 0 || F == 0 || NF == 0) return ADVSTEP_OK;
     LFCC_REQUIRE(dband && spec && fbt_start && fbt_w && dspec && B <= kMaxGridY && F * NF <= INT32_MAX);
     const dim3 grid((unsigned)ceil_div(F * NF, kBlock), (unsigned)B);
     hipLaunchKernelGGL(lfcc_bands_backward_kernel, grid, dim3(kBlock), 0, as_stream(stream), dband,
                        reinterpret_cast<const float2 *>(spec), fbt_start, fbt_w, (int)span_t,
-                       reinterpret_cast<float2 *>(dspec), (int)F, (int)M, (int)NF);
+                       reinterpret_cast<float2 *>(dspec), (int)F, (int)M, (int)NF, hermitian_half);
+    return status_after_launch();
+}
+
+int advstep_stft_frames_f32(const float *x, const float *window, float *frames, int64_t B, int64_t T, int64_t NF,
+                            int64_t hop, int64_t nfft, advstep_stream_t stream) {
+    LFCC_REQUIRE(B >= 0 && T >= 0 && NF >= 0 && hop >= 1 && nfft >= 4 && nfft % 4 == 0);
+    if (B == 0 || NF == 0) return ADVSTEP_OK;
+    const int64_t pad = nfft / 2;
+    LFCC_REQUIRE(x && window && frames && B <= kMaxGridY && T > pad && (NF - 1) * hop + nfft - pad <= T + pad &&
+                 T + nfft <= INT32_MAX && ((reinterpret_cast<uintptr_t>(frames) & 15u) == 0));
+    const dim3 grid((unsigned)ceil_div(NF * (nfft / 4), kBlock), (unsigned)B);
+    hipLaunchKernelGGL(stft_frames_kernel, grid, dim3(kBlock), 0, as_stream(stream), x, window, frames, (int)T, (int)NF,
+                       (int)hop, (int)nfft, (int)pad);
+    return status_after_launch();
+}
+
+int advstep_stft_overlap_add_f32(const float *dframes, const float *window, float *dx, int64_t B, int64_t T, int64_t NF,
+                                 int64_t hop, int64_t nfft, advstep_stream_t stream) {
+    LFCC_REQUIRE(B >= 0 && T >= 0 && NF >= 0 && hop >= 1 && nfft >= 4);
+    if (B == 0 || T == 0) return ADVSTEP_OK;
+    const int64_t pad = nfft / 2;
+    LFCC_REQUIRE(dframes && window && dx && B <= kMaxGridY && T > pad && T + nfft <= INT32_MAX);
+    const dim3 grid((unsigned)ceil_div(T, kBlock), (unsigned)B);
+    hipLaunchKernelGGL(stft_overlap_add_kernel, grid, dim3(kBlock), 0, as_stream(stream), dframes, window, dx, (int)T,
+                       (int)NF, (int)hop, (int)nfft, (int)pad);
     return status_after_launch();
 }
 

@@ -99,9 +99,87 @@ class _LfccTail(torch.autograd.Function):
                                                   _stream(dev))
             _lib.check(st, "advstep_lfcc_floor_fixup_f32")
             st = lib.advstep_lfcc_bands_backward_f32(dband.data_ptr(), sr.data_ptr(), fbt_start.data_ptr(),
-                                                     fbt_w.data_ptr(), span_t, dspec.data_ptr(), B, F, M, NF, _stream(dev))
+                                                     fbt_w.data_ptr(), span_t, dspec.data_ptr(), B, F, M, NF, 0,
+                                                     _stream(dev))
             _lib.check(st, "advstep_lfcc_bands_backward_f32")
         return torch.view_as_complex(dspec).transpose(1, 2), None, None, None
+
+
+class _LfccFromWaveform(torch.autograd.Function):
+    """The whole LFCC frontend: framing kernel -> rocFFT r2c -> tail kernels; backward: tail kernels -> rocFFT c2r ->
+    overlap-add kernel.  No padded copy, no strided-frame clone, no index_add."""
+
+    @staticmethod
+    def forward(ctx, x, window, hop, tables: FilterbankTables, dct, top_db: float):
+        B, T = x.shape
+        nfft = window.numel()
+        NF = 1 + T // hop
+        F = nfft // 2 + 1
+        M, K = dct.shape
+        dev = x.device
+        lib = _lib.load()
+        frames = torch.empty((B, NF, nfft), dtype=torch.float32, device=dev)
+        with _Launch("stft_frames", dev):
+            st = lib.advstep_stft_frames_f32(x.data_ptr(), window.data_ptr(), frames.data_ptr(), B, T, NF, hop, nfft,
+                                             _stream(dev))
+        _lib.check(st, "advstep_stft_frames_f32")
+        spec = torch.fft.rfft(frames, dim=-1)              # (B, NF, F) complex64, contiguous
+        del frames
+        sr = torch.view_as_real(spec)
+        band_db = torch.empty((B, NF, M), dtype=torch.float32, device=dev)
+        nblk = lib.advstep_lfcc_block_count(B, M, NF)
+        block_max = torch.empty(max(nblk, 1), dtype=torch.float32, device=dev)
+        stats = torch.empty(4, dtype=torch.float32, device=dev)
+        out = torch.empty((B, NF, K), dtype=torch.float32, device=dev)
+        with _Launch("lfcc_forward", dev):
+            st = lib.advstep_lfcc_bands_f32(sr.data_ptr(), tables.fb_start.data_ptr(), tables.fb_w.data_ptr(), tables.span,
+                                            band_db.data_ptr(), block_max.data_ptr(), B, F, M, NF, _stream(dev))
+            _lib.check(st, "advstep_lfcc_bands_f32")
+            st = lib.advstep_lfcc_reduce_max_f32(block_max.data_ptr(), nblk, stats.data_ptr(), _stream(dev))
+            _lib.check(st, "advstep_lfcc_reduce_max_f32")
+            st = lib.advstep_lfcc_project_f32(band_db.data_ptr(), dct.data_ptr(), stats.data_ptr(), top_db, out.data_ptr(),
+                                              B, M, NF, K, _stream(dev))
+            _lib.check(st, "advstep_lfcc_project_f32")
+        ctx.save_for_backward(sr, band_db, stats, dct, tables.fbt_start, tables.fbt_w, window)
+        ctx.meta = (B, T, F, NF, M, K, tables.span_t, float(top_db), hop, nfft)
+        return out.transpose(1, 2)
+
+    @staticmethod
+    def backward(ctx, gout):
+        sr, band_db, stats, dct, fbt_start, fbt_w, window = ctx.saved_tensors
+        B, T, F, NF, M, K, span_t, top_db, hop, nfft = ctx.meta
+        dev = gout.device
+        go = gout.transpose(1, 2).contiguous()
+        lib = _lib.load()
+        dband = torch.empty((B, NF, M), dtype=torch.float32, device=dev)
+        dspec = torch.empty((B, NF, F, 2), dtype=torch.float32, device=dev)
+        with _Launch("lfcc_backward", dev):
+            st = lib.advstep_lfcc_project_backward_f32(go.data_ptr(), dct.data_ptr(), band_db.data_ptr(), stats.data_ptr(),
+                                                       top_db, dband.data_ptr(), B, M, NF, K, _stream(dev))
+            _lib.check(st, "advstep_lfcc_project_backward_f32")
+            st = lib.advstep_lfcc_floor_fixup_f32(band_db.data_ptr(), stats.data_ptr(), dband.data_ptr(), band_db.numel(),
+                                                  _stream(dev))
+            _lib.check(st, "advstep_lfcc_floor_fixup_f32")
+            st = lib.advstep_lfcc_bands_backward_f32(dband.data_ptr(), sr.data_ptr(), fbt_start.data_ptr(),
+                                                     fbt_w.data_ptr(), span_t, dspec.data_ptr(), B, F, M, NF, 1,
+                                                     _stream(dev))
+            _lib.check(st, "advstep_lfcc_bands_backward_f32")
+        # gradient of the one-sided real FFT = unnormalised c2r inverse of the pre-scaled half spectrum
+        dframes = torch.fft.irfft(torch.view_as_complex(dspec), n=nfft, dim=-1, norm="forward").contiguous()
+        dx = torch.empty((B, T), dtype=torch.float32, device=dev)
+        with _Launch("stft_overlap_add", dev):
+            st = lib.advstep_stft_overlap_add_f32(dframes.data_ptr(), window.data_ptr(), dx.data_ptr(), B, T, NF, hop, nfft,
+                                                  _stream(dev))
+        _lib.check(st, "advstep_stft_overlap_add_f32")
+        return dx, None, None, None, None, None
+
+
+def lfcc_from_waveform(x: torch.Tensor, window_nfft: torch.Tensor, hop: int, tables: FilterbankTables, dct: torch.Tensor,
+                       top_db: float = 80.0) -> torch.Tensor:
+    """Waveform (B, T) -> LFCC (B, K, 1 + T // hop); `window_nfft` is the analysis window zero-padded (centred) to n_fft."""
+    if not x.is_cuda or x.dtype != torch.float32 or x.dim() != 2:
+        raise _lib.AdvstepError("lfcc_from_waveform needs a float32 (B, T) waveform on a HIP device (no CPU fallback)")
+    return _LfccFromWaveform.apply(x.contiguous(), window_nfft, hop, tables, dct, top_db)
 
 
 def lfcc_tail(spec: torch.Tensor, tables: FilterbankTables, dct: torch.Tensor, top_db: float = 80.0) -> torch.Tensor:

@@ -26,6 +26,12 @@ from typing import Callable, List, Union
 import torch
 from torch import nn
 
+def _fused_stft_enabled() -> bool:
+    """ADVSTEP_FUSED_STFT=0 keeps torch.stft (pad + strided frames + clone) in front of the fused LFCC tail."""
+    import os
+    return os.environ.get("ADVSTEP_FUSED_STFT", "1") != "0"
+
+
 def _fused_lfcc_enabled() -> bool:
     """ADVSTEP_FUSED_LFCC=0 keeps the plain torch op chain on the GPU (A/B measurements); default on."""
     import os
@@ -135,6 +141,18 @@ class LFCC(nn.Module):
             self._tables_key, self._tables_val = key, frontend_ops.filterbank_tables(self.filter_mat)
         return self._tables_val
 
+    def _window_nfft(self):
+        """The analysis window zero-padded (centred) to n_fft, as torch.stft applies it; cached."""
+        w = self.Spectrogram.window
+        key = (w.data_ptr(), w._version, str(w.device))
+        if getattr(self, "_wpad_key", None) != key:
+            n_fft = self.Spectrogram.n_fft
+            left = (n_fft - w.numel()) // 2
+            padded = torch.zeros(n_fft, dtype=w.dtype, device=w.device)
+            padded[left:left + w.numel()] = w.detach()
+            self._wpad_key, self._wpad_val = key, padded
+        return self._wpad_val
+
     def forward(self, waveform: torch.Tensor) -> torch.Tensor:
         if (waveform.is_cuda and waveform.dim() == 2 and waveform.dtype == torch.float32 and _fused_lfcc_enabled()
                 and self.dct_mat.shape[0] <= 128 and self.dct_mat.shape[1] in (20, 40, 80)):
@@ -142,6 +160,10 @@ class LFCC(nn.Module):
             # written frame-major for LCNN's first block
             from . import frontend_ops
             sg = self.Spectrogram
+            if waveform.shape[1] > sg.n_fft // 2 and sg.n_fft % 4 == 0 and _fused_stft_enabled():
+                # framing and overlap-add are kernels too; only the batched FFT itself is rocFFT
+                return frontend_ops.lfcc_from_waveform(waveform, self._window_nfft(), sg.hop_length, self._tables(),
+                                                       self.dct_mat, self.top_db)
             spec = torch.stft(waveform, n_fft=sg.n_fft, hop_length=sg.hop_length, win_length=sg.win_length,
                               window=sg.window, center=True, pad_mode="reflect", normalized=False, onesided=True,
                               return_complex=True)

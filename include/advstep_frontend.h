@@ -58,10 +58,23 @@ int advstep_lfcc_project_backward_f32(const float *dout, const float *dct, const
 int advstep_lfcc_floor_fixup_f32(const float *band_db, const float *stats, float *dband, int64_t n,
                                  advstep_stream_t stream);
 
-/* dspec[b, t, f] = 2 * spec[b, t, f] * sum_j fbt_w[f, j] * dband[b, t, fbt_start[f] + j]  (complex, as float pairs). */
+/* dspec[b, t, f] = 2 * spec[b, t, f] * sum_j fbt_w[f, j] * dband[b, t, fbt_start[f] + j]  (complex, as float pairs).
+ * hermitian_half != 0 pre-scales it for a c2r inverse FFT (interior bins * 1/2, DC / Nyquist imaginary parts 0):
+ * the gradient of a one-sided real FFT is then irfft(dspec, norm="forward"). */
 int advstep_lfcc_bands_backward_f32(const float *dband, const float *spec, const int32_t *fbt_start, const float *fbt_w,
                                     int64_t span_t, float *dspec, int64_t B, int64_t F, int64_t M, int64_t NF,
-                                    advstep_stream_t stream);
+                                    int hermitian_half, advstep_stream_t stream);
+
+/* STFT framing of torch.stft(center=True, pad_mode="reflect") without the padded copy and the strided-frame clone:
+ * frames[b, f, n] = window[n] * x[b, reflect(f*hop + n - nfft/2)], window (nfft) already centred/zero-padded.
+ * frames (B, NF, nfft) is what a batched r2c FFT consumes; requires T > nfft/2. */
+int advstep_stft_frames_f32(const float *x, const float *window, float *frames, int64_t B, int64_t T, int64_t NF,
+                            int64_t hop, int64_t nfft, advstep_stream_t stream);
+
+/* Transpose of the framing (the backward of the line above): windowed overlap-add with the reflected borders folded
+ * back, as a gather (no atomics, deterministic): dx (B, T) from dframes (B, NF, nfft). */
+int advstep_stft_overlap_add_f32(const float *dframes, const float *window, float *dx, int64_t B, int64_t T, int64_t NF,
+                                 int64_t hop, int64_t nfft, advstep_stream_t stream);
 
 #ifdef __cplusplus
 }

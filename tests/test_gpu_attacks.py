@@ -195,3 +195,47 @@ def test_evaluation_loop_end_to_end(cuda):
                              batch_size=8, dataset=SyntheticDetectionDataset(20))
     # a white-box attack cannot make the (same-seed) detector MORE accurate than on clean data
     assert rep["adv_eval/accuracy"] <= clean["adv_eval/accuracy"] + 1e-9
+
+
+# ---- BASELINE.json configs[2] and configs[3]: the other two detectors ---------------------------------------------------------
+
+def test_pgdl2_on_specrnet_mel_every_launch_checked(cuda, checked):
+    """configs[2]: SpecRNet + mel-spectrogram frontend (2 channels), PGDL2 (reduced to 3 steps / 4 utterances)."""
+    from audio_deepfake_adversarial_attacks_amd import torchattacks
+    from audio_deepfake_adversarial_attacks_amd.datasets.synthetic import synthetic_waveforms
+    from audio_deepfake_adversarial_attacks_amd.models.models import get_model
+    torch.manual_seed(0)
+    model = get_model("specrnet", {"frontend_algorithm": ["mel_spec"], "input_channels": 2}, str(cuda)).to(cuda).eval()
+    x, y = synthetic_waveforms(4, seed=21)
+    x, y = x.to(cuda), y.to(cuda)
+    ops = checked()
+    x01, mn, mx = ops.to_minmax(x)
+    atk = armed(torchattacks.PGDL2, model, ops, eps=0.1, steps=3)
+    adv01 = atk(x01, y)
+    adv = ops.revert_minmax(adv01, mn, mx)
+    assert ((adv01 - x01).norm(dim=1) <= 0.1 * (1 + 1e-4)).all() and adv01.min() >= 0 and adv01.max() <= 1
+    assert torch.isfinite(adv).all() and ops.calls["pgd_l2_step"] == 3 and ops.calls["pgd_l2_init"] == 1
+    assert ((adv01 - x01).abs() > 0).float().mean().item() > 0.9
+
+
+def test_fgsm_and_cw_transfer_rawnet3_to_lcnn(cuda, checked, lcnn_model):
+    """configs[3]: attack model RawNet3 (raw waveform), target LCNN + LFCC (transferability, reference README:115-118);
+    FGSM then CW, reduced to 2 utterances / 3 CW steps."""
+    from audio_deepfake_adversarial_attacks_amd import torchattacks
+    from audio_deepfake_adversarial_attacks_amd.datasets.synthetic import synthetic_waveforms
+    from audio_deepfake_adversarial_attacks_amd.evaluation import score_batch
+    from audio_deepfake_adversarial_attacks_amd.models.models import get_model
+    torch.manual_seed(0)
+    raw = get_model("rawnet3", {}, str(cuda)).to(cuda).eval()
+    x, y = synthetic_waveforms(2, seed=31)
+    x, y = x.to(cuda), y.to(cuda)
+    ops = checked()
+    x01, mn, mx = ops.to_minmax(x)
+    adv_fgsm = armed(torchattacks.FGSM, raw, ops, eps=0.001)(x01, y)
+    assert (adv_fgsm - x01).abs().max().item() <= 0.001 + 1e-7
+    adv_cw = armed(torchattacks.CW, raw, ops, c=1.0, steps=3, lr=0.01)(x01, y)
+    assert adv_cw.shape == x01.shape and adv_cw.min() >= 0 and adv_cw.max() <= 1
+    for adv01 in (adv_fgsm, adv_cw):
+        preds, labels = score_batch(lcnn_model.eval(), ops.revert_minmax(adv01, mn, mx))
+        assert torch.isfinite(preds).all() and set(labels.tolist()) <= {0, 1}
+    assert ops.calls["cw_adam_step"] >= 1 and ops.calls["fgsm_step"] == 1
