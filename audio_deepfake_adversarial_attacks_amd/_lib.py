@@ -36,16 +36,16 @@ SIGNATURES = {
     "advstep_ce2_loss_grad_f32": (ctypes.c_int, [_p, _p, _p, _p, _i64, _f32, _p]),
     # include/advstep_lcnn.h
     "advstep_mfm_sel_bytes": (_sz, [_i64, _i64, _i64]),
-    "advstep_mfm_forward_f32": (ctypes.c_int, [_p, _p, _p, _p, _i64, _i64, _i64, _p]),
-    "advstep_mfm_backward_f32": (ctypes.c_int, [_p, _p, _p, _i64, _i64, _i64, _p]),
-    "advstep_mfm_pool2_forward_f32": (ctypes.c_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _p]),
-    "advstep_mfm_pool2_backward_f32": (ctypes.c_int, [_p, _p, _p, _i64, _i64, _i64, _i64, _p]),
+    "advstep_mfm_forward_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _p]),
+    "advstep_mfm_backward_f32": (ctypes.c_int, [_p, _p, _p, _p, _i64, _i64, _i64, _p]),
+    "advstep_mfm_pool2_forward_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p]),
+    "advstep_mfm_pool2_backward_f32": (ctypes.c_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _p]),
     "advstep_conv5_mfm_pool2_forward_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p]),
     "advstep_conv5_mfm_pool2_backward_f32": (ctypes.c_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _p]),
     "advstep_conv1x1_mfm_supported": (ctypes.c_int, [_i64]),
     "advstep_conv1x1_mfm_sel_bytes": (_sz, [_i64, _i64, _i64]),
-    "advstep_conv1x1_mfm_forward_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p]),
-    "advstep_conv1x1_mfm_backward_f32": (ctypes.c_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _p]),
+    "advstep_conv1x1_mfm_forward_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p]),
+    "advstep_conv1x1_mfm_backward_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p]),
     "advstep_lstm_supported": (ctypes.c_int, [_i64]),
     "advstep_lstm_forward_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p]),
     "advstep_lstm_backward_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p]),

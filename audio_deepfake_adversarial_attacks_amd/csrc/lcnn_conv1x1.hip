@@ -29,12 +29,18 @@ inline int status_after_launch() { return hipGetLastError() == hipSuccess ? ADVS
 
 __device__ __forceinline__ bool mfm_takes_b(float a, float b) { return !(a != a) && !(a >= b); }
 
+// grid (ceil(P / 256), N, Z): blockIdx.z owns the channel pairs [z * cper, (z + 1) * cper) — small feature maps
+// (P = 500 in LCNN's last blocks) would otherwise run one wave per SIMD with nothing to hide the scalar weight loads.
+// bn_mean / bn_invstd (C, nullable): the eval-mode BatchNorm2d(affine=False) that follows every 1x1 block in LCNN,
+// y = (max - mean[c]) * invstd[c], applied in the epilogue.
 template <int CIN>
 __global__ __launch_bounds__(kBlock) void conv1x1_mfm_forward_kernel(const float *__restrict__ x,
                                                                      const float *__restrict__ weight,
                                                                      const float *__restrict__ bias,
+                                                                     const float *__restrict__ bn_mean,
+                                                                     const float *__restrict__ bn_invstd,
                                                                      float *__restrict__ y,
-                                                                     unsigned long long *__restrict__ sel, int C,
+                                                                     unsigned long long *__restrict__ sel, int C, int cper,
                                                                      int64_t P, int64_t PW) {
     const int64_t n = blockIdx.y;
     const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -46,7 +52,9 @@ __global__ __launch_bounds__(kBlock) void conv1x1_mfm_forward_kernel(const float
 
     float *yn = y + n * (int64_t)C * P + p;
     unsigned long long *sn = sel + n * (int64_t)C * PW + (p >> 6);
-    for (int c = 0; c < C; ++c) {
+    const int c_begin = blockIdx.z * cper;
+    const int c_end = c_begin + cper < C ? c_begin + cper : C;
+    for (int c = c_begin; c < c_end; ++c) {
         const float *wa = weight + (int64_t)c * CIN;  // wave-uniform: scalar loads
         const float *wb = weight + (int64_t)(c + C) * CIN;
         float a = 0.0f, b = 0.0f;
@@ -61,60 +69,82 @@ __global__ __launch_bounds__(kBlock) void conv1x1_mfm_forward_kernel(const float
         }
         const bool tb = mfm_takes_b(a, b);
         const unsigned long long word = __ballot(valid && tb);
+        float v = tb ? b : a;
+        if (bn_mean) v = (v - bn_mean[c]) * bn_invstd[c];
         if (valid) {
-            yn[(int64_t)c * P] = tb ? b : a;
+            yn[(int64_t)c * P] = v;
             if ((threadIdx.x & 63) == 0) sn[(int64_t)c * PW] = word;
         }
     }
 }
 
-template <int CIN>
+// grid (ceil(P / 256), N, CIN / CHUNK): blockIdx.z owns input channels [z * CHUNK, (z + 1) * CHUNK).
+// gscale (C, nullable): the following BatchNorm's backward, gy * invstd[c].
+template <int CIN, int CHUNK>
 __global__ __launch_bounds__(kBlock) void conv1x1_mfm_backward_kernel(const float *__restrict__ gy,
                                                                       const unsigned long long *__restrict__ sel,
                                                                       const float *__restrict__ weight,
+                                                                      const float *__restrict__ gscale,
                                                                       float *__restrict__ gx, int C, int64_t P,
                                                                       int64_t PW) {
     const int64_t n = blockIdx.y;
     const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (p >= P) return;
+    const int ci0 = blockIdx.z * CHUNK;
     const float *gn = gy + n * (int64_t)C * P + p;
     const unsigned long long *sn = sel + n * (int64_t)C * PW + (p >> 6);
     const int lane = threadIdx.x & 63;
-    float acc[CIN];
+    float acc[CHUNK];
 #pragma unroll
-    for (int ci = 0; ci < CIN; ++ci) acc[ci] = 0.0f;
+    for (int k = 0; k < CHUNK; ++k) acc[k] = 0.0f;
     for (int c = 0; c < C; ++c) {
-        const float g = gn[(int64_t)c * P];
+        float g = gn[(int64_t)c * P];
+        if (gscale) g *= gscale[c];
         const bool tb = (sn[(int64_t)c * PW] >> lane) & 1ull;
         const float ga = tb ? 0.0f : g, gb = tb ? g : 0.0f;
-        const float *wa = weight + (int64_t)c * CIN;
-        const float *wb = weight + (int64_t)(c + C) * CIN;
+        const float *wa = weight + (int64_t)c * CIN + ci0;
+        const float *wb = weight + (int64_t)(c + C) * CIN + ci0;
 #pragma unroll
-        for (int ci = 0; ci < CIN; ++ci) {
-            acc[ci] = fmaf(ga, wa[ci], acc[ci]);
-            acc[ci] = fmaf(gb, wb[ci], acc[ci]);
+        for (int k = 0; k < CHUNK; ++k) {
+            acc[k] = fmaf(ga, wa[k], acc[k]);
+            acc[k] = fmaf(gb, wb[k], acc[k]);
         }
     }
-    float *xn = gx + n * CIN * P + p;
+    float *xn = gx + n * CIN * P + (int64_t)ci0 * P + p;
 #pragma unroll
-    for (int ci = 0; ci < CIN; ++ci) xn[(int64_t)ci * P] = acc[ci];
+    for (int k = 0; k < CHUNK; ++k) xn[(int64_t)k * P] = acc[k];
 }
 
 constexpr int64_t kMaxGridY = 65535;
+constexpr int64_t kWantBlocks = 2048;  // ~8 workgroups per CU keep the scalar-load latency covered
 
 template <int CIN>
-void launch_fwd(const float *x, const float *w, const float *b, float *y, unsigned long long *sel, int64_t N, int64_t C,
-                int64_t P, hipStream_t st) {
-    const dim3 grid((unsigned)ceil_div(P, kBlock), (unsigned)N);
-    hipLaunchKernelGGL(conv1x1_mfm_forward_kernel<CIN>, grid, dim3(kBlock), 0, st, x, w, b, y, sel, (int)C, P,
-                       ceil_div(P, 64));
+void launch_fwd(const float *x, const float *w, const float *b, const float *bn_mean, const float *bn_invstd, float *y,
+                unsigned long long *sel, int64_t N, int64_t C, int64_t P, hipStream_t st) {
+    const int64_t blocks = ceil_div(P, kBlock) * N;
+    int64_t z = blocks >= kWantBlocks ? 1 : ceil_div(kWantBlocks, blocks);
+    if (z > 8) z = 8;
+    if (z > C) z = C;
+    const int64_t cper = ceil_div(C, z);
+    z = ceil_div(C, cper);
+    const dim3 grid((unsigned)ceil_div(P, kBlock), (unsigned)N, (unsigned)z);
+    hipLaunchKernelGGL(conv1x1_mfm_forward_kernel<CIN>, grid, dim3(kBlock), 0, st, x, w, b, bn_mean, bn_invstd, y, sel,
+                       (int)C, (int)cper, P, ceil_div(P, 64));
 }
-template <int CIN>
-void launch_bwd(const float *gy, const unsigned long long *sel, const float *w, float *gx, int64_t N, int64_t C,
-                int64_t P, hipStream_t st) {
-    const dim3 grid((unsigned)ceil_div(P, kBlock), (unsigned)N);
-    hipLaunchKernelGGL(conv1x1_mfm_backward_kernel<CIN>, grid, dim3(kBlock), 0, st, gy, sel, w, gx, (int)C, P,
-                       ceil_div(P, 64));
+template <int CIN, int CHUNK>
+void launch_bwd_chunk(const float *gy, const unsigned long long *sel, const float *w, const float *gscale, float *gx,
+                      int64_t N, int64_t C, int64_t P, hipStream_t st) {
+    const dim3 grid((unsigned)ceil_div(P, kBlock), (unsigned)N, (unsigned)(CIN / CHUNK));
+    hipLaunchKernelGGL((conv1x1_mfm_backward_kernel<CIN, CHUNK>), grid, dim3(kBlock), 0, st, gy, sel, w, gscale, gx,
+                       (int)C, P, ceil_div(P, 64));
+}
+template <int CIN, int SMALL>
+void launch_bwd(const float *gy, const unsigned long long *sel, const float *w, const float *gscale, float *gx, int64_t N,
+                int64_t C, int64_t P, hipStream_t st) {
+    if (ceil_div(P, kBlock) * N >= kWantBlocks)
+        launch_bwd_chunk<CIN, CIN>(gy, sel, w, gscale, gx, N, C, P, st);
+    else
+        launch_bwd_chunk<CIN, SMALL>(gy, sel, w, gscale, gx, N, C, P, st);
 }
 
 }  // namespace
@@ -133,23 +163,25 @@ size_t advstep_conv1x1_mfm_sel_bytes(int64_t N, int64_t C, int64_t P) {
     return (size_t)N * (size_t)C * (size_t)ceil_div(P, 64) * sizeof(unsigned long long);
 }
 
-int advstep_conv1x1_mfm_forward_f32(const float *x, const float *weight, const float *bias, float *y, uint64_t *sel,
-                                    int64_t N, int64_t Cin, int64_t C, int64_t P, advstep_stream_t stream) {
+int advstep_conv1x1_mfm_forward_f32(const float *x, const float *weight, const float *bias, const float *bn_mean,
+                                    const float *bn_invstd, float *y, uint64_t *sel, int64_t N, int64_t Cin, int64_t C,
+                                    int64_t P, advstep_stream_t stream) {
     C11_REQUIRE(N >= 0 && C >= 0 && P >= 0 && advstep_conv1x1_mfm_supported(Cin));
     if (N == 0 || C == 0 || P == 0) return ADVSTEP_OK;
     C11_REQUIRE(x && weight && y && sel && N <= kMaxGridY && C <= INT32_MAX && ((reinterpret_cast<uintptr_t>(sel) & 7u) == 0));
+    C11_REQUIRE((bn_mean == nullptr) == (bn_invstd == nullptr));
     auto *s64 = reinterpret_cast<unsigned long long *>(sel);
     hipStream_t st = as_stream(stream);
     switch (Cin) {
-        case 32: launch_fwd<32>(x, weight, bias, y, s64, N, C, P, st); break;
-        case 48: launch_fwd<48>(x, weight, bias, y, s64, N, C, P, st); break;
-        default: launch_fwd<64>(x, weight, bias, y, s64, N, C, P, st); break;
+        case 32: launch_fwd<32>(x, weight, bias, bn_mean, bn_invstd, y, s64, N, C, P, st); break;
+        case 48: launch_fwd<48>(x, weight, bias, bn_mean, bn_invstd, y, s64, N, C, P, st); break;
+        default: launch_fwd<64>(x, weight, bias, bn_mean, bn_invstd, y, s64, N, C, P, st); break;
     }
     return status_after_launch();
 }
 
-int advstep_conv1x1_mfm_backward_f32(const float *gy, const uint64_t *sel, const float *weight, float *gx, int64_t N,
-                                     int64_t Cin, int64_t C, int64_t P, advstep_stream_t stream) {
+int advstep_conv1x1_mfm_backward_f32(const float *gy, const uint64_t *sel, const float *weight, const float *gscale,
+                                     float *gx, int64_t N, int64_t Cin, int64_t C, int64_t P, advstep_stream_t stream) {
     C11_REQUIRE(N >= 0 && C >= 0 && P >= 0 && advstep_conv1x1_mfm_supported(Cin));
     if (N == 0 || P == 0) return ADVSTEP_OK;
     C11_REQUIRE(gx && N <= kMaxGridY && C <= INT32_MAX);
@@ -159,9 +191,9 @@ int advstep_conv1x1_mfm_backward_f32(const float *gy, const uint64_t *sel, const
     C11_REQUIRE(gy && sel && weight);
     auto *s64 = reinterpret_cast<const unsigned long long *>(sel);
     switch (Cin) {
-        case 32: launch_bwd<32>(gy, s64, weight, gx, N, C, P, st); break;
-        case 48: launch_bwd<48>(gy, s64, weight, gx, N, C, P, st); break;
-        default: launch_bwd<64>(gy, s64, weight, gx, N, C, P, st); break;
+        case 32: launch_bwd<32, 8>(gy, s64, weight, gscale, gx, N, C, P, st); break;
+        case 48: launch_bwd<48, 12>(gy, s64, weight, gscale, gx, N, C, P, st); break;
+        default: launch_bwd<64, 16>(gy, s64, weight, gscale, gx, N, C, P, st); break;
     }
     return status_after_launch();
 }

@@ -41,7 +41,9 @@ __device__ __forceinline__ bool mfm_takes_b(float a, float b) { return !(a != a)
 // evaluate_... conv -> add_(bias) -> max, folded into this pass; one rounding, like ATen's separate add kernel).
 template <bool VEC>
 __global__ __launch_bounds__(kBlock) void mfm_forward_kernel(const float *__restrict__ x,
-                                                             const float *__restrict__ bias, float *__restrict__ y,
+                                                             const float *__restrict__ bias,
+                                                             const float *__restrict__ bn_mean,
+                                                             const float *__restrict__ bn_invstd, float *__restrict__ y,
                                                              uint8_t *__restrict__ sel, int64_t P, int64_t G,
                                                              int64_t HW, int64_t C) {
     const int64_t n = blockIdx.y;
@@ -103,6 +105,15 @@ __global__ __launch_bounds__(kBlock) void mfm_forward_kernel(const float *__rest
             o.y = t1 ? b[k].y : a[k].y;
             o.z = t2 ? b[k].z : a[k].z;
             o.w = t3 ? b[k].w : a[k].w;
+            if (bn_mean) {  // eval-mode BatchNorm2d(affine=False) that follows: (v - mean[c]) * invstd[c]
+                const int64_t i = g * 4;
+                const int64_t c0 = i / HW, c1 = (i + 1 < P ? i + 1 : P - 1) / HW, c2 = (i + 2 < P ? i + 2 : P - 1) / HW,
+                              c3 = (i + 3 < P ? i + 3 : P - 1) / HW;
+                o.x = (o.x - bn_mean[c0]) * bn_invstd[c0];
+                o.y = (o.y - bn_mean[c1]) * bn_invstd[c1];
+                o.z = (o.z - bn_mean[c2]) * bn_invstd[c2];
+                o.w = (o.w - bn_mean[c3]) * bn_invstd[c3];
+            }
             if (VEC) {
                 reinterpret_cast<float4 *>(yo)[g] = o;
             } else {
@@ -119,8 +130,9 @@ __global__ __launch_bounds__(kBlock) void mfm_forward_kernel(const float *__rest
 
 template <bool VEC>
 __global__ __launch_bounds__(kBlock) void mfm_backward_kernel(const float *__restrict__ gy,
-                                                              const uint8_t *__restrict__ sel, float *__restrict__ gx,
-                                                              int64_t P, int64_t G) {
+                                                              const uint8_t *__restrict__ sel,
+                                                              const float *__restrict__ gscale, float *__restrict__ gx,
+                                                              int64_t P, int64_t G, int64_t HW) {
     const int64_t n = blockIdx.y;
     const float *go = gy + n * P;
     const uint8_t *so = sel + n * G;
@@ -142,6 +154,13 @@ __global__ __launch_bounds__(kBlock) void mfm_backward_kernel(const float *__res
                 v[k].y = (i + 1 < P) ? go[i + 1] : 0.0f;
                 v[k].z = (i + 2 < P) ? go[i + 2] : 0.0f;
                 v[k].w = (i + 3 < P) ? go[i + 3] : 0.0f;
+            }
+            if (gscale) {  // backward of the BatchNorm that followed: gy * invstd[c]
+                const int64_t i = g * 4;
+                v[k].x *= gscale[i / HW];
+                v[k].y *= gscale[(i + 1 < P ? i + 1 : P - 1) / HW];
+                v[k].z *= gscale[(i + 2 < P ? i + 2 : P - 1) / HW];
+                v[k].w *= gscale[(i + 3 < P ? i + 3 : P - 1) / HW];
             }
         }
     }
@@ -192,6 +211,8 @@ __device__ __forceinline__ float pool_select(float a00, float b00, float a01, fl
 // VEC path (W % 4 == 0, 16-byte aligned planes): thread = (c, ho, wq) -> two pooled outputs from four float4 loads.
 __global__ __launch_bounds__(kBlock) void mfm_pool2_forward_vec_kernel(const float *__restrict__ x,
                                                                        const float *__restrict__ bias,
+                                                                       const float *__restrict__ bn_mean,
+                                                                       const float *__restrict__ bn_invstd,
                                                                        float *__restrict__ y,
                                                                        uint8_t *__restrict__ idx, int C, int H, int W) {
     const int Ho = H >> 1, W4 = W >> 2, Wo = W >> 1;
@@ -222,6 +243,11 @@ __global__ __launch_bounds__(kBlock) void mfm_pool2_forward_vec_kernel(const flo
         float2 o;
         o.x = pool_select(a0.x, b0.x, a0.y, b0.y, a1.x, b1.x, a1.y, b1.y, c0);
         o.y = pool_select(a0.z, b0.z, a0.w, b0.w, a1.z, b1.z, a1.w, b1.w, c1);
+        if (bn_mean) {
+            const float mu = bn_mean[c], is = bn_invstd[c];
+            o.x = (o.x - mu) * is;
+            o.y = (o.y - mu) * is;
+        }
         reinterpret_cast<float2 *>(yn)[i] = o;              // (c, ho, 2wq..2wq+1) is item i of the flattened output pairs
         reinterpret_cast<uchar2 *>(in)[i] = make_uchar2((unsigned char)c0, (unsigned char)c1);
     }
@@ -230,6 +256,8 @@ __global__ __launch_bounds__(kBlock) void mfm_pool2_forward_vec_kernel(const flo
 // generic path: thread = one pooled output
 __global__ __launch_bounds__(kBlock) void mfm_pool2_forward_scalar_kernel(const float *__restrict__ x,
                                                                           const float *__restrict__ bias,
+                                                                          const float *__restrict__ bn_mean,
+                                                                          const float *__restrict__ bn_invstd,
                                                                           float *__restrict__ y,
                                                                           uint8_t *__restrict__ idx, int C, int H, int W) {
     const int Ho = H >> 1, Wo = W >> 1;
@@ -246,11 +274,14 @@ __global__ __launch_bounds__(kBlock) void mfm_pool2_forward_scalar_kernel(const 
     const float *pb = pa + (int64_t)C * plane;
     int code;
     const float ba = bias ? bias[c] : 0.0f, bb = bias ? bias[c + C] : 0.0f;
+    float v;
     if (bias)
-        y[n * items + i] = pool_select(pa[0] + ba, pb[0] + bb, pa[1] + ba, pb[1] + bb, pa[W] + ba, pb[W] + bb,
-                                       pa[W + 1] + ba, pb[W + 1] + bb, code);
+        v = pool_select(pa[0] + ba, pb[0] + bb, pa[1] + ba, pb[1] + bb, pa[W] + ba, pb[W] + bb, pa[W + 1] + ba,
+                        pb[W + 1] + bb, code);
     else
-        y[n * items + i] = pool_select(pa[0], pb[0], pa[1], pb[1], pa[W], pb[W], pa[W + 1], pb[W + 1], code);
+        v = pool_select(pa[0], pb[0], pa[1], pb[1], pa[W], pb[W], pa[W + 1], pb[W + 1], code);
+    if (bn_mean) v = (v - bn_mean[c]) * bn_invstd[c];
+    y[n * items + i] = v;
     idx[n * items + i] = (uint8_t)code;
 }
 
@@ -258,6 +289,7 @@ __global__ __launch_bounds__(kBlock) void mfm_pool2_forward_scalar_kernel(const 
 // When H is odd, the threads of the last pooled row also zero the trailing input row.
 __global__ __launch_bounds__(kBlock) void mfm_pool2_backward_vec_kernel(const float *__restrict__ gy,
                                                                         const uint8_t *__restrict__ idx,
+                                                                        const float *__restrict__ gscale,
                                                                         float *__restrict__ gx, int C, int H, int W) {
     const int Ho = H >> 1, W4 = W >> 2, Wo = W >> 1;
     const int64_t n = blockIdx.y;
@@ -275,7 +307,11 @@ __global__ __launch_bounds__(kBlock) void mfm_pool2_backward_vec_kernel(const fl
         const int64_t t = i / W4;
         const int ho = (int)(t % Ho);
         const int c = (int)(t / Ho);
-        const float2 g = reinterpret_cast<const float2 *>(gn)[i];
+        float2 g = reinterpret_cast<const float2 *>(gn)[i];
+        if (gscale) {
+            g.x *= gscale[c];
+            g.y *= gscale[c];
+        }
         const uchar2 code = reinterpret_cast<const uchar2 *>(in)[i];
         // window of output 0 = columns 0-1, of output 1 = columns 2-3; rows dh = 0, 1; halves a / b
         const int p0 = code.x & 3, p1 = code.y & 3;
@@ -304,6 +340,7 @@ __global__ __launch_bounds__(kBlock) void mfm_pool2_backward_vec_kernel(const fl
 // generic backward: gx was zero-filled by the host side; thread = one pooled output scatters its gradient
 __global__ __launch_bounds__(kBlock) void mfm_pool2_backward_scalar_kernel(const float *__restrict__ gy,
                                                                            const uint8_t *__restrict__ idx,
+                                                                           const float *__restrict__ gscale,
                                                                            float *__restrict__ gx, int C, int H, int W) {
     const int Ho = H >> 1, Wo = W >> 1;
     const int64_t n = blockIdx.y;
@@ -318,7 +355,7 @@ __global__ __launch_bounds__(kBlock) void mfm_pool2_backward_scalar_kernel(const
     const int code = idx[n * items + i];
     const int64_t half = (code & 4) ? (int64_t)C * plane : 0;
     gx[n * 2 * C * plane + half + c * plane + (int64_t)(2 * ho + ((code >> 1) & 1)) * W + 2 * wo + (code & 1)] =
-        gy[n * items + i];
+        gscale ? gy[n * items + i] * gscale[c] : gy[n * items + i];
 }
 
 constexpr int64_t kMaxGridY = 65535;
@@ -337,36 +374,37 @@ size_t advstep_mfm_sel_bytes(int64_t N, int64_t C, int64_t HW) {
     return (size_t)N * (size_t)ceil_div(C * HW, 4);
 }
 
-int advstep_mfm_forward_f32(const float *x, const float *bias, float *y, uint8_t *sel, int64_t N, int64_t C,
-                            int64_t HW, advstep_stream_t stream) {
+int advstep_mfm_forward_f32(const float *x, const float *bias, const float *bn_mean, const float *bn_invstd, float *y,
+                            uint8_t *sel, int64_t N, int64_t C, int64_t HW, advstep_stream_t stream) {
     LCNN_REQUIRE(N >= 0 && C >= 0 && HW >= 0);
     if (N == 0 || C == 0 || HW == 0) return ADVSTEP_OK;
     LCNN_REQUIRE(x && y && sel && N <= kMaxGridY);
     const int64_t P = C * HW, G = ceil_div(P, 4);
     const dim3 grid((unsigned)ceil_div(G, kBlock * kGroupsPerThread), (unsigned)N);
     if (P % 4 == 0 && aligned16(x) && aligned16(y))
-        hipLaunchKernelGGL(mfm_forward_kernel<true>, grid, dim3(kBlock), 0, as_stream(stream), x, bias, y, sel, P, G, HW, C);
+        hipLaunchKernelGGL(mfm_forward_kernel<true>, grid, dim3(kBlock), 0, as_stream(stream), x, bias, bn_mean, bn_invstd, y, sel, P, G, HW, C);
     else
-        hipLaunchKernelGGL(mfm_forward_kernel<false>, grid, dim3(kBlock), 0, as_stream(stream), x, bias, y, sel, P, G, HW, C);
+        hipLaunchKernelGGL(mfm_forward_kernel<false>, grid, dim3(kBlock), 0, as_stream(stream), x, bias, bn_mean, bn_invstd, y, sel, P, G, HW, C);
     return status_after_launch();
 }
 
-int advstep_mfm_backward_f32(const float *gy, const uint8_t *sel, float *gx, int64_t N, int64_t C, int64_t HW,
-                             advstep_stream_t stream) {
+int advstep_mfm_backward_f32(const float *gy, const uint8_t *sel, const float *gscale, float *gx, int64_t N, int64_t C,
+                             int64_t HW, advstep_stream_t stream) {
     LCNN_REQUIRE(N >= 0 && C >= 0 && HW >= 0);
     if (N == 0 || C == 0 || HW == 0) return ADVSTEP_OK;
     LCNN_REQUIRE(gy && sel && gx && N <= kMaxGridY);
     const int64_t P = C * HW, G = ceil_div(P, 4);
     const dim3 grid((unsigned)ceil_div(G, kBlock * kGroupsPerThread), (unsigned)N);
     if (P % 4 == 0 && aligned16(gy) && aligned16(gx))
-        hipLaunchKernelGGL(mfm_backward_kernel<true>, grid, dim3(kBlock), 0, as_stream(stream), gy, sel, gx, P, G);
+        hipLaunchKernelGGL(mfm_backward_kernel<true>, grid, dim3(kBlock), 0, as_stream(stream), gy, sel, gscale, gx, P, G, HW);
     else
-        hipLaunchKernelGGL(mfm_backward_kernel<false>, grid, dim3(kBlock), 0, as_stream(stream), gy, sel, gx, P, G);
+        hipLaunchKernelGGL(mfm_backward_kernel<false>, grid, dim3(kBlock), 0, as_stream(stream), gy, sel, gscale, gx, P, G, HW);
     return status_after_launch();
 }
 
-int advstep_mfm_pool2_forward_f32(const float *x, const float *bias, float *y, uint8_t *idx, int64_t N, int64_t C,
-                                  int64_t H, int64_t W, advstep_stream_t stream) {
+int advstep_mfm_pool2_forward_f32(const float *x, const float *bias, const float *bn_mean, const float *bn_invstd,
+                                  float *y, uint8_t *idx, int64_t N, int64_t C, int64_t H, int64_t W,
+                                  advstep_stream_t stream) {
     LCNN_REQUIRE(N >= 0 && C >= 0 && H >= 0 && W >= 0);
     const int64_t Ho = H / 2, Wo = W / 2;
     if (N == 0 || C == 0 || Ho == 0 || Wo == 0) return ADVSTEP_OK;
@@ -376,16 +414,16 @@ int advstep_mfm_pool2_forward_f32(const float *x, const float *bias, float *y, u
         ((reinterpret_cast<uintptr_t>(idx) & 1u) == 0)) {
         const int64_t items = C * Ho * (W / 4);
         const dim3 grid((unsigned)ceil_div(items, 2 * kBlock), (unsigned)N);
-        hipLaunchKernelGGL(mfm_pool2_forward_vec_kernel, grid, dim3(kBlock), 0, st, x, bias, y, idx, (int)C, (int)H, (int)W);
+        hipLaunchKernelGGL(mfm_pool2_forward_vec_kernel, grid, dim3(kBlock), 0, st, x, bias, bn_mean, bn_invstd, y, idx, (int)C, (int)H, (int)W);
     } else {
         const dim3 grid((unsigned)ceil_div(C * Ho * Wo, kBlock), (unsigned)N);
-        hipLaunchKernelGGL(mfm_pool2_forward_scalar_kernel, grid, dim3(kBlock), 0, st, x, bias, y, idx, (int)C, (int)H, (int)W);
+        hipLaunchKernelGGL(mfm_pool2_forward_scalar_kernel, grid, dim3(kBlock), 0, st, x, bias, bn_mean, bn_invstd, y, idx, (int)C, (int)H, (int)W);
     }
     return status_after_launch();
 }
 
-int advstep_mfm_pool2_backward_f32(const float *gy, const uint8_t *idx, float *gx, int64_t N, int64_t C, int64_t H,
-                                   int64_t W, advstep_stream_t stream) {
+int advstep_mfm_pool2_backward_f32(const float *gy, const uint8_t *idx, const float *gscale, float *gx, int64_t N,
+                                   int64_t C, int64_t H, int64_t W, advstep_stream_t stream) {
     LCNN_REQUIRE(N >= 0 && C >= 0 && H >= 0 && W >= 0);
     if (N == 0 || C == 0 || H == 0 || W == 0) return ADVSTEP_OK;
     LCNN_REQUIRE(gx && N <= kMaxGridY && C <= INT32_MAX && H <= INT32_MAX && W <= INT32_MAX);
@@ -400,11 +438,11 @@ int advstep_mfm_pool2_backward_f32(const float *gy, const uint8_t *idx, float *g
         ((reinterpret_cast<uintptr_t>(idx) & 1u) == 0)) {
         const int64_t items = C * Ho * (W / 4);
         const dim3 grid((unsigned)ceil_div(items, 2 * kBlock), (unsigned)N);
-        hipLaunchKernelGGL(mfm_pool2_backward_vec_kernel, grid, dim3(kBlock), 0, st, gy, idx, gx, (int)C, (int)H, (int)W);
+        hipLaunchKernelGGL(mfm_pool2_backward_vec_kernel, grid, dim3(kBlock), 0, st, gy, idx, gscale, gx, (int)C, (int)H, (int)W);
     } else {
         if (hipMemsetAsync(gx, 0, (size_t)N * 2 * C * H * W * sizeof(float), st) != hipSuccess) return ADVSTEP_ELAUNCH;
         const dim3 grid((unsigned)ceil_div(C * Ho * Wo, kBlock), (unsigned)N);
-        hipLaunchKernelGGL(mfm_pool2_backward_scalar_kernel, grid, dim3(kBlock), 0, st, gy, idx, gx, (int)C, (int)H, (int)W);
+        hipLaunchKernelGGL(mfm_pool2_backward_scalar_kernel, grid, dim3(kBlock), 0, st, gy, idx, gscale, gx, (int)C, (int)H, (int)W);
     }
     return status_after_launch();
 }

@@ -31,65 +31,78 @@ def _bias_grad(gx: torch.Tensor, needed: bool):
     return gx.sum(dim=(0, 2, 3)) if needed else None
 
 
+def _bn_ptrs(bn):
+    """bn = (mean (C), invstd (C)) of an eval-mode BatchNorm2d(affine=False) folded into the kernel, or None."""
+    if bn is None:
+        return None, None
+    mean, invstd = bn
+    _require(mean, "bn mean"), _require(invstd, "bn invstd")
+    return mean.data_ptr(), invstd.data_ptr()
+
+
 class _Mfm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, bias):
+    def forward(ctx, x, bias, bn):
         _check_input(x, bias)
+        bn_mean, bn_invstd = _bn_ptrs(bn)
         N, C2, H, W = x.shape
         C, HW = C2 // 2, H * W
         y = torch.empty((N, C, H, W), dtype=x.dtype, device=x.device)
         lib = _lib.load()
         sel = torch.empty(max(lib.advstep_mfm_sel_bytes(N, C, HW), 1), dtype=torch.uint8, device=x.device)
         with _Launch("mfm_forward", x.device):
-            st = lib.advstep_mfm_forward_f32(x.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(),
-                                             sel.data_ptr(), N, C, HW, _stream(x.device))
+            st = lib.advstep_mfm_forward_f32(x.data_ptr(), bias.data_ptr() if bias is not None else None, bn_mean,
+                                             bn_invstd, y.data_ptr(), sel.data_ptr(), N, C, HW, _stream(x.device))
         _lib.check(st, "advstep_mfm_forward_f32")
-        ctx.save_for_backward(sel)
+        ctx.save_for_backward(sel, *([bn[1]] if bn is not None else []))
         ctx.shape = (N, C, H, W)
         ctx.has_bias = bias is not None
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        (sel,) = ctx.saved_tensors
+        sel, *scale = ctx.saved_tensors
         N, C, H, W = ctx.shape
         gy = gy.contiguous()
         gx = torch.empty((N, 2 * C, H, W), dtype=gy.dtype, device=gy.device)
         with _Launch("mfm_backward", gy.device):
-            st = _lib.load().advstep_mfm_backward_f32(gy.data_ptr(), sel.data_ptr(), gx.data_ptr(), N, C, H * W,
-                                                      _stream(gy.device))
+            st = _lib.load().advstep_mfm_backward_f32(gy.data_ptr(), sel.data_ptr(), scale[0].data_ptr() if scale else None,
+                                                      gx.data_ptr(), N, C, H * W, _stream(gy.device))
         _lib.check(st, "advstep_mfm_backward_f32")
-        return gx, _bias_grad(gx, ctx.has_bias and ctx.needs_input_grad[1])
+        return gx, _bias_grad(gx, ctx.has_bias and ctx.needs_input_grad[1]), None
 
 
 class _MfmPool2(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, bias):
+    def forward(ctx, x, bias, bn):
         _check_input(x, bias)
+        bn_mean, bn_invstd = _bn_ptrs(bn)
         N, C2, H, W = x.shape
         C = C2 // 2
         y = torch.empty((N, C, H // 2, W // 2), dtype=x.dtype, device=x.device)
         idx = torch.empty(max(y.numel(), 2), dtype=torch.uint8, device=x.device)
         with _Launch("mfm_pool2_forward", x.device):
             st = _lib.load().advstep_mfm_pool2_forward_f32(x.data_ptr(), bias.data_ptr() if bias is not None else None,
-                                                           y.data_ptr(), idx.data_ptr(), N, C, H, W, _stream(x.device))
+                                                           bn_mean, bn_invstd, y.data_ptr(), idx.data_ptr(), N, C, H, W,
+                                                           _stream(x.device))
         _lib.check(st, "advstep_mfm_pool2_forward_f32")
-        ctx.save_for_backward(idx)
+        ctx.save_for_backward(idx, *([bn[1]] if bn is not None else []))
         ctx.shape = (N, C, H, W)
         ctx.has_bias = bias is not None
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        (idx,) = ctx.saved_tensors
+        idx, *scale = ctx.saved_tensors
         N, C, H, W = ctx.shape
         gy = gy.contiguous()
         gx = torch.empty((N, 2 * C, H, W), dtype=gy.dtype, device=gy.device)
         with _Launch("mfm_pool2_backward", gy.device):
-            st = _lib.load().advstep_mfm_pool2_backward_f32(gy.data_ptr(), idx.data_ptr(), gx.data_ptr(), N, C, H, W,
-                                                            _stream(gy.device))
+            st = _lib.load().advstep_mfm_pool2_backward_f32(gy.data_ptr(), idx.data_ptr(),
+                                                            scale[0].data_ptr() if scale else None, gx.data_ptr(), N, C, H,
+                                                            W, _stream(gy.device))
         _lib.check(st, "advstep_mfm_pool2_backward_f32")
-        return gx, _bias_grad(gx, ctx.has_bias and ctx.needs_input_grad[1])
+        return gx, _bias_grad(gx, ctx.has_bias and ctx.needs_input_grad[1]), None
 
 
 class _Conv5MfmPool2(torch.autograd.Function):
@@ -142,10 +155,11 @@ class _Conv1x1Mfm(torch.autograd.Function):
     """Conv2d(Cin, 2C, 1x1) + bias + MFM in one kernel; differentiable w.r.t. the input only."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, bn):
         _require(x, "x"), _require(weight, "weight")
         if bias is not None:
             _require(bias, "bias")
+        bn_mean, bn_invstd = _bn_ptrs(bn)
         if x.dim() != 4 or weight.dim() != 4 or tuple(weight.shape[2:]) != (1, 1) or weight.shape[1] != x.shape[1] \
                 or weight.shape[0] % 2 != 0 or (bias is not None and bias.numel() != weight.shape[0]):
             raise ValueError(f"expected x (N, Cin, H, W), weight (2C, Cin, 1, 1), bias (2C); got {tuple(x.shape)}, "
@@ -159,10 +173,10 @@ class _Conv1x1Mfm(torch.autograd.Function):
         sel = torch.empty(max(lib.advstep_conv1x1_mfm_sel_bytes(N, C, P) // 8, 1), dtype=torch.int64, device=x.device)
         with _Launch("conv1x1_mfm_forward", x.device):
             st = lib.advstep_conv1x1_mfm_forward_f32(x.data_ptr(), weight.data_ptr(),
-                                                     bias.data_ptr() if bias is not None else None, y.data_ptr(),
-                                                     sel.data_ptr(), N, Cin, C, P, _stream(x.device))
+                                                     bias.data_ptr() if bias is not None else None, bn_mean, bn_invstd,
+                                                     y.data_ptr(), sel.data_ptr(), N, Cin, C, P, _stream(x.device))
         _lib.check(st, "advstep_conv1x1_mfm_forward_f32")
-        ctx.save_for_backward(sel, weight)
+        ctx.save_for_backward(sel, weight, *([bn[1]] if bn is not None else []))
         ctx.shape = (N, Cin, C, H, W)
         return y
 
@@ -171,24 +185,25 @@ class _Conv1x1Mfm(torch.autograd.Function):
         if ctx.needs_input_grad[1] or (len(ctx.needs_input_grad) > 2 and ctx.needs_input_grad[2]):
             raise RuntimeError("conv1x1_mfm provides the input gradient only; call it with frozen weights "
                                "(the model falls back to Conv2d + mfm otherwise)")
-        sel, weight = ctx.saved_tensors
+        sel, weight, *scale = ctx.saved_tensors
         N, Cin, C, H, W = ctx.shape
         gy = gy.contiguous()
         gx = torch.empty((N, Cin, H, W), dtype=gy.dtype, device=gy.device)
         with _Launch("conv1x1_mfm_backward", gy.device):
             st = _lib.load().advstep_conv1x1_mfm_backward_f32(gy.data_ptr(), sel.data_ptr(), weight.data_ptr(),
-                                                              gx.data_ptr(), N, Cin, C, H * W, _stream(gy.device))
+                                                              scale[0].data_ptr() if scale else None, gx.data_ptr(), N, Cin,
+                                                              C, H * W, _stream(gy.device))
         _lib.check(st, "advstep_conv1x1_mfm_backward_f32")
-        return gx, None, None
+        return gx, None, None, None
 
 
 def conv1x1_mfm_supported(in_channels: int) -> bool:
     return bool(_lib.load().advstep_conv1x1_mfm_supported(in_channels))
 
 
-def conv1x1_mfm(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """MFM(conv2d(x, weight (2C, Cin, 1, 1), bias)) in one kernel (Cin in 32/48/64)."""
-    return _Conv1x1Mfm.apply(x.contiguous(), weight.contiguous(), bias)
+def conv1x1_mfm(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn=None) -> torch.Tensor:
+    """[BN_eval](MFM(conv2d(x, weight (2C, Cin, 1, 1), bias))) in one kernel (Cin in 32/48/64); bn = (mean, invstd)."""
+    return _Conv1x1Mfm.apply(x.contiguous(), weight.contiguous(), bias, bn)
 
 
 class _LstmLayer(torch.autograd.Function):
@@ -240,11 +255,21 @@ def lstm_layer(x: torch.Tensor, w_ih: torch.Tensor, w_hh: torch.Tensor, bias: to
     return _LstmLayer.apply(x.contiguous(), w_ih, w_hh, bias)
 
 
-def mfm(x: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """(N, 2C, H, W) -> (N, C, H, W): max(x[:, :C] + bias[:C], x[:, C:] + bias[C:])."""
-    return _Mfm.apply(x.contiguous(), bias)
+def mfm(x: torch.Tensor, bias: Optional[torch.Tensor] = None, bn=None) -> torch.Tensor:
+    """(N, 2C, H, W) -> (N, C, H, W): max(x[:, :C] + bias[:C], x[:, C:] + bias[C:]) [then (. - mean) * invstd]."""
+    return _Mfm.apply(x.contiguous(), bias, bn)
 
 
-def mfm_pool2(x: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """(N, 2C, H, W) -> (N, C, H//2, W//2): MaxPool2d(2, 2) of the max-feature-map."""
-    return _MfmPool2.apply(x.contiguous(), bias)
+def mfm_pool2(x: torch.Tensor, bias: Optional[torch.Tensor] = None, bn=None) -> torch.Tensor:
+    """(N, 2C, H, W) -> (N, C, H//2, W//2): MaxPool2d(2, 2) of the max-feature-map [then (. - mean) * invstd]."""
+    return _MfmPool2.apply(x.contiguous(), bias, bn)
+
+
+def bn_eval_stats(bn: torch.nn.modules.batchnorm._BatchNorm):
+    """(running_mean, 1 / sqrt(running_var + eps)) of an eval-mode, affine-free BatchNorm, cached on the module."""
+    key = (bn.running_var.data_ptr(), bn.running_var._version, bn.running_mean._version, str(bn.running_var.device))
+    if getattr(bn, "_advstep_key", None) != key:
+        with torch.no_grad():
+            invstd = (1.0 / torch.sqrt(bn.running_var + bn.eps)).contiguous()
+        bn._advstep_key, bn._advstep_stats = key, (bn.running_mean.detach().contiguous(), invstd)
+    return bn._advstep_stats

@@ -115,6 +115,16 @@ def _fused_conv0_enabled() -> bool:
     return os.environ.get("ADVSTEP_LCNN_CONV0", "1") != "0"
 
 
+def _fused_bn_enabled() -> bool:
+    """ADVSTEP_LCNN_BN=0 keeps ATen's batch-norm kernels after the fused blocks (A/B measurements); default on."""
+    return os.environ.get("ADVSTEP_LCNN_BN", "1") != "0"
+
+
+def _foldable_bn(mod) -> bool:
+    return (isinstance(mod, nn.BatchNorm2d) and not mod.training and not mod.affine and mod.track_running_stats
+            and mod.running_mean is not None)
+
+
 def _fused_lstm_enabled() -> bool:
     """ADVSTEP_LCNN_LSTM=0 keeps MIOpen's RNN path (A/B measurements); default on."""
     return os.environ.get("ADVSTEP_LCNN_LSTM", "1") != "0"
@@ -184,21 +194,25 @@ class BaseLCNN(nn.Module):
                     x = lcnn_ops.conv5_mfm_pool2(x, m.weight, m.bias)
                     i += 3
                     continue
+                pooled = isinstance(after, nn.MaxPool2d) and _is_pool2(after)
+                consumed = 3 if pooled else 2
+                # an eval-mode BatchNorm2d(affine=False) right after the block is folded into the kernel's epilogue
+                tail = mods[i + consumed] if i + consumed < len(mods) else None
+                bn = None
+                if _foldable_bn(tail) and _fused_bn_enabled():
+                    bn = lcnn_ops.bn_eval_stats(tail)
+                    consumed += 1
                 if (params_frozen and _is_pointwise_conv(m) and lcnn_ops.conv1x1_mfm_supported(m.in_channels)
-                        and not (isinstance(after, nn.MaxPool2d)) and _fused_conv1x1_enabled()):
-                    # 1x1 conv + bias + MFM in ONE kernel: the 2C-channel conv output never exists
-                    x = lcnn_ops.conv1x1_mfm(x, m.weight, m.bias)
-                    i += 2
+                        and not isinstance(after, nn.MaxPool2d) and _fused_conv1x1_enabled()):
+                    # 1x1 conv + bias + MFM (+ BN) in ONE kernel: the 2C-channel conv output never exists
+                    x = lcnn_ops.conv1x1_mfm(x, m.weight, m.bias, bn)
+                    i += consumed
                     continue
                 fold_bias = m.bias is not None and not (torch.is_grad_enabled() and m.bias.requires_grad)
                 h = F.conv2d(x, m.weight, None if fold_bias else m.bias, m.stride, m.padding, m.dilation, m.groups)
                 bias = m.bias if fold_bias else None
-                if isinstance(after, nn.MaxPool2d) and _is_pool2(after):
-                    x = lcnn_ops.mfm_pool2(h, bias)
-                    i += 3
-                else:
-                    x = lcnn_ops.mfm(h, bias)
-                    i += 2
+                x = lcnn_ops.mfm_pool2(h, bias, bn) if pooled else lcnn_ops.mfm(h, bias, bn)
+                i += consumed
             else:
                 x = m(x)
                 i += 1

@@ -12,6 +12,9 @@
  * Semantics are those of the ATen kernels being replaced, bit for bit, including ties and NaN:
  *   MFM     y = a if (isnan(a) || a >= b) else b,  a = x[n, c], b = x[n, c + C]      (lower index wins a tie)
  *   pool    scan (dh, dw) in row-major order, take v when (v > best || isnan(v)), best starts at -inf
+ * Every forward entry point takes optional bn_mean / bn_invstd (C floats, both NULL or both set): the eval-mode
+ * BatchNorm2d(affine=False) that follows the block in LCNN (lcnn.py:127,131,134,141,144,148), y = (y - mean[c]) * invstd[c]
+ * with invstd = 1 / sqrt(running_var + eps), applied in the epilogue; the matching backward takes gscale (= invstd).
  * Conventions as in advstep.h: contiguous NCHW float32 device pointers, caller-owned outputs, stream-ordered,
  * status codes.
  */
@@ -34,23 +37,25 @@ size_t advstep_mfm_sel_bytes(int64_t N, int64_t C, int64_t HW);
 /* y (N, C, HW) = max-feature-map of x (N, 2C, HW) [+ bias (2C) when bias != NULL: the convolution's bias add
  * (one rounding per element, as ATen's separate add kernel) is folded into this pass]; sel receives, per group of 4
  * outputs, bit k = 1 when output k came from the second half of the channels. */
-int advstep_mfm_forward_f32(const float *x, const float *bias, float *y, uint8_t *sel, int64_t N, int64_t C,
-                            int64_t HW, advstep_stream_t stream);
+int advstep_mfm_forward_f32(const float *x, const float *bias, const float *bn_mean, const float *bn_invstd, float *y,
+                            uint8_t *sel, int64_t N, int64_t C, int64_t HW, advstep_stream_t stream);
 
-/* gx (N, 2C, HW) from gy (N, C, HW): the gradient goes to the selected half, the other half gets 0. */
-int advstep_mfm_backward_f32(const float *gy, const uint8_t *sel, float *gx, int64_t N, int64_t C, int64_t HW,
-                             advstep_stream_t stream);
+/* gx (N, 2C, HW) from gy (N, C, HW) [* gscale (C) when given]: the gradient goes to the selected half, the other
+ * half gets 0. */
+int advstep_mfm_backward_f32(const float *gy, const uint8_t *sel, const float *gscale, float *gx, int64_t N, int64_t C,
+                             int64_t HW, advstep_stream_t stream);
 
 /* y (N, C, H/2, W/2) = MaxPool2d(2, 2)(MFM(x)), x (N, 2C, H, W) (floor division: a trailing odd row / column is
  * dropped, as with ceil_mode=False); bias (2C) as above, may be NULL.  idx receives one byte per pooled output: bit 2 = second channel half,
  * bit 1 = dh, bit 0 = dw of the winning input. */
-int advstep_mfm_pool2_forward_f32(const float *x, const float *bias, float *y, uint8_t *idx, int64_t N, int64_t C,
-                                  int64_t H, int64_t W, advstep_stream_t stream);
+int advstep_mfm_pool2_forward_f32(const float *x, const float *bias, const float *bn_mean, const float *bn_invstd,
+                                  float *y, uint8_t *idx, int64_t N, int64_t C, int64_t H, int64_t W,
+                                  advstep_stream_t stream);
 
 /* gx (N, 2C, H, W) from gy (N, C, H/2, W/2) and idx: every input position receives either the pooled gradient
  * (the winner) or 0 — including a trailing odd row / column. */
-int advstep_mfm_pool2_backward_f32(const float *gy, const uint8_t *idx, float *gx, int64_t N, int64_t C, int64_t H,
-                                   int64_t W, advstep_stream_t stream);
+int advstep_mfm_pool2_backward_f32(const float *gy, const uint8_t *idx, const float *gscale, float *gx, int64_t N,
+                                   int64_t C, int64_t H, int64_t W, advstep_stream_t stream);
 
 /* ---- first block fused: Conv2d(1, 2C, (5,5), stride 1, padding 2) -> MaxFeatureMap2D -> MaxPool2d(2, 2) -----------
  * (src/models/lcnn.py:121-123).  With ONE input channel the convolution is not a GEMM (K = 25): it is a 1.06 GB
@@ -69,15 +74,19 @@ int advstep_conv5_mfm_pool2_backward_f32(const float *gy, const uint8_t *idx, co
 /* ---- 1x1 blocks fused: Conv2d(Cin, 2C, (1,1)) -> MaxFeatureMap2D  (src/models/lcnn.py:125-126,132-133,139-140,146-147)
  * x (N, Cin, P) with P = H*W, weight (2C, Cin), bias (2C) or NULL -> y (N, C, P); sel gets ONE bit per output
  * (N * C * ceil(P/64) 64-bit words, bit = pixel % 64, set when the second channel half won).  The 2C-channel conv
- * output is never written.  Cin must be one advstep_conv1x1_mfm_supported() accepts (32, 48, 64: LCNN's). */
+ * output is never written.  Cin must be one advstep_conv1x1_mfm_supported() accepts (32, 48, 64: LCNN's).
+ * bn_mean / bn_invstd (C) or both NULL: the eval-mode BatchNorm2d(affine=False) that follows each of these blocks
+ * (lcnn.py:127,134,141,148), y = (max - mean[c]) * invstd[c], folded into the epilogue. */
 int advstep_conv1x1_mfm_supported(int64_t Cin);
 size_t advstep_conv1x1_mfm_sel_bytes(int64_t N, int64_t C, int64_t P);
-int advstep_conv1x1_mfm_forward_f32(const float *x, const float *weight, const float *bias, float *y, uint64_t *sel,
-                                    int64_t N, int64_t Cin, int64_t C, int64_t P, advstep_stream_t stream);
+int advstep_conv1x1_mfm_forward_f32(const float *x, const float *weight, const float *bias, const float *bn_mean,
+                                    const float *bn_invstd, float *y, uint64_t *sel, int64_t N, int64_t Cin, int64_t C,
+                                    int64_t P, advstep_stream_t stream);
 
-/* Input gradient of the block above: gx (N, Cin, P) = sum_c gy[n, c, p] * weight[selected half of pair c, :]. */
-int advstep_conv1x1_mfm_backward_f32(const float *gy, const uint64_t *sel, const float *weight, float *gx, int64_t N,
-                                     int64_t Cin, int64_t C, int64_t P, advstep_stream_t stream);
+/* Input gradient of the block above: gx (N, Cin, P) = sum_c (gy[n, c, p] * gscale[c]) * weight[selected half of
+ * pair c, :]; gscale (C) = the BatchNorm's invstd, or NULL. */
+int advstep_conv1x1_mfm_backward_f32(const float *gy, const uint64_t *sel, const float *weight, const float *gscale,
+                                     float *gx, int64_t N, int64_t Cin, int64_t C, int64_t P, advstep_stream_t stream);
 
 /* ---- recurrent part of a (bi)directional LSTM layer  (src/models/lcnn.py:24-46: nn.LSTM(160, 80, bidirectional)) ------
  * The input projections are computed by the caller with one GEMM:

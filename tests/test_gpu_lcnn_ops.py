@@ -121,6 +121,8 @@ def test_fused_lcnn_is_bit_identical_to_plain_lcnn(cuda, monkeypatch):
     monkeypatch.setenv("ADVSTEP_LCNN_CONV0", "0")
     monkeypatch.setenv("ADVSTEP_LCNN_CONV1X1", "0")
     monkeypatch.setenv("ADVSTEP_LCNN_LSTM", "0")
+    monkeypatch.setenv("ADVSTEP_LCNN_BN", "0")
+    monkeypatch.setenv("ADVSTEP_FUSED_LFCC", "0")
 
     def run(fused, frozen, waveform=False):
         monkeypatch.setenv("ADVSTEP_LCNN_FUSED", "1" if fused else "0")
@@ -302,3 +304,36 @@ def test_blstm_layer_uses_kernel_when_frozen_and_matches_miopen(cuda, monkeypatc
     assert (y1 - y0).abs().max().item() <= 2e-6 and (g1 - g0).abs().max().item() <= 2e-5 * max(g0.abs().max().item(), 1.0)
     for p in layer.parameters():
         p.requires_grad_(True)
+
+
+# ---- eval-mode BatchNorm folded into the block kernels ---------------------------------------------------------------------------
+
+def _bn_ref(y, mean, var, eps=1e-5):
+    return torch.nn.functional.batch_norm(y, mean, var, None, None, False, 0.1, eps)
+
+
+@pytest.mark.parametrize("kind", ["mfm", "mfm_pool2", "conv1x1"])
+def test_folded_batchnorm_matches_aten(L, cuda, kind):
+    g = torch.Generator().manual_seed(11)
+    C = 32
+    mean = torch.randn(C, generator=g).to(cuda)
+    var = (torch.rand(C, generator=g) + 0.5).to(cuda)
+    bn = (mean, (1.0 / torch.sqrt(var + 1e-5)).contiguous())
+    if kind == "conv1x1":
+        x = torch.randn(3, 32, 9, 10, generator=g).to(cuda).requires_grad_(True)
+        w = (torch.randn(2 * C, 32, 1, 1, generator=g) * 0.2).to(cuda)
+        b = torch.randn(2 * C, generator=g).to(cuda)
+        ref = _bn_ref(ref_mfm(torch.nn.functional.conv2d(x, w, b)), mean, var)
+        got = L.conv1x1_mfm(x, w, b, bn)
+        tol = 2e-5
+    else:
+        x = make((3, 2 * C, 10, 12), cuda, 12).requires_grad_(True)
+        b = torch.randn(2 * C, generator=g).to(cuda)
+        ref = _bn_ref((ref_mfm_pool if kind == "mfm_pool2" else ref_mfm)(x, b), mean, var)
+        got = (L.mfm_pool2 if kind == "mfm_pool2" else L.mfm)(x, b, bn)
+        tol = 1e-6   # same operations; ATen may use rsqrt for invstd
+    gy = torch.randn(ref.shape, generator=g).to(cuda)
+    (g_ref,) = torch.autograd.grad(ref, x, gy)
+    (g_got,) = torch.autograd.grad(got, x, gy)
+    assert (got - ref).abs().max().item() <= tol * max(ref.abs().max().item(), 1.0)
+    assert (g_got - g_ref).abs().max().item() <= max(tol, 2e-6) * max(g_ref.abs().max().item(), 1.0)

@@ -73,18 +73,19 @@ def main():
     idx = torch.empty(y_p.numel(), dtype=torch.uint8, device=dev)
     gxb = [torch.empty(B, 2 * C, H, W, device=dev) for _ in range(nsets2)]
     stream = torch.cuda.current_stream().cuda_stream
-    lib.advstep_mfm_forward_f32(cx[0].data_ptr(), None, y_m.data_ptr(), sel.data_ptr(), B, C, H * W, stream)
-    lib.advstep_mfm_pool2_forward_f32(cx[0].data_ptr(), None, y_p.data_ptr(), idx.data_ptr(), B, C, H, W, stream)
+    lib.advstep_mfm_forward_f32(cx[0].data_ptr(), None, None, None, y_m.data_ptr(), sel.data_ptr(), B, C, H * W, stream)
+    lib.advstep_mfm_pool2_forward_f32(cx[0].data_ptr(), None, None, None, y_p.data_ptr(), idx.data_ptr(), B, C, H, W, stream)
     nm, npool = y_m.numel(), y_p.numel()
     lcnn_cases = {
-        "mfm_forward(+bias)": (lambda i: lib.advstep_mfm_forward_f32(cx[i % nsets2].data_ptr(), cbias.data_ptr(), y_m.data_ptr(),
-                                                                     sel.data_ptr(), B, C, H * W, stream), nm * 12.25),
-        "mfm_backward": (lambda i: lib.advstep_mfm_backward_f32(y_m.data_ptr(), sel.data_ptr(), gxb[i % nsets2].data_ptr(), B, C,
-                                                                H * W, stream), nm * 12.25),
+        "mfm_forward(+bias)": (lambda i: lib.advstep_mfm_forward_f32(cx[i % nsets2].data_ptr(), cbias.data_ptr(), None, None,
+                                                                     y_m.data_ptr(), sel.data_ptr(), B, C, H * W, stream),
+                               nm * 12.25),
+        "mfm_backward": (lambda i: lib.advstep_mfm_backward_f32(y_m.data_ptr(), sel.data_ptr(), None, gxb[i % nsets2].data_ptr(), B,
+                                                                C, H * W, stream), nm * 12.25),
         "mfm_pool2_forward(+bias)": (lambda i: lib.advstep_mfm_pool2_forward_f32(cx[i % nsets2].data_ptr(), cbias.data_ptr(),
-                                                                                 y_p.data_ptr(), idx.data_ptr(), B, C, H, W,
-                                                                                 stream), npool * 37.0),
-        "mfm_pool2_backward": (lambda i: lib.advstep_mfm_pool2_backward_f32(y_p.data_ptr(), idx.data_ptr(),
+                                                                                 None, None, y_p.data_ptr(), idx.data_ptr(),
+                                                                                 B, C, H, W, stream), npool * 37.0),
+        "mfm_pool2_backward": (lambda i: lib.advstep_mfm_pool2_backward_f32(y_p.data_ptr(), idx.data_ptr(), None,
                                                                             gxb[i % nsets2].data_ptr(), B, C, H, W, stream),
                                npool * 37.0),
     }
