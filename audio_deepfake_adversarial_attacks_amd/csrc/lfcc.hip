@@ -186,6 +186,165 @@ __global__ __launch_bounds__(kBlock) void lfcc_project_backward_kernel(const flo
     for (int i = threadIdx.x; i < nfr * M; i += kBlock) dst[i] = band_s[i / M][i % M];
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The DCT projection as a true dense contraction on the matrix cores (fp32-in / fp32-accumulate MFMA, exact f32):
+//   out (frames x 80) = max(band_db, floor) (frames x 128) . dct (128 x 80)           K = 128
+//   g   (frames x 128) = dout (frames x 80) . dct^T (80 x 128)                         K = 80
+// v_mfma_f32_32x32x2_f32: lane l supplies A[i = l & 31][k = l >> 5] and B[k = l >> 5][j = l & 31]; the 32x32
+// accumulator lives in 16 registers, col = l & 31, row = (r & 3) + 8 (r >> 2) + 4 (l >> 5).
+// One wave owns 32 frames; a 256-thread workgroup owns 128.  Operands are staged in LDS with odd row pitches so the
+// per-step fragment reads are bank-conflict free.  Specialised for M = 128, K = 80 (LFCC); other sizes use the VALU
+// kernels above.
+// ---------------------------------------------------------------------------------------------------------
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kMfmaFrames = 128;   // frames per workgroup (4 waves x 32)
+constexpr int kLfccM = 128, kLfccK = 80, kLfccKPad = 96;
+
+__device__ __forceinline__ int mfma_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+__global__ __launch_bounds__(kBlock) void lfcc_project_mfma_kernel(const float *__restrict__ band_db,
+                                                                   const float *__restrict__ dct, float *stats,
+                                                                   float top_db, float *__restrict__ out, int NF) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float(*band_s)[kLfccM + 1] = reinterpret_cast<float(*)[kLfccM + 1]>(smem);                      // [128][129]
+    float(*dct_s)[kLfccKPad] = reinterpret_cast<float(*)[kLfccKPad]>(smem + kMfmaFrames * (kLfccM + 1));  // [128][96]
+    const int64_t b = blockIdx.y;
+    const int t0 = blockIdx.x * kMfmaFrames;
+    const int nfr = NF - t0 < kMfmaFrames ? NF - t0 : kMfmaFrames;
+    const float gmax = stats[0];
+    const float floor_db = gmax - top_db;
+    const float *src = band_db + (b * NF + t0) * kLfccM;
+    int ties = 0;
+    // stage the (frames x 128) band tile and the DCT with 16-byte global loads, several in flight per thread
+    const float4 *src4 = reinterpret_cast<const float4 *>(src);
+#pragma unroll 4
+    for (int i = threadIdx.x; i < kMfmaFrames * kLfccM / 4; i += kBlock) {
+        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (i < nfr * kLfccM / 4) {
+            v = src4[i];
+            ties += (v.x == gmax) + (v.y == gmax) + (v.z == gmax) + (v.w == gmax);
+            float *pv = &v.x;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                pv[e] = (pv[e] != pv[e]) ? pv[e] : ((floor_db != floor_db) ? floor_db : (pv[e] > floor_db ? pv[e] : floor_db));
+        }
+        float *row = &band_s[i >> 5][(i & 31) * 4];
+        row[0] = v.x; row[1] = v.y; row[2] = v.z; row[3] = v.w;
+    }
+    const float4 *dct4 = reinterpret_cast<const float4 *>(dct);
+#pragma unroll 4
+    for (int i = threadIdx.x; i < kLfccM * kLfccKPad / 4; i += kBlock) {
+        const int m = i / (kLfccKPad / 4), k4 = i - m * (kLfccKPad / 4);
+        const float4 v = k4 < kLfccK / 4 ? dct4[m * (kLfccK / 4) + k4] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        *reinterpret_cast<float4 *>(&dct_s[m][k4 * 4]) = v;
+    }
+    if (ties) atomicAdd(&stats[1], (float)ties);
+    __syncthreads();
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row0 = wave * 32;
+    if (row0 < nfr) {  // wave-uniform
+        f32x16 acc0 = {0}, acc1 = {0}, acc2 = {0};
+        const int li = lane & 31, lk = lane >> 5;
+#pragma unroll 4
+        for (int s = 0; s < kLfccM / 2; ++s) {
+            const float a = band_s[row0 + li][2 * s + lk];
+            const float *br = dct_s[2 * s + lk];
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, br[li], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, br[32 + li], acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, br[64 + li], acc2, 0, 0, 0);
+        }
+        float *dst = out + (b * NF + t0 + row0) * kLfccK;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = mfma_row(r, lane);
+            if (row0 + row < nfr) {
+                float *o = dst + (int64_t)row * kLfccK;
+                o[li] = acc0[r];
+                o[32 + li] = acc1[r];
+                if (li < kLfccK - 64) o[64 + li] = acc2[r];
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void lfcc_project_backward_mfma_kernel(const float *__restrict__ dout,
+                                                                            const float *__restrict__ dct,
+                                                                            const float *__restrict__ band_db,
+                                                                            float *stats, float top_db,
+                                                                            float *__restrict__ dband, int NF) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float(*g_s)[kLfccK + 1] = reinterpret_cast<float(*)[kLfccK + 1]>(smem);                           // [128][81]
+    float(*dct_s)[kLfccK + 1] = reinterpret_cast<float(*)[kLfccK + 1]>(smem + kMfmaFrames * (kLfccK + 1));  // [128][81]
+    float(*band_s)[kLfccM + 1] =
+        reinterpret_cast<float(*)[kLfccM + 1]>(smem + (kMfmaFrames + kLfccM) * (kLfccK + 1));               // [128][129]
+    __shared__ float red[kBlock / 64];
+    const int64_t b = blockIdx.y;
+    const int t0 = blockIdx.x * kMfmaFrames;
+    const int nfr = NF - t0 < kMfmaFrames ? NF - t0 : kMfmaFrames;
+    const float *src = dout + (b * NF + t0) * kLfccK;
+    const float4 *src4 = reinterpret_cast<const float4 *>(src);
+#pragma unroll 4
+    for (int i = threadIdx.x; i < kMfmaFrames * kLfccK / 4; i += kBlock) {
+        const int t = i / (kLfccK / 4), k4 = i - t * (kLfccK / 4);
+        const float4 v = i < nfr * kLfccK / 4 ? src4[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        float *row = &g_s[t][k4 * 4];
+        row[0] = v.x; row[1] = v.y; row[2] = v.z; row[3] = v.w;
+    }
+    const float4 *dct4 = reinterpret_cast<const float4 *>(dct);
+#pragma unroll 4
+    for (int i = threadIdx.x; i < kLfccM * kLfccK / 4; i += kBlock) {
+        const int m = i / (kLfccK / 4), k4 = i - m * (kLfccK / 4);
+        const float4 v = dct4[i];
+        float *row = &dct_s[m][k4 * 4];
+        row[0] = v.x; row[1] = v.y; row[2] = v.z; row[3] = v.w;
+    }
+    const float4 *band4 = reinterpret_cast<const float4 *>(band_db + (b * NF + t0) * kLfccM);
+#pragma unroll 4
+    for (int i = threadIdx.x; i < nfr * kLfccM / 4; i += kBlock) {
+        const float4 v = band4[i];
+        float *row = &band_s[i >> 5][(i & 31) * 4];
+        row[0] = v.x; row[1] = v.y; row[2] = v.z; row[3] = v.w;
+    }
+    __syncthreads();
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row0 = wave * 32;
+    const float floor_db = stats[0] - top_db;
+    float floored = 0.0f;
+    if (row0 < nfr) {
+        f32x16 acc[4] = {{0}, {0}, {0}, {0}};
+        const int li = lane & 31, lk = lane >> 5;
+#pragma unroll 4
+        for (int s = 0; s < kLfccK / 2; ++s) {
+            const int k = 2 * s + lk;
+            const float a = g_s[row0 + li][k];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, dct_s[32 * j + li][k], acc[j], 0, 0, 0);
+        }
+        float *dst = dband + (b * NF + t0 + row0) * kLfccM;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = mfma_row(r, lane);
+            if (row0 + row < nfr) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int m = 32 * j + li;
+                    const float db = band_s[row0 + row][m];
+                    const float sgrad = acc[j][r];
+                    const float wgt = db > floor_db ? 1.0f : (db == floor_db ? 0.5f : 0.0f);
+                    floored += (1.0f - wgt) * sgrad;
+                    dst[(int64_t)row * kLfccM + m] = (wgt * sgrad) * dlog_of_db(db);
+                }
+            }
+        }
+    }
+    floored = block_sum(floored, red);
+    if (threadIdx.x == 0 && floored != 0.0f) atomicAdd(&stats[2], floored);
+}
+
 __global__ __launch_bounds__(kBlock) void lfcc_floor_fixup_kernel(const float *__restrict__ band_db,
                                                                   const float *__restrict__ stats,
                                                                   float *__restrict__ dband, int64_t n) {
@@ -318,7 +477,14 @@ int advstep_lfcc_project_f32(const float *band_db, const float *dct, float *stat
     LFCC_REQUIRE(band_db && dct && stats && out && B <= kMaxGridY && M <= INT32_MAX && NF <= INT32_MAX);
     const dim3 grid((unsigned)ceil_div(NF, kFrames), (unsigned)B);
     hipStream_t st = as_stream(stream);
-    if (K == 80)
+    if (K == kLfccK && M == kLfccM) {  // matrix-core path
+        const dim3 mgrid((unsigned)ceil_div(NF, kMfmaFrames), (unsigned)B);
+        const size_t lds = (size_t)(kMfmaFrames * (kLfccM + 1) + kLfccM * kLfccKPad) * sizeof(float);
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(lfcc_project_mfma_kernel),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)attr;  // > 64 KiB of dynamic LDS must be opted into once
+        hipLaunchKernelGGL(lfcc_project_mfma_kernel, mgrid, dim3(kBlock), lds, st, band_db, dct, stats, top_db, out, (int)NF);
+    } else if (K == 80)
         hipLaunchKernelGGL(lfcc_project_kernel<20>, grid, dim3(kBlock), 0, st, band_db, dct, stats, top_db, out, (int)M, (int)NF);
     else if (K == 40)
         hipLaunchKernelGGL(lfcc_project_kernel<10>, grid, dim3(kBlock), 0, st, band_db, dct, stats, top_db, out, (int)M, (int)NF);
@@ -335,7 +501,16 @@ int advstep_lfcc_project_backward_f32(const float *dout, const float *dct, const
     LFCC_REQUIRE(dout && dct && band_db && stats && dband && B <= kMaxGridY && M <= INT32_MAX && NF <= INT32_MAX);
     const dim3 grid((unsigned)ceil_div(NF, kFrames), (unsigned)B);
     hipStream_t st = as_stream(stream);
-    if (K == 80)
+    if (K == kLfccK && M == kLfccM) {  // matrix-core path
+        const dim3 mgrid((unsigned)ceil_div(NF, kMfmaFrames), (unsigned)B);
+        const size_t lds =
+            (size_t)(kMfmaFrames * (kLfccK + 1) + kLfccM * (kLfccK + 1) + kMfmaFrames * (kLfccM + 1)) * sizeof(float);
+        static const hipError_t attr = hipFuncSetAttribute(
+            reinterpret_cast<const void *>(lfcc_project_backward_mfma_kernel),
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)attr;
+        hipLaunchKernelGGL(lfcc_project_backward_mfma_kernel, mgrid, dim3(kBlock), lds, st, dout, dct, band_db, stats, top_db, dband, (int)NF);
+    } else if (K == 80)
         hipLaunchKernelGGL(lfcc_project_backward_kernel<20>, grid, dim3(kBlock), 0, st, dout, dct, band_db, stats, top_db, dband, (int)M, (int)NF);
     else if (K == 40)
         hipLaunchKernelGGL(lfcc_project_backward_kernel<10>, grid, dim3(kBlock), 0, st, dout, dct, band_db, stats, top_db, dband, (int)M, (int)NF);
