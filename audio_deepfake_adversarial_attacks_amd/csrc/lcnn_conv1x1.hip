@@ -1,17 +1,22 @@
 // lcnn_conv1x1.hip — LCNN's 1x1 "network-in-network" blocks fused on gfx950:
-//     Conv2d(Cin, 2C, (1, 1)) -> MaxFeatureMap2D          (src/models/lcnn.py:125-126, 132-133, 139-140, 146-147)
+//     Conv2d(Cin, 2C, (1, 1)) -> MaxFeatureMap2D [-> BatchNorm2d(eval, affine=False)]
+//     (src/models/lcnn.py:125-127, 132-134, 139-141, 146-148)
 // forward and input-backward (C ABI: include/advstep_lcnn.h).
 //
-// A 1x1 convolution over NCHW is a skinny GEMM per pixel column (K = Cin = 32..64, M = 2C = 64..128) whose output
-// is consumed only by the max-feature-map.  Run separately (MIOpen GEMM + ATen add + max) the 2C-channel tensor is
-// written and read twice (L3 at B = 128: 265 MB each way); fused, a thread keeps its pixel's Cin inputs in
-// registers, forms both halves of each channel pair with wave-uniform (scalar) weight operands, and writes only the
-// C-channel winner plus ONE selection bit (wave ballot).  Reads Cin*4 B and writes C*4 B per pixel: HBM-bound
-// (VALU work 2*Cin*C fma per pixel stays under the memory time at these sizes); fp32 MFMA would run at the same
-// rate as the VALU here and needs no help from it.
-//   forward : thread = pixel, x[:, p] in Cin registers, loop over the C pairs (2*Cin fma with SGPR weights).
-//   backward: thread = pixel, Cin accumulators; for every pair the gradient goes to the selected half's weight row.
-// Fixed summation order (ci ascending / c ascending), fma: deterministic; equals MIOpen's result to float rounding.
+// A 1x1 convolution over NCHW is a skinny GEMM per pixel column — out (2C x P) = W (2C x Cin) . X (Cin x P) with
+// K = Cin = 32..64 — and its output is consumed only by the max-feature-map.  Run separately (MIOpen GEMM + ATen add +
+// max) the 2C-channel tensor is written and read twice (L3 at B = 128: 265 MB each way).  Here it is ONE kernel on the
+// matrix cores: v_mfma_f32_32x32x2_f32 (fp32 in, fp32 accumulate, exact: the result is the k-ordered fmaf chain), the
+// "MFMA where the work is a true dense contraction" part of the design.
+//   * a wave owns 32 pixels: its B fragments (X[ci][px], one float per lane per K-step) are loaded straight from global
+//     memory — 128 B contiguous per half wave — and live in Cin/2 registers;
+//   * W is staged once per workgroup in LDS with an odd row pitch (conflict-free fragment reads);
+//   * rows of the two channel halves land in the SAME (lane, register) slot of two accumulators, so the max-feature-map
+//     is a register-to-register max; bias, the eval BatchNorm and the selection bit (wave ballot) are the epilogue;
+//   * backward is the transposed GEMM over K = 2C with the max-feature-map backward applied while the B fragment is
+//     formed (the gradient goes to the selected half's weight row), so the 2C-channel gradient never exists either.
+// HBM traffic: Cin*4 B in, C*4 B + 1 bit out per pixel.  Accumulator map (32x32 tile, 16 registers): col = lane & 31,
+// row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
 
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -21,175 +26,183 @@
 
 namespace {
 
-constexpr int kBlock = 256;
+constexpr int kBlock = 256;          // 4 waves
+constexpr int kTilesPerWave = 1;     // 32-pixel tiles a wave walks (1: more, shorter waves measured fastest; 4 was 1.5x slower)
+constexpr int kPixPerBlock = 128;    // backward: 32 pixels per wave
+constexpr int kFwdPixPerBlock = 4 * 32 * kTilesPerWave;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 inline hipStream_t as_stream(advstep_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 inline int status_after_launch() { return hipGetLastError() == hipSuccess ? ADVSTEP_OK : ADVSTEP_ELAUNCH; }
 
 __device__ __forceinline__ bool mfm_takes_b(float a, float b) { return !(a != a) && !(a >= b); }
+__device__ __forceinline__ int mfma_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
-// grid (ceil(P / 256), N, Z): blockIdx.z owns the channel pairs [z * cper, (z + 1) * cper) — small feature maps
-// (P = 500 in LCNN's last blocks) would otherwise run one wave per SIMD with nothing to hide the scalar weight loads.
-// bn_mean / bn_invstd (C, nullable): the eval-mode BatchNorm2d(affine=False) that follows every 1x1 block in LCNN,
-// y = (max - mean[c]) * invstd[c], applied in the epilogue.
-// PIX pixels per thread (p, p + 256, ...): every scalar weight operand is used PIX times, which halves the scalar-load
-// traffic and latency per fma for the large feature maps.
-template <int CIN, int PIX>
+// grid (ceil(P / 512), N).  TILES = ceil(C / 32) channel tiles per half.
+// LDS: w_s[2 * TILES * 32][CIN + 1]; rows [0, 32 TILES) = first half (zero beyond C), rows [32 TILES, 64 TILES) = second.
+template <int CIN, int TILES>
 __global__ __launch_bounds__(kBlock) void conv1x1_mfm_forward_kernel(const float *__restrict__ x,
                                                                      const float *__restrict__ weight,
                                                                      const float *__restrict__ bias,
                                                                      const float *__restrict__ bn_mean,
                                                                      const float *__restrict__ bn_invstd,
-                                                                     float *__restrict__ y,
-                                                                     unsigned long long *__restrict__ sel, int C, int cper,
-                                                                     int64_t P, int64_t PW) {
-    const int64_t n = blockIdx.y;
-    const int64_t p0 = (int64_t)blockIdx.x * (kBlock * PIX) + threadIdx.x;
-    bool valid[PIX];
-    float xr[PIX][CIN];
-#pragma unroll
-    for (int q = 0; q < PIX; ++q) {
-        const int64_t p = p0 + (int64_t)q * kBlock;
-        valid[q] = p < P;
-        const float *xn = x + n * CIN * P + (valid[q] ? p : 0);
-#pragma unroll
-        for (int ci = 0; ci < CIN; ++ci) xr[q][ci] = valid[q] ? xn[(int64_t)ci * P] : 0.0f;
+                                                                     float *__restrict__ y, uint32_t *__restrict__ sel,
+                                                                     int C, int64_t P, int64_t PW) {
+    extern __shared__ __attribute__((aligned(16))) float w_s[];
+    constexpr int CP = TILES * 32, PITCH = CIN + 1;
+    for (int i = threadIdx.x; i < 2 * CP * CIN; i += kBlock) {
+        const int row = i / CIN, ci = i - row * CIN;
+        const int half = row / CP, c = row - half * CP;
+        w_s[row * PITCH + ci] = c < C ? weight[(int64_t)(half * C + c) * CIN + ci] : 0.0f;
     }
-    float *yn = y + n * (int64_t)C * P + p0;
-    unsigned long long *sn = sel + n * (int64_t)C * PW + (p0 >> 6);
-    const int c_begin = blockIdx.z * cper;
-    const int c_end = c_begin + cper < C ? c_begin + cper : C;
-    for (int c = c_begin; c < c_end; ++c) {
-        const float *wa = weight + (int64_t)c * CIN;  // wave-uniform: scalar loads
-        const float *wb = weight + (int64_t)(c + C) * CIN;
-        float a[PIX], b[PIX];
+    __syncthreads();
+
+    const int64_t n = blockIdx.y;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, lk = lane >> 5;
+    // a wave walks kTilesPerWave pixel tiles; the B fragments of tile i+1 are in flight while tile i is on the matrix
+    // cores and its epilogue stores drain (register double buffering)
+    const int64_t wave_p0 = ((int64_t)blockIdx.x * 4 + wave) * (32 * kTilesPerWave);
+    if (wave_p0 >= P) return;  // wave-uniform: no pixel of this wave exists
+    const float *xbase = x + n * CIN * P;
+
+    float xnext[CIN / 2];
+    {
+        const int64_t p = wave_p0 + li;
 #pragma unroll
-        for (int q = 0; q < PIX; ++q) a[q] = b[q] = 0.0f;
+        for (int s = 0; s < CIN / 2; ++s) xnext[s] = p < P ? xbase[(int64_t)(2 * s + lk) * P + p] : 0.0f;
+    }
+    for (int it = 0; it < kTilesPerWave; ++it) {
+        const int64_t tile_p0 = wave_p0 + (int64_t)it * 32;
+        if (tile_p0 >= P) break;  // wave-uniform
+        const int64_t p = tile_p0 + li;
+        const bool valid = p < P;
+        float xb[CIN / 2];
 #pragma unroll
-        for (int ci = 0; ci < CIN; ++ci) {
-            const float ua = wa[ci], ub = wb[ci];
+        for (int s = 0; s < CIN / 2; ++s) xb[s] = xnext[s];
+        if (it + 1 < kTilesPerWave) {
+            const int64_t pn = p + 32;
 #pragma unroll
-            for (int q = 0; q < PIX; ++q) {
-                a[q] = fmaf(ua, xr[q][ci], a[q]);
-                b[q] = fmaf(ub, xr[q][ci], b[q]);
-            }
+            for (int s = 0; s < CIN / 2; ++s) xnext[s] = pn < P ? xbase[(int64_t)(2 * s + lk) * P + pn] : 0.0f;
         }
-        const float ba = bias ? bias[c] : 0.0f, bb = bias ? bias[c + C] : 0.0f;
-        const float mu = bn_mean ? bn_mean[c] : 0.0f, is = bn_mean ? bn_invstd[c] : 1.0f;
+        float *yn = y + n * (int64_t)C * P + p;
+        uint32_t *sn = sel + n * (int64_t)C * PW + (p >> 5);
 #pragma unroll
-        for (int q = 0; q < PIX; ++q) {
-            const float va = bias ? a[q] + ba : a[q], vb = bias ? b[q] + bb : b[q];
-            const bool tb = mfm_takes_b(va, vb);
-            const unsigned long long word = __ballot(valid[q] && tb);
-            float v = tb ? vb : va;
-            if (bn_mean) v = (v - mu) * is;
-            if (valid[q]) {
-                yn[(int64_t)c * P + (int64_t)q * kBlock] = v;
-                if ((threadIdx.x & 63) == 0) sn[(int64_t)c * PW + q * (kBlock / 64)] = word;
+        for (int t = 0; t < TILES; ++t) {
+            f32x16 acc_a = {0}, acc_b = {0};
+            const float *wa = w_s + (t * 32 + li) * PITCH + lk;
+            const float *wb = wa + CP * PITCH;
+#pragma unroll
+            for (int s = 0; s < CIN / 2; ++s) {
+                acc_a = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[2 * s], xb[s], acc_a, 0, 0, 0);
+                acc_b = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[2 * s], xb[s], acc_b, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = t * 32 + mfma_row(r, lane);
+                const bool live = c < C;
+                float va = acc_a[r], vb = acc_b[r];
+                if (bias && live) {
+                    va += bias[c];
+                    vb += bias[c + C];
+                }
+                const bool tb = live && mfm_takes_b(va, vb);
+                // lanes 0-31 hold channel c_lo for 32 pixels, lanes 32-63 channel c_lo + 4: one ballot, two 32-bit words
+                const unsigned long long word = __ballot(valid && tb);
+                float v = tb ? vb : va;
+                if (bn_mean && live) v = (v - bn_mean[c]) * bn_invstd[c];
+                if (live && valid) yn[(int64_t)c * P] = v;
+                if (live && li == 0) sn[(int64_t)c * PW] = lk ? (uint32_t)(word >> 32) : (uint32_t)word;
             }
         }
     }
 }
 
-// grid (ceil(P / (256 PIX)), N, CIN / CHUNK): blockIdx.z owns input channels [z * CHUNK, (z + 1) * CHUNK).
-// gscale (C, nullable): the following BatchNorm's backward, gy * invstd[c].
-template <int CIN, int CHUNK, int PIX>
+// grid (ceil(P / 128), N).  MT = ceil(CIN / 32) output tiles (input channels).  LDS: w_s[2C][32 MT + 1], columns >= CIN zero.
+template <int CIN, int MT>
 __global__ __launch_bounds__(kBlock) void conv1x1_mfm_backward_kernel(const float *__restrict__ gy,
-                                                                      const unsigned long long *__restrict__ sel,
+                                                                      const uint32_t *__restrict__ sel,
                                                                       const float *__restrict__ weight,
                                                                       const float *__restrict__ gscale,
                                                                       float *__restrict__ gx, int C, int64_t P,
                                                                       int64_t PW) {
+    extern __shared__ __attribute__((aligned(16))) float w_s[];
+    constexpr int CW = MT * 32, PITCH = CW + 1;
+    for (int i = threadIdx.x; i < 2 * C * CW; i += kBlock) {
+        const int row = i / CW, ci = i - row * CW;
+        w_s[row * PITCH + ci] = ci < CIN ? weight[(int64_t)row * CIN + ci] : 0.0f;
+    }
+    __syncthreads();
+
     const int64_t n = blockIdx.y;
-    const int64_t p0 = (int64_t)blockIdx.x * (kBlock * PIX) + threadIdx.x;
-    if (p0 >= P) return;
-    const int ci0 = blockIdx.z * CHUNK;
-    const float *gn = gy + n * (int64_t)C * P + p0;
-    const unsigned long long *sn = sel + n * (int64_t)C * PW + (p0 >> 6);
-    const int lane = threadIdx.x & 63;
-    bool valid[PIX];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, lk = lane >> 5;
+    const int64_t p = (int64_t)blockIdx.x * kPixPerBlock + wave * 32 + li;
+    const bool valid = p < P;
+    if ((int64_t)blockIdx.x * kPixPerBlock + wave * 32 >= P) return;
+
+    const float *gn = gy + n * (int64_t)C * P + (valid ? p : 0);
+    const uint32_t *sn = sel + n * (int64_t)C * PW + ((valid ? p : 0) >> 5);
+    f32x16 acc[MT];
 #pragma unroll
-    for (int q = 0; q < PIX; ++q) valid[q] = p0 + (int64_t)q * kBlock < P;
-    float acc[PIX][CHUNK];
+    for (int m = 0; m < MT; ++m) acc[m] = (f32x16){0};
+    // K runs over the 2C rows of W^T; step s feeds channel pair c = 2 s + lk to BOTH halves: the gradient reaches the
+    // selected half only (max-feature-map backward), the other B fragment is zero
+    const int steps = (C + 1) >> 1;
+    for (int s = 0; s < steps; ++s) {
+        const int c = 2 * s + lk;
+        const bool live = c < C;
+        float g = (live && valid) ? gn[(int64_t)c * P] : 0.0f;
+        if (gscale && live) g *= gscale[c];
+        const bool tb = live && ((sn[(int64_t)(live ? c : 0) * PW] >> li) & 1u);
+        const float ga = tb ? 0.0f : g, gb = tb ? g : 0.0f;
+        const float *wa = w_s + (live ? c : 0) * PITCH + li;
+        const float *wb = w_s + ((live ? c : 0) + C) * PITCH + li;
 #pragma unroll
-    for (int q = 0; q < PIX; ++q)
-#pragma unroll
-        for (int k = 0; k < CHUNK; ++k) acc[q][k] = 0.0f;
-    for (int c = 0; c < C; ++c) {
-        const float sc = gscale ? gscale[c] : 1.0f;
-        float ga[PIX], gb[PIX];
-#pragma unroll
-        for (int q = 0; q < PIX; ++q) {
-            float g = valid[q] ? gn[(int64_t)c * P + (int64_t)q * kBlock] : 0.0f;
-            if (gscale) g *= sc;
-            const bool tb = valid[q] && ((sn[(int64_t)c * PW + q * (kBlock / 64)] >> lane) & 1ull);
-            ga[q] = tb ? 0.0f : g;
-            gb[q] = tb ? g : 0.0f;
-        }
-        const float *wa = weight + (int64_t)c * CIN + ci0;
-        const float *wb = weight + (int64_t)(c + C) * CIN + ci0;
-#pragma unroll
-        for (int k = 0; k < CHUNK; ++k) {
-            const float ua = wa[k], ub = wb[k];
-#pragma unroll
-            for (int q = 0; q < PIX; ++q) {
-                acc[q][k] = fmaf(ga[q], ua, acc[q][k]);
-                acc[q][k] = fmaf(gb[q], ub, acc[q][k]);
-            }
+        for (int m = 0; m < MT; ++m) {
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(live ? wa[32 * m] : 0.0f, ga, acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(live ? wb[32 * m] : 0.0f, gb, acc[m], 0, 0, 0);
         }
     }
+    if (!valid) return;
+    float *xn = gx + n * CIN * P + p;
 #pragma unroll
-    for (int q = 0; q < PIX; ++q) {
-        if (!valid[q]) continue;
-        float *xn = gx + n * CIN * P + (int64_t)ci0 * P + p0 + (int64_t)q * kBlock;
+    for (int m = 0; m < MT; ++m) {
 #pragma unroll
-        for (int k = 0; k < CHUNK; ++k) xn[(int64_t)k * P] = acc[q][k];
+        for (int r = 0; r < 16; ++r) {
+            const int ci = m * 32 + mfma_row(r, lane);
+            if (ci < CIN) xn[(int64_t)ci * P] = acc[m][r];
+        }
     }
 }
 
 constexpr int64_t kMaxGridY = 65535;
-constexpr int64_t kWantBlocks = 2048;  // ~8 workgroups per CU keep the scalar-load latency covered
 
-template <int CIN, int PIX>
-void launch_fwd_pix(const float *x, const float *w, const float *b, const float *bn_mean, const float *bn_invstd, float *y,
-                    unsigned long long *sel, int64_t N, int64_t C, int64_t P, int64_t z, hipStream_t st) {
-    const int64_t cper = ceil_div(C, z);
-    z = ceil_div(C, cper);
-    const dim3 grid((unsigned)ceil_div(P, kBlock * PIX), (unsigned)N, (unsigned)z);
-    hipLaunchKernelGGL((conv1x1_mfm_forward_kernel<CIN, PIX>), grid, dim3(kBlock), 0, st, x, w, b, bn_mean, bn_invstd, y,
-                       sel, (int)C, (int)cper, P, ceil_div(P, 64));
+template <typename K>
+void opt_in_lds(K kernel, size_t bytes) {
+    if (bytes > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)bytes);
 }
-template <int CIN, int BIGPIX>
+
+template <int CIN, int TILES>
 void launch_fwd(const float *x, const float *w, const float *b, const float *bn_mean, const float *bn_invstd, float *y,
-                unsigned long long *sel, int64_t N, int64_t C, int64_t P, hipStream_t st) {
-    const int64_t blocks = ceil_div(P, kBlock) * N;
-    if (blocks >= 2 * kWantBlocks) {  // plenty of parallelism: amortise the scalar weight loads over BIGPIX pixels
-        launch_fwd_pix<CIN, BIGPIX>(x, w, b, bn_mean, bn_invstd, y, sel, N, C, P, 1, st);
-        return;
-    }
-    int64_t z = blocks >= kWantBlocks ? 1 : ceil_div(kWantBlocks, blocks);
-    if (z > 8) z = 8;
-    if (z > C) z = C;
-    launch_fwd_pix<CIN, 1>(x, w, b, bn_mean, bn_invstd, y, sel, N, C, P, z, st);
+                uint32_t *sel, int64_t N, int64_t C, int64_t P, hipStream_t st) {
+    const size_t lds = (size_t)2 * TILES * 32 * (CIN + 1) * sizeof(float);
+    opt_in_lds(conv1x1_mfm_forward_kernel<CIN, TILES>, lds);
+    const dim3 grid((unsigned)ceil_div(P, kFwdPixPerBlock), (unsigned)N);
+    hipLaunchKernelGGL((conv1x1_mfm_forward_kernel<CIN, TILES>), grid, dim3(kBlock), lds, st, x, w, b, bn_mean, bn_invstd, y,
+                       sel, (int)C, P, ceil_div(P, 32));
 }
-template <int CIN, int CHUNK, int PIX>
-void launch_bwd_chunk(const float *gy, const unsigned long long *sel, const float *w, const float *gscale, float *gx,
-                      int64_t N, int64_t C, int64_t P, hipStream_t st) {
-    const dim3 grid((unsigned)ceil_div(P, kBlock * PIX), (unsigned)N, (unsigned)(CIN / CHUNK));
-    hipLaunchKernelGGL((conv1x1_mfm_backward_kernel<CIN, CHUNK, PIX>), grid, dim3(kBlock), 0, st, gy, sel, w, gscale, gx,
-                       (int)C, P, ceil_div(P, 64));
-}
-template <int CIN, int SMALL, int BIGPIX>
-void launch_bwd(const float *gy, const unsigned long long *sel, const float *w, const float *gscale, float *gx, int64_t N,
-                int64_t C, int64_t P, hipStream_t st) {
-    const int64_t blocks = ceil_div(P, kBlock) * N;
-    if (blocks >= 2 * kWantBlocks)
-        launch_bwd_chunk<CIN, CIN, BIGPIX>(gy, sel, w, gscale, gx, N, C, P, st);
-    else if (blocks >= kWantBlocks)
-        launch_bwd_chunk<CIN, CIN, 1>(gy, sel, w, gscale, gx, N, C, P, st);
-    else
-        launch_bwd_chunk<CIN, SMALL, 1>(gy, sel, w, gscale, gx, N, C, P, st);
+
+template <int CIN, int MT>
+void launch_bwd(const float *gy, const uint32_t *sel, const float *w, const float *gscale, float *gx, int64_t N, int64_t C,
+                int64_t P, hipStream_t st) {
+    const size_t lds = (size_t)2 * C * (MT * 32 + 1) * sizeof(float);
+    opt_in_lds(conv1x1_mfm_backward_kernel<CIN, MT>, lds);
+    const dim3 grid((unsigned)ceil_div(P, kPixPerBlock), (unsigned)N);
+    hipLaunchKernelGGL((conv1x1_mfm_backward_kernel<CIN, MT>), grid, dim3(kBlock), lds, st, gy, sel, w, gscale, gx, (int)C, P,
+                       ceil_div(P, 32));
 }
 
 }  // namespace
@@ -205,40 +218,50 @@ int advstep_conv1x1_mfm_supported(int64_t Cin) { return Cin == 32 || Cin == 48 |
 
 size_t advstep_conv1x1_mfm_sel_bytes(int64_t N, int64_t C, int64_t P) {
     if (N <= 0 || C <= 0 || P <= 0) return 0;
-    return (size_t)N * (size_t)C * (size_t)ceil_div(P, 64) * sizeof(unsigned long long);
+    return (size_t)N * (size_t)C * (size_t)ceil_div(P, 32) * sizeof(uint32_t);
 }
 
 int advstep_conv1x1_mfm_forward_f32(const float *x, const float *weight, const float *bias, const float *bn_mean,
-                                    const float *bn_invstd, float *y, uint64_t *sel, int64_t N, int64_t Cin, int64_t C,
+                                    const float *bn_invstd, float *y, void *sel, int64_t N, int64_t Cin, int64_t C,
                                     int64_t P, advstep_stream_t stream) {
     C11_REQUIRE(N >= 0 && C >= 0 && P >= 0 && advstep_conv1x1_mfm_supported(Cin));
     if (N == 0 || C == 0 || P == 0) return ADVSTEP_OK;
-    C11_REQUIRE(x && weight && y && sel && N <= kMaxGridY && C <= INT32_MAX && ((reinterpret_cast<uintptr_t>(sel) & 7u) == 0));
+    C11_REQUIRE(x && weight && y && sel && N <= kMaxGridY && C <= 64 && ((reinterpret_cast<uintptr_t>(sel) & 3u) == 0));
     C11_REQUIRE((bn_mean == nullptr) == (bn_invstd == nullptr));
-    auto *s64 = reinterpret_cast<unsigned long long *>(sel);
+    auto *s32 = static_cast<uint32_t *>(sel);
     hipStream_t st = as_stream(stream);
+    const bool two = C > 32;
     switch (Cin) {
-        case 32: launch_fwd<32, 2>(x, weight, bias, bn_mean, bn_invstd, y, s64, N, C, P, st); break;
-        case 48: launch_fwd<48, 2>(x, weight, bias, bn_mean, bn_invstd, y, s64, N, C, P, st); break;
-        default: launch_fwd<64, 1>(x, weight, bias, bn_mean, bn_invstd, y, s64, N, C, P, st); break;
+        case 32:
+            two ? launch_fwd<32, 2>(x, weight, bias, bn_mean, bn_invstd, y, s32, N, C, P, st)
+                : launch_fwd<32, 1>(x, weight, bias, bn_mean, bn_invstd, y, s32, N, C, P, st);
+            break;
+        case 48:
+            two ? launch_fwd<48, 2>(x, weight, bias, bn_mean, bn_invstd, y, s32, N, C, P, st)
+                : launch_fwd<48, 1>(x, weight, bias, bn_mean, bn_invstd, y, s32, N, C, P, st);
+            break;
+        default:
+            two ? launch_fwd<64, 2>(x, weight, bias, bn_mean, bn_invstd, y, s32, N, C, P, st)
+                : launch_fwd<64, 1>(x, weight, bias, bn_mean, bn_invstd, y, s32, N, C, P, st);
+            break;
     }
     return status_after_launch();
 }
 
-int advstep_conv1x1_mfm_backward_f32(const float *gy, const uint64_t *sel, const float *weight, const float *gscale,
-                                     float *gx, int64_t N, int64_t Cin, int64_t C, int64_t P, advstep_stream_t stream) {
+int advstep_conv1x1_mfm_backward_f32(const float *gy, const void *sel, const float *weight, const float *gscale, float *gx,
+                                     int64_t N, int64_t Cin, int64_t C, int64_t P, advstep_stream_t stream) {
     C11_REQUIRE(N >= 0 && C >= 0 && P >= 0 && advstep_conv1x1_mfm_supported(Cin));
     if (N == 0 || P == 0) return ADVSTEP_OK;
-    C11_REQUIRE(gx && N <= kMaxGridY && C <= INT32_MAX);
+    C11_REQUIRE(gx && N <= kMaxGridY && C <= 64);
     hipStream_t st = as_stream(stream);
     if (C == 0)
         return hipMemsetAsync(gx, 0, (size_t)N * Cin * P * sizeof(float), st) == hipSuccess ? ADVSTEP_OK : ADVSTEP_ELAUNCH;
     C11_REQUIRE(gy && sel && weight);
-    auto *s64 = reinterpret_cast<const unsigned long long *>(sel);
+    auto *s32 = static_cast<const uint32_t *>(sel);
     switch (Cin) {
-        case 32: launch_bwd<32, 8, 2>(gy, s64, weight, gscale, gx, N, C, P, st); break;
-        case 48: launch_bwd<48, 12, 2>(gy, s64, weight, gscale, gx, N, C, P, st); break;
-        default: launch_bwd<64, 16, 1>(gy, s64, weight, gscale, gx, N, C, P, st); break;
+        case 32: launch_bwd<32, 1>(gy, s32, weight, gscale, gx, N, C, P, st); break;
+        case 48: launch_bwd<48, 2>(gy, s32, weight, gscale, gx, N, C, P, st); break;
+        default: launch_bwd<64, 2>(gy, s32, weight, gscale, gx, N, C, P, st); break;
     }
     return status_after_launch();
 }

@@ -170,7 +170,7 @@ class _Conv1x1Mfm(torch.autograd.Function):
         if not lib.advstep_conv1x1_mfm_supported(Cin):
             raise ValueError(f"conv1x1_mfm supports Cin in (32, 48, 64), got {Cin}")
         y = torch.empty((N, C, H, W), dtype=x.dtype, device=x.device)
-        sel = torch.empty(max(lib.advstep_conv1x1_mfm_sel_bytes(N, C, P) // 8, 1), dtype=torch.int64, device=x.device)
+        sel = torch.empty(max(lib.advstep_conv1x1_mfm_sel_bytes(N, C, P), 4), dtype=torch.uint8, device=x.device)
         with _Launch("conv1x1_mfm_forward", x.device):
             st = lib.advstep_conv1x1_mfm_forward_f32(x.data_ptr(), weight.data_ptr(),
                                                      bias.data_ptr() if bias is not None else None, bn_mean, bn_invstd,

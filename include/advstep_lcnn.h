@@ -72,20 +72,21 @@ int advstep_conv5_mfm_pool2_backward_f32(const float *gy, const uint8_t *idx, co
                                          int64_t C, int64_t H, int64_t W, advstep_stream_t stream);
 
 /* ---- 1x1 blocks fused: Conv2d(Cin, 2C, (1,1)) -> MaxFeatureMap2D  (src/models/lcnn.py:125-126,132-133,139-140,146-147)
+ * A skinny GEMM (K = Cin) run on the matrix cores (fp32-in / fp32-accumulate MFMA: exact f32).
  * x (N, Cin, P) with P = H*W, weight (2C, Cin), bias (2C) or NULL -> y (N, C, P); sel gets ONE bit per output
- * (N * C * ceil(P/64) 64-bit words, bit = pixel % 64, set when the second channel half won).  The 2C-channel conv
- * output is never written.  Cin must be one advstep_conv1x1_mfm_supported() accepts (32, 48, 64: LCNN's).
+ * (N * C * ceil(P/32) 32-bit words, bit = pixel % 32, set when the second channel half won).  The 2C-channel conv
+ * output is never written.  Cin must be one advstep_conv1x1_mfm_supported() accepts (32, 48, 64: LCNN's); C <= 64.
  * bn_mean / bn_invstd (C) or both NULL: the eval-mode BatchNorm2d(affine=False) that follows each of these blocks
  * (lcnn.py:127,134,141,148), y = (max - mean[c]) * invstd[c], folded into the epilogue. */
 int advstep_conv1x1_mfm_supported(int64_t Cin);
 size_t advstep_conv1x1_mfm_sel_bytes(int64_t N, int64_t C, int64_t P);
 int advstep_conv1x1_mfm_forward_f32(const float *x, const float *weight, const float *bias, const float *bn_mean,
-                                    const float *bn_invstd, float *y, uint64_t *sel, int64_t N, int64_t Cin, int64_t C,
+                                    const float *bn_invstd, float *y, void *sel, int64_t N, int64_t Cin, int64_t C,
                                     int64_t P, advstep_stream_t stream);
 
 /* Input gradient of the block above: gx (N, Cin, P) = sum_c (gy[n, c, p] * gscale[c]) * weight[selected half of
  * pair c, :]; gscale (C) = the BatchNorm's invstd, or NULL. */
-int advstep_conv1x1_mfm_backward_f32(const float *gy, const uint64_t *sel, const float *weight, const float *gscale,
+int advstep_conv1x1_mfm_backward_f32(const float *gy, const void *sel, const float *weight, const float *gscale,
                                      float *gx, int64_t N, int64_t Cin, int64_t C, int64_t P, advstep_stream_t stream);
 
 /* ---- recurrent part of a (bi)directional LSTM layer  (src/models/lcnn.py:24-46: nn.LSTM(160, 80, bidirectional)) ------

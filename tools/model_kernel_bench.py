@@ -72,7 +72,7 @@ def main():
         bb = torch.randn(2 * c, device=dev)
         mean, invstd = torch.randn(c, device=dev), torch.rand(c, device=dev) + 0.5
         yy = torch.empty(B, c, h, wd, device=dev)
-        sel = torch.empty(lib.advstep_conv1x1_mfm_sel_bytes(B, c, P) // 8, dtype=torch.int64, device=dev)
+        sel = torch.empty(lib.advstep_conv1x1_mfm_sel_bytes(B, c, P), dtype=torch.uint8, device=dev)
         gxx = torch.empty_like(xx)
         moved = 4.0 * B * P * (cin + c)
         timeit(f"conv1x1_mfm_forward  {name} ({cin}->{2 * c}, {h}x{wd})", lambda: lib.advstep_conv1x1_mfm_forward_f32(
