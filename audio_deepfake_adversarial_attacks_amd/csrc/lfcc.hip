@@ -82,11 +82,18 @@ __global__ __launch_bounds__(kBlock) void lfcc_bands_kernel(const float2 *__rest
     if (threadIdx.x == 0) bmax[b * gridDim.x + blockIdx.x] = r;
 }
 
-__global__ __launch_bounds__(kBlock) void lfcc_reduce_max_kernel(const float *__restrict__ bmax, int64_t n,
-                                                                 float *__restrict__ stats) {
-    __shared__ float lds[kBlock / 64];
+// one workgroup of 1024 threads, 16-byte loads: ~26 K block maxima at B = 128
+__global__ __launch_bounds__(1024) void lfcc_reduce_max_kernel(const float *__restrict__ bmax, int64_t n,
+                                                               float *__restrict__ stats) {
+    __shared__ float lds[1024 / 64];
     float v = -INFINITY;
-    for (int64_t i = threadIdx.x; i < n; i += kBlock) v = max_nan(v, bmax[i]);
+    const int64_t n4 = ((reinterpret_cast<uintptr_t>(bmax) & 15u) == 0) ? n / 4 : 0;
+    const float4 *b4 = reinterpret_cast<const float4 *>(bmax);
+    for (int64_t i = threadIdx.x; i < n4; i += 1024) {
+        const float4 q = b4[i];
+        v = max_nan(max_nan(v, q.x), max_nan(max_nan(q.y, q.z), q.w));
+    }
+    for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += 1024) v = max_nan(v, bmax[i]);
     v = block_max(v, lds);
     if (threadIdx.x == 0) {
         stats[0] = v;
@@ -466,7 +473,7 @@ int advstep_lfcc_bands_f32(const float *spec, const int32_t *fb_start, const flo
 
 int advstep_lfcc_reduce_max_f32(const float *block_max, int64_t n, float *stats, advstep_stream_t stream) {
     LFCC_REQUIRE(n >= 1 && block_max && stats);
-    hipLaunchKernelGGL(lfcc_reduce_max_kernel, dim3(1), dim3(kBlock), 0, as_stream(stream), block_max, n, stats);
+    hipLaunchKernelGGL(lfcc_reduce_max_kernel, dim3(1), dim3(1024), 0, as_stream(stream), block_max, n, stats);
     return status_after_launch();
 }
 

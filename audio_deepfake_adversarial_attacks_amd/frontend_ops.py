@@ -12,8 +12,15 @@ from typing import NamedTuple
 
 import torch
 
-from . import _lib
+import os
+
+from . import _lib, fft_plans
 from .hip_ops import _Launch, _stream
+
+
+def _direct_fft_enabled() -> bool:
+    """ADVSTEP_DIRECT_FFT=0 routes the frontend's FFTs through torch.fft (A/B measurements); default on."""
+    return os.environ.get("ADVSTEP_DIRECT_FFT", "1") != "0"
 
 
 class FilterbankTables(NamedTuple):
@@ -123,9 +130,10 @@ class _LfccFromWaveform(torch.autograd.Function):
             st = lib.advstep_stft_frames_f32(x.data_ptr(), window.data_ptr(), frames.data_ptr(), B, T, NF, hop, nfft,
                                              _stream(dev))
         _lib.check(st, "advstep_stft_frames_f32")
-        spec = torch.fft.rfft(frames, dim=-1)              # (B, NF, F) complex64, contiguous
+        sr = torch.empty((B, NF, F, 2), dtype=torch.float32, device=dev)      # interleaved complex spectrum
+        if not (_direct_fft_enabled() and fft_plans.rfft_into(frames.view(B * NF, nfft), sr.view(B * NF, F, 2))):
+            sr = torch.view_as_real(torch.fft.rfft(frames, dim=-1))           # same library, plus a defensive input clone
         del frames
-        sr = torch.view_as_real(spec)
         band_db = torch.empty((B, NF, M), dtype=torch.float32, device=dev)
         nblk = lib.advstep_lfcc_block_count(B, M, NF)
         block_max = torch.empty(max(nblk, 1), dtype=torch.float32, device=dev)
@@ -165,7 +173,9 @@ class _LfccFromWaveform(torch.autograd.Function):
                                                      _stream(dev))
             _lib.check(st, "advstep_lfcc_bands_backward_f32")
         # gradient of the one-sided real FFT = unnormalised c2r inverse of the pre-scaled half spectrum
-        dframes = torch.fft.irfft(torch.view_as_complex(dspec), n=nfft, dim=-1, norm="forward").contiguous()
+        dframes = torch.empty((B, NF, nfft), dtype=torch.float32, device=dev)
+        if not (_direct_fft_enabled() and fft_plans.irfft_into(dspec.view(B * NF, F, 2), dframes.view(B * NF, nfft))):
+            dframes = torch.fft.irfft(torch.view_as_complex(dspec), n=nfft, dim=-1, norm="forward").contiguous()
         dx = torch.empty((B, T), dtype=torch.float32, device=dev)
         with _Launch("stft_overlap_add", dev):
             st = lib.advstep_stft_overlap_add_f32(dframes.data_ptr(), window.data_ptr(), dx.data_ptr(), B, T, NF, hop, nfft,
