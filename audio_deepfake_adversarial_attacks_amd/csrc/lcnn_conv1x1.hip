@@ -52,10 +52,18 @@ __global__ __launch_bounds__(kBlock) void conv1x1_mfm_forward_kernel(const float
                                                                      int C, int64_t P, int64_t PW) {
     extern __shared__ __attribute__((aligned(16))) float w_s[];
     constexpr int CP = TILES * 32, PITCH = CIN + 1;
+    float *par_s = w_s + 2 * CP * PITCH;  // [4][CP]: bias of half a, bias of half b, BN mean, BN invstd
     for (int i = threadIdx.x; i < 2 * CP * CIN; i += kBlock) {
         const int row = i / CIN, ci = i - row * CIN;
         const int half = row / CP, c = row - half * CP;
         w_s[row * PITCH + ci] = c < C ? weight[(int64_t)(half * C + c) * CIN + ci] : 0.0f;
+    }
+    for (int c = threadIdx.x; c < CP; c += kBlock) {
+        const bool live = c < C;
+        par_s[c] = (bias && live) ? bias[c] : 0.0f;
+        par_s[CP + c] = (bias && live) ? bias[c + C] : 0.0f;
+        par_s[2 * CP + c] = (bn_mean && live) ? bn_mean[c] : 0.0f;
+        par_s[3 * CP + c] = (bn_mean && live) ? bn_invstd[c] : 1.0f;
     }
     __syncthreads();
 
@@ -98,20 +106,16 @@ __global__ __launch_bounds__(kBlock) void conv1x1_mfm_forward_kernel(const float
                 acc_a = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[2 * s], xb[s], acc_a, 0, 0, 0);
                 acc_b = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[2 * s], xb[s], acc_b, 0, 0, 0);
             }
+            // branch-free epilogue: per-channel parameters come from LDS (identity values where absent)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int c = t * 32 + mfma_row(r, lane);
                 const bool live = c < C;
-                float va = acc_a[r], vb = acc_b[r];
-                if (bias && live) {
-                    va += bias[c];
-                    vb += bias[c + C];
-                }
-                const bool tb = live && mfm_takes_b(va, vb);
+                const float va = acc_a[r] + par_s[c], vb = acc_b[r] + par_s[CP + c];
+                const bool tb = mfm_takes_b(va, vb);
                 // lanes 0-31 hold channel c_lo for 32 pixels, lanes 32-63 channel c_lo + 4: one ballot, two 32-bit words
-                const unsigned long long word = __ballot(valid && tb);
-                float v = tb ? vb : va;
-                if (bn_mean && live) v = (v - bn_mean[c]) * bn_invstd[c];
+                const unsigned long long word = __ballot(valid && live && tb);
+                const float v = ((tb ? vb : va) - par_s[2 * CP + c]) * par_s[3 * CP + c];
                 if (live && valid) yn[(int64_t)c * P] = v;
                 if (live && li == 0) sn[(int64_t)c * PW] = lk ? (uint32_t)(word >> 32) : (uint32_t)word;
             }
@@ -129,10 +133,12 @@ __global__ __launch_bounds__(kBlock) void conv1x1_mfm_backward_kernel(const floa
                                                                       int64_t PW) {
     extern __shared__ __attribute__((aligned(16))) float w_s[];
     constexpr int CW = MT * 32, PITCH = CW + 1;
+    float *gs_s = w_s + 2 * C * PITCH;  // [C]: the following BatchNorm's invstd (1 where absent)
     for (int i = threadIdx.x; i < 2 * C * CW; i += kBlock) {
         const int row = i / CW, ci = i - row * CW;
         w_s[row * PITCH + ci] = ci < CIN ? weight[(int64_t)row * CIN + ci] : 0.0f;
     }
+    for (int c = threadIdx.x; c < C; c += kBlock) gs_s[c] = gscale ? gscale[c] : 1.0f;
     __syncthreads();
 
     const int64_t n = blockIdx.y;
@@ -152,8 +158,7 @@ __global__ __launch_bounds__(kBlock) void conv1x1_mfm_backward_kernel(const floa
     for (int s = 0; s < steps; ++s) {
         const int c = 2 * s + lk;
         const bool live = c < C;
-        float g = (live && valid) ? gn[(int64_t)c * P] : 0.0f;
-        if (gscale && live) g *= gscale[c];
+        const float g = (live && valid) ? gn[(int64_t)c * P] * gs_s[c] : 0.0f;
         const bool tb = live && ((sn[(int64_t)(live ? c : 0) * PW] >> li) & 1u);
         const float ga = tb ? 0.0f : g, gb = tb ? g : 0.0f;
         const float *wa = w_s + (live ? c : 0) * PITCH + li;
@@ -188,7 +193,7 @@ void opt_in_lds(K kernel, size_t bytes) {
 template <int CIN, int TILES>
 void launch_fwd(const float *x, const float *w, const float *b, const float *bn_mean, const float *bn_invstd, float *y,
                 uint32_t *sel, int64_t N, int64_t C, int64_t P, hipStream_t st) {
-    const size_t lds = (size_t)2 * TILES * 32 * (CIN + 1) * sizeof(float);
+    const size_t lds = (size_t)(2 * TILES * 32 * (CIN + 1) + 4 * TILES * 32) * sizeof(float);
     opt_in_lds(conv1x1_mfm_forward_kernel<CIN, TILES>, lds);
     const dim3 grid((unsigned)ceil_div(P, kFwdPixPerBlock), (unsigned)N);
     hipLaunchKernelGGL((conv1x1_mfm_forward_kernel<CIN, TILES>), grid, dim3(kBlock), lds, st, x, w, b, bn_mean, bn_invstd, y,
@@ -198,7 +203,7 @@ void launch_fwd(const float *x, const float *w, const float *b, const float *bn_
 template <int CIN, int MT>
 void launch_bwd(const float *gy, const uint32_t *sel, const float *w, const float *gscale, float *gx, int64_t N, int64_t C,
                 int64_t P, hipStream_t st) {
-    const size_t lds = (size_t)2 * C * (MT * 32 + 1) * sizeof(float);
+    const size_t lds = (size_t)(2 * C * (MT * 32 + 1) + C) * sizeof(float);
     opt_in_lds(conv1x1_mfm_backward_kernel<CIN, MT>, lds);
     const dim3 grid((unsigned)ceil_div(P, kPixPerBlock), (unsigned)N);
     hipLaunchKernelGGL((conv1x1_mfm_backward_kernel<CIN, MT>), grid, dim3(kBlock), lds, st, gy, sel, w, gscale, gx, (int)C, P,

@@ -60,6 +60,32 @@ __global__ __launch_bounds__(BLOCK) void k_tile(const float4 *__restrict__ adv, 
     }
 }
 
+// nt on the two cold streams (adv, orig) only; grad (just produced by the backward pass) and the store stay default
+template <int BLOCK, int VECS>
+__global__ __launch_bounds__(BLOCK) void k_mixed(const float4 *__restrict__ adv, const float4 *__restrict__ grad,
+                                                 const float4 *__restrict__ orig, float4 *out, long n4, long ntiles,
+                                                 float alpha, float eps) {
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long base = tile * (BLOCK * VECS) + threadIdx.x;
+        float4 a[VECS], g[VECS], x[VECS];
+#pragma unroll
+        for (int j = 0; j < VECS; ++j) {
+            const long i = base + (long)j * BLOCK;
+            if (i < n4) { a[j] = ld<true>(adv + i); g[j] = ld<false>(grad + i); x[j] = ld<true>(orig + i); }
+        }
+#pragma unroll
+        for (int j = 0; j < VECS; ++j) {
+            const long i = base + (long)j * BLOCK;
+            if (i < n4) st<false>(out + i, step4(a[j], g[j], x[j], alpha, eps));
+        }
+    }
+}
+template <int BLOCK, int VECS>
+void launch_mixed(const float4 *a, const float4 *g, const float4 *x, float4 *o, long n4, hipStream_t s) {
+    long ntiles = (n4 + BLOCK * VECS - 1) / (BLOCK * VECS);
+    hipLaunchKernelGGL((k_mixed<BLOCK, VECS>), dim3((int)ntiles), dim3(BLOCK), 0, s, a, g, x, o, n4, ntiles, 2.0f / 255, 0.003f);
+}
+
 struct Variant { const char *name; void (*launch)(const float4 *, const float4 *, const float4 *, float4 *, long, hipStream_t); };
 
 template <int BLOCK, int VECS, bool NTLD, bool NTST, int MAXGRID>
@@ -97,6 +123,9 @@ int main(int argc, char **argv) {
         {"b256 v4 grid 512 strided ", launch_tile<256, 4, false, false, 512>},
         {"b256 v2 grid 2048 strided", launch_tile<256, 2, false, false, 2048>},
         {"b256 v1                  ", launch_tile<256, 1, false, false, 0>},
+        {"b256 v1 nt-load          ", launch_tile<256, 1, true, false, 0>},
+        {"b256 v1 nt adv+orig only ", launch_mixed<256, 1>},
+        {"b256 v2 nt adv+orig only ", launch_mixed<256, 2>},
     };
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -111,9 +140,15 @@ int main(int argc, char **argv) {
             CK(hipEventRecord(e0, 0));
             for (int i = 0; i < launches; ++i) { int s = i % sets; v.launch((float4 *)adv[s], (float4 *)grad[s], (float4 *)orig[s], (float4 *)out[s], n4, 0); }
             CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms_cold, e0, e1));
+            // in-situ-like: adv / orig / out cold (rotating), grad hot (one buffer)
+            float ms_mix;
+            CK(hipEventRecord(e0, 0));
+            for (int i = 0; i < launches; ++i) { int s = i % sets; v.launch((float4 *)adv[s], (float4 *)grad[0], (float4 *)orig[s], (float4 *)out[s], n4, 0); }
+            CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms_mix, e0, e1));
             const double bytes = 16.0 * n;
-            printf("%s hot %7.2f us %6.0f GB/s | cold %7.2f us %6.0f GB/s\n", v.name, 1e3 * ms_hot / launches,
-                   bytes / (ms_hot / launches * 1e-3) / 1e9, 1e3 * ms_cold / launches, bytes / (ms_cold / launches * 1e-3) / 1e9);
+            printf("%s hot %7.2f us %6.0f GB/s | cold %7.2f us %6.0f GB/s | grad-hot %7.2f us %6.0f GB/s\n", v.name, 1e3 * ms_hot / launches,
+                   bytes / (ms_hot / launches * 1e-3) / 1e9, 1e3 * ms_cold / launches, bytes / (ms_cold / launches * 1e-3) / 1e9,
+                   1e3 * ms_mix / launches, bytes / (ms_mix / launches * 1e-3) / 1e9);
         }
         printf("--\n");
     }
