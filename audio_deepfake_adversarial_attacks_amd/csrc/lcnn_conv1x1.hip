@@ -27,9 +27,7 @@
 namespace {
 
 constexpr int kBlock = 256;          // 4 waves
-constexpr int kTilesPerWave = 1;     // 32-pixel tiles a wave walks (1: more, shorter waves measured fastest; 4 was 1.5x slower)
-constexpr int kPixPerBlock = 128;    // backward: 32 pixels per wave
-constexpr int kFwdPixPerBlock = 4 * 32 * kTilesPerWave;
+constexpr int kPixPerBlock = 128;    // 32 pixels per wave
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -40,7 +38,7 @@ inline int status_after_launch() { return hipGetLastError() == hipSuccess ? ADVS
 __device__ __forceinline__ bool mfm_takes_b(float a, float b) { return !(a != a) && !(a >= b); }
 __device__ __forceinline__ int mfma_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
-// grid (ceil(P / 512), N).  TILES = ceil(C / 32) channel tiles per half.
+// grid (ceil(P / 128), N).  TILES = ceil(C / 32) channel tiles per half.
 // LDS: w_s[2 * TILES * 32][CIN + 1]; rows [0, 32 TILES) = first half (zero beyond C), rows [32 TILES, 64 TILES) = second.
 template <int CIN, int TILES>
 __global__ __launch_bounds__(kBlock) void conv1x1_mfm_forward_kernel(const float *__restrict__ x,
@@ -69,62 +67,49 @@ __global__ __launch_bounds__(kBlock) void conv1x1_mfm_forward_kernel(const float
 
     const int64_t n = blockIdx.y;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, lk = lane >> 5;
-    // a wave walks kTilesPerWave pixel tiles; the B fragments of tile i+1 are in flight while tile i is on the matrix
-    // cores and its epilogue stores drain (register double buffering)
-    const int64_t wave_p0 = ((int64_t)blockIdx.x * 4 + wave) * (32 * kTilesPerWave);
+    // one 32-pixel tile per wave (walking several tiles per wave with register double buffering measured 1.5-1.8x
+    // slower: the live B fragments of two tiles push the kernel down to 1-2 waves per SIMD)
+    const int64_t wave_p0 = ((int64_t)blockIdx.x * 4 + wave) * 32;
     if (wave_p0 >= P) return;  // wave-uniform: no pixel of this wave exists
+    const int64_t p = wave_p0 + li;
+    const bool valid = p < P;
     const float *xbase = x + n * CIN * P;
+    float xb[CIN / 2];
+#pragma unroll
+    for (int s = 0; s < CIN / 2; ++s) xb[s] = valid ? xbase[(int64_t)(2 * s + lk) * P + p] : 0.0f;
 
-    float xnext[CIN / 2];
-    {
-        const int64_t p = wave_p0 + li;
+    float *yn = y + n * (int64_t)C * P + p;
+    uint32_t *sn = sel + n * (int64_t)C * PW + (p >> 5);
 #pragma unroll
-        for (int s = 0; s < CIN / 2; ++s) xnext[s] = p < P ? xbase[(int64_t)(2 * s + lk) * P + p] : 0.0f;
-    }
-    for (int it = 0; it < kTilesPerWave; ++it) {
-        const int64_t tile_p0 = wave_p0 + (int64_t)it * 32;
-        if (tile_p0 >= P) break;  // wave-uniform
-        const int64_t p = tile_p0 + li;
-        const bool valid = p < P;
-        float xb[CIN / 2];
+    for (int t = 0; t < TILES; ++t) {
+        f32x16 acc_a = {0}, acc_b = {0};
+        const float *wa = w_s + (t * 32 + li) * PITCH + lk;
+        const float *wb = wa + CP * PITCH;
 #pragma unroll
-        for (int s = 0; s < CIN / 2; ++s) xb[s] = xnext[s];
-        if (it + 1 < kTilesPerWave) {
-            const int64_t pn = p + 32;
-#pragma unroll
-            for (int s = 0; s < CIN / 2; ++s) xnext[s] = pn < P ? xbase[(int64_t)(2 * s + lk) * P + pn] : 0.0f;
+        for (int s = 0; s < CIN / 2; ++s) {
+            acc_a = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[2 * s], xb[s], acc_a, 0, 0, 0);
+            acc_b = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[2 * s], xb[s], acc_b, 0, 0, 0);
         }
-        float *yn = y + n * (int64_t)C * P + p;
-        uint32_t *sn = sel + n * (int64_t)C * PW + (p >> 5);
+        // branch-free epilogue: per-channel parameters come from LDS (identity values where absent)
 #pragma unroll
-        for (int t = 0; t < TILES; ++t) {
-            f32x16 acc_a = {0}, acc_b = {0};
-            const float *wa = w_s + (t * 32 + li) * PITCH + lk;
-            const float *wb = wa + CP * PITCH;
-#pragma unroll
-            for (int s = 0; s < CIN / 2; ++s) {
-                acc_a = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[2 * s], xb[s], acc_a, 0, 0, 0);
-                acc_b = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[2 * s], xb[s], acc_b, 0, 0, 0);
-            }
-            // branch-free epilogue: per-channel parameters come from LDS (identity values where absent)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int c = t * 32 + mfma_row(r, lane);
-                const bool live = c < C;
-                const float va = acc_a[r] + par_s[c], vb = acc_b[r] + par_s[CP + c];
-                const bool tb = mfm_takes_b(va, vb);
-                // lanes 0-31 hold channel c_lo for 32 pixels, lanes 32-63 channel c_lo + 4: one ballot, two 32-bit words
-                const unsigned long long word = __ballot(valid && live && tb);
-                const float v = ((tb ? vb : va) - par_s[2 * CP + c]) * par_s[3 * CP + c];
-                if (live && valid) yn[(int64_t)c * P] = v;
-                if (live && li == 0) sn[(int64_t)c * PW] = lk ? (uint32_t)(word >> 32) : (uint32_t)word;
-            }
+        for (int r = 0; r < 16; ++r) {
+            const int c = t * 32 + mfma_row(r, lane);
+            const bool live = c < C;
+            const float va = acc_a[r] + par_s[c], vb = acc_b[r] + par_s[CP + c];
+            const bool tb = mfm_takes_b(va, vb);
+            // lanes 0-31 hold channel c_lo for 32 pixels, lanes 32-63 channel c_lo + 4: one ballot, two 32-bit words
+            const unsigned long long word = __ballot(valid && live && tb);
+            const float v = ((tb ? vb : va) - par_s[2 * CP + c]) * par_s[3 * CP + c];
+            if (live && valid) yn[(int64_t)c * P] = v;
+            if (live && li == 0) sn[(int64_t)c * PW] = lk ? (uint32_t)(word >> 32) : (uint32_t)word;
         }
     }
 }
 
 // grid (ceil(P / 128), N).  MT = ceil(CIN / 32) output tiles (input channels).  LDS: w_s[2C][32 MT + 1], columns >= CIN zero.
-template <int CIN, int MT>
+// STEPS = C / 2 when known at compile time (LCNN: 16, 24, 32): every gradient / selection load of the wave is issued
+// before the first MFMA; STEPS = 0 is the generic runtime loop.
+template <int CIN, int MT, int STEPS>
 __global__ __launch_bounds__(kBlock) void conv1x1_mfm_backward_kernel(const float *__restrict__ gy,
                                                                       const uint32_t *__restrict__ sel,
                                                                       const float *__restrict__ weight,
@@ -154,6 +139,30 @@ __global__ __launch_bounds__(kBlock) void conv1x1_mfm_backward_kernel(const floa
     for (int m = 0; m < MT; ++m) acc[m] = (f32x16){0};
     // K runs over the 2C rows of W^T; step s feeds channel pair c = 2 s + lk to BOTH halves: the gradient reaches the
     // selected half only (max-feature-map backward), the other B fragment is zero
+    if constexpr (STEPS > 0) {
+        float g[STEPS];
+        uint32_t taken = 0;  // bit s: the second half won for channel 2 s + lk at this lane's pixel
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+            const int c = 2 * s + lk;
+            g[s] = valid ? gn[(int64_t)c * P] : 0.0f;
+            taken |= ((sn[(int64_t)c * PW] >> li) & 1u) << s;
+        }
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+            const int c = 2 * s + lk;
+            const float gs = g[s] * gs_s[c];
+            const bool tb = (taken >> s) & 1u;
+            const float ga = tb ? 0.0f : gs, gb = tb ? gs : 0.0f;
+            const float *wa = w_s + c * PITCH + li;
+            const float *wb = wa + C * PITCH;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[32 * m], ga, acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[32 * m], gb, acc[m], 0, 0, 0);
+            }
+        }
+    } else {
     const int steps = (C + 1) >> 1;
     for (int s = 0; s < steps; ++s) {
         const int c = 2 * s + lk;
@@ -168,6 +177,7 @@ __global__ __launch_bounds__(kBlock) void conv1x1_mfm_backward_kernel(const floa
             acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(live ? wa[32 * m] : 0.0f, ga, acc[m], 0, 0, 0);
             acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(live ? wb[32 * m] : 0.0f, gb, acc[m], 0, 0, 0);
         }
+    }
     }
     if (!valid) return;
     float *xn = gx + n * CIN * P + p;
@@ -195,19 +205,30 @@ void launch_fwd(const float *x, const float *w, const float *b, const float *bn_
                 uint32_t *sel, int64_t N, int64_t C, int64_t P, hipStream_t st) {
     const size_t lds = (size_t)(2 * TILES * 32 * (CIN + 1) + 4 * TILES * 32) * sizeof(float);
     opt_in_lds(conv1x1_mfm_forward_kernel<CIN, TILES>, lds);
-    const dim3 grid((unsigned)ceil_div(P, kFwdPixPerBlock), (unsigned)N);
+    const dim3 grid((unsigned)ceil_div(P, kPixPerBlock), (unsigned)N);
     hipLaunchKernelGGL((conv1x1_mfm_forward_kernel<CIN, TILES>), grid, dim3(kBlock), lds, st, x, w, b, bn_mean, bn_invstd, y,
                        sel, (int)C, P, ceil_div(P, 32));
 }
 
+template <int CIN, int MT, int STEPS>
+void launch_bwd_steps(const float *gy, const uint32_t *sel, const float *w, const float *gscale, float *gx, int64_t N,
+                      int64_t C, int64_t P, hipStream_t st) {
+    const size_t lds = (size_t)(2 * C * (MT * 32 + 1) + C) * sizeof(float);
+    opt_in_lds(conv1x1_mfm_backward_kernel<CIN, MT, STEPS>, lds);
+    const dim3 grid((unsigned)ceil_div(P, kPixPerBlock), (unsigned)N);
+    hipLaunchKernelGGL((conv1x1_mfm_backward_kernel<CIN, MT, STEPS>), grid, dim3(kBlock), lds, st, gy, sel, w, gscale, gx,
+                       (int)C, P, ceil_div(P, 32));
+}
+
+// LCNN's blocks have C == Cin (the conv doubles the channels, the max-feature-map halves them): that case gets the
+// fully unrolled kernel, anything else the runtime loop
 template <int CIN, int MT>
 void launch_bwd(const float *gy, const uint32_t *sel, const float *w, const float *gscale, float *gx, int64_t N, int64_t C,
                 int64_t P, hipStream_t st) {
-    const size_t lds = (size_t)(2 * C * (MT * 32 + 1) + C) * sizeof(float);
-    opt_in_lds(conv1x1_mfm_backward_kernel<CIN, MT>, lds);
-    const dim3 grid((unsigned)ceil_div(P, kPixPerBlock), (unsigned)N);
-    hipLaunchKernelGGL((conv1x1_mfm_backward_kernel<CIN, MT>), grid, dim3(kBlock), lds, st, gy, sel, w, gscale, gx, (int)C, P,
-                       ceil_div(P, 32));
+    if (C == CIN)
+        launch_bwd_steps<CIN, MT, CIN / 2>(gy, sel, w, gscale, gx, N, C, P, st);
+    else
+        launch_bwd_steps<CIN, MT, 0>(gy, sel, w, gscale, gx, N, C, P, st);
 }
 
 }  // namespace
