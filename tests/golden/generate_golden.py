@@ -273,6 +273,82 @@ def gen_cw(ta, aa_utils):
     np.savez_compressed(OUT / "cw.npz", **out)
 
 
+def fab_projection_inputs(T: int, seed: int):
+    """(t, w, b) rows for the FAB projections, regenerated from the seed by the tests (only outputs are stored):
+    points in [0, 1] with exact 0s and 1s, hyperplane normals with exact zeros, offsets that put the hyperplane very
+    close, inside reach on either side, and out of the box's reach."""
+    g = torch.Generator().manual_seed(seed)
+    R = 6
+    t = torch.rand(R, T, generator=g)
+    t[:, ::7] = 0.0
+    t[:, 3::11] = 1.0
+    w = torch.randn(R, T, generator=g) * 0.01
+    w[:, ::13] = 0.0
+    dot = (w * t).sum(1)
+    b = dot + torch.tensor([1e-4, -1e-3, 0.05, -0.2, 0.45, 5.0]) * w.abs().sum(1)
+    return t, w, b
+
+
+def gen_fab_projections():
+    """fab.py:562-717 called directly on seeded rows; only the outputs (and input checksums) are stored."""
+    from adversarial_attacks.torchattacks.attacks import fab as rfab
+
+    out = {}
+    for T, seed in ((257, 11), (T_RAGGED, 12), (T_FULL, 13)):
+        t, w, b = fab_projection_inputs(T, seed)
+        key = f"T{T}"
+        out[f"{key}_seed"] = np.int64(seed)
+        out[f"{key}_checksum"] = np.array([t.double().sum().item(), w.double().sum().item(), b.double().sum().item()])
+        out[f"{key}_b"] = npy(b)
+        for name in ("linf", "l2", "l1"):
+            d = getattr(rfab, "projection_" + name)(t.clone(), w.clone(), b.clone())
+            out[f"{key}_{name}"] = npy(d)
+    np.savez_compressed(OUT / "fab_projection.npz", **out)
+
+
+def gen_fab_attack(ta, aa_utils):
+    """FAB.forward / attack_single_run on the surrogate detector, with every model input recorded: per iteration the
+    reference evaluates the model at x1 (fab.py:93) and at the combined point before the backward step (fab.py:269)."""
+    model = surrogate(7)
+    x = waveforms(6, T_SMALL, 3)
+    x01, _, _ = aa_utils.to_minmax(x)
+    y = (model(x01).flatten() > 0).long()
+    y[2] = 1 - y[2]  # one utterance the detector already gets wrong: FAB must leave it untouched
+    out = {f"model_{k}": npy(v) for k, v in model.state_dict().items()}
+    out["x01"] = npy(x01)
+    out["labels"] = npy(y)
+    runs = {
+        "linf": dict(norm="Linf", eta=1.05, steps=8, eps=None),
+        "linf_eta10": dict(norm="Linf", eta=10, steps=5, eps=None),       # AttackEnum.FAB's overshoot
+        "linf_tight": dict(norm="Linf", eta=1.05, steps=12, eps=0.26),    # some rows end above eps: rejected
+        "l2": dict(norm="L2", eta=1.05, steps=12, eps=20.0),
+    }
+    for name, kw in runs.items():
+        atk = ta.FAB(model, n_classes=2, **kw)
+        atk.set_training_mode(True, False, False)
+        with record_attack(model) as rec:
+            adv = atk(x01, y)
+        # inputs: [perturb's clean pass, single-run's clean pass, (x1_k, combined_k) * steps, final check]
+        ins = rec["inputs"]
+        assert len(ins) == 3 + 2 * kw["steps"], len(ins)
+        out[f"{name}_adv"] = npy(adv)
+        if name in ("linf", "linf_eta10"):   # per-iteration traces only where the tests replay step by step
+            out[f"{name}_x1"] = np.stack([npy(v) for v in ins[2:-1:2]])
+        if name == "linf":
+            out[f"{name}_combined"] = np.stack([npy(v) for v in ins[3:-1:2]])
+        out[f"{name}_single_run"] = npy(atk.attack_single_run(x01, y))
+        out[f"{name}_params"] = np.array([kw["eta"], kw["steps"], atk.eps])
+    # L1 through attack_single_run only: FAB.forward raises for L1 in the reference (fab.py:518-522, `res` unassigned)
+    atk = ta.FAB(model, n_classes=2, norm="L1", eta=1.05, steps=12)
+    out["l1_single_run"] = npy(atk.attack_single_run(x01, y))
+    try:
+        atk(x01, y)
+        out["l1_forward_raises"] = np.bool_(False)
+    except UnboundLocalError:
+        out["l1_forward_raises"] = np.bool_(True)
+    np.savez_compressed(OUT / "fab_attack.npz", **out)
+
+
 def gen_metrics():
     from src.metrics import calculate_eer
     from sklearn.metrics import precision_recall_fscore_support, roc_auc_score
@@ -364,6 +440,8 @@ def main():
     gen_pgd_linf(ta, aa_utils)
     gen_pgd_l2(ta, aa_utils)
     gen_cw(ta, aa_utils)
+    gen_fab_projections()
+    gen_fab_attack(ta, aa_utils)
     gen_metrics()
     gen_model_bodies()
     for p in sorted(OUT.glob("*.npz")):

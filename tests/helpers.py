@@ -34,3 +34,19 @@ def randn(shape, seed, scale=1.0):
 
 def dev(a, device):
     return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+
+
+def fab_projection_inputs(T: int, seed: int):
+    """The seeded (t, w, b) rows tests/golden/generate_golden.py fed to the reference's FAB projections (the fixture
+    stores only outputs + input checksums): exact 0s / 1s in the points, exact zeros in the normals, hyperplanes from
+    very close to out of the box's reach."""
+    g = torch.Generator().manual_seed(seed)
+    R = 6
+    t = torch.rand(R, T, generator=g)
+    t[:, ::7] = 0.0
+    t[:, 3::11] = 1.0
+    w = torch.randn(R, T, generator=g) * 0.01
+    w[:, ::13] = 0.0
+    dot = (w * t).sum(1)
+    b = dot + torch.tensor([1e-4, -1e-3, 0.05, -0.2, 0.45, 5.0]) * w.abs().sum(1)
+    return t, w, b

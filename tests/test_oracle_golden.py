@@ -166,3 +166,78 @@ def test_torch_oracle_minmax_matches_c_oracle():
     assert same(x01.numpy(), c01) and same(mn.numpy().ravel(), cmn) and same(mx.numpy().ravel(), cmx)
     p = torch.rand(5, 777)
     assert same(OA.revert_minmax(p, mn, mx).numpy(), K.minmax_revert(p.numpy(), cmn, cmx))
+
+
+# ---- FAB: floating-point parity, tolerances stated per check -------------------------------------------
+def _fab_rows(golden, T):
+    from tests.helpers import fab_projection_inputs
+
+    g = golden("fab_projection")
+    t, w, b = fab_projection_inputs(T, int(g[f"T{T}_seed"]))
+    # the inputs are regenerated from the seed: make sure this torch build draws the same numbers
+    assert np.allclose([t.double().sum().item(), w.double().sum().item(), b.double().sum().item()], g[f"T{T}_checksum"],
+                       rtol=1e-12, atol=1e-9)
+    assert same(b.numpy(), g[f"T{T}_b"])
+    return g, t.numpy(), w.numpy(), b.numpy()
+
+
+@pytest.mark.parametrize("T", [257, 4099, 64600])
+def test_fab_projections_match_reference(golden, T):
+    """oracle/fab.py's float64 sorted-breakpoint solution against the reference's float32 sort/cumsum/bisection
+    (fab.py:562-717) on the same rows.  Linf / L2: 2e-6 max-abs on moves of size <= 1; L1: the one partially moved
+    coordinate is residual / w_i with float32 cancellation in the residual, 5e-4."""
+    from oracle import fab as OF
+
+    g, t, w, b = _fab_rows(golden, T)
+    for name, tol in (("linf", 2e-6), ("l2", 2e-6), ("l1", 5e-4)):
+        got = getattr(OF, "projection_" + name)(t, w, b)
+        want = g[f"T{T}_{name}"]
+        assert np.abs(got - want).max() <= tol, (name, np.abs(got - want).max())
+
+
+def test_fab_attack_matches_reference(golden):
+    """Whole FAB runs of the reference (surrogate detector, eta = 1.05) against oracle/fab.py: 5e-6 max-abs on the
+    adversarial waveform after 8-12 iterations; rows the detector already misclassifies stay bit-identical."""
+    from oracle import fab as OF
+
+    g = golden("fab_attack")
+    model = surrogate_from(g)
+    x01, y = T(g["x01"]), T(g["labels"])
+    for name, norm in (("linf", "Linf"), ("linf_tight", "Linf"), ("l2", "L2")):
+        eta, steps, eps = g[f"{name}_params"]
+        adv = OF.fab(model, x01, y, norm=norm, eps=float(eps), steps=int(steps), eta=float(eta)).numpy()
+        assert np.abs(adv - g[f"{name}_adv"]).max() <= 5e-6, name
+        assert same(adv[2], g["x01"][2])
+        run = OF.attack_single_run(model, x01, y, norm, float(eps), int(steps), 0.1, float(eta), 0.9).numpy()
+        assert np.abs(run - g[f"{name}_single_run"]).max() <= 5e-6, name
+    # eps = 0.26 rejects every row whose best adversarial point is farther than eps (fab.py:518-526)
+    assert same(g["linf_tight_adv"], g["x01"]) and not same(g["linf_tight_single_run"], g["x01"])
+    # L1 moves coordinates one at a time in order of |w|: a last-bit difference in the residual changes WHICH coordinates
+    # move, so rows agree either coordinate-wise (2e-4) or in the size of the perturbation (5e-4 relative L1 norm)
+    run = OF.attack_single_run(model, x01, y, "L1", 5.0, 12, 0.1, 1.05, 0.9).numpy()
+    err = np.abs(run - g["l1_single_run"]).max(axis=1)
+    n_mine, n_ref = np.abs(run - g["x01"]).sum(axis=1), np.abs(g["l1_single_run"] - g["x01"]).sum(axis=1)
+    assert (err <= 2e-4).sum() >= 5 and np.allclose(n_mine, n_ref, rtol=5e-4)
+    assert bool(g["l1_forward_raises"])
+    with pytest.raises(UnboundLocalError):
+        OF.fab(model, x01, y, norm="L1", steps=2)
+
+
+def test_fab_iterations_replay_reference_trace(golden):
+    """Step by step: from the reference's own x1 at iteration k, one oracle iteration lands on the reference's x1 at
+    k + 1 (2e-6), including AttackEnum.FAB's eta = 10 overshoot, whose whole-run trajectory is too sensitive to compare
+    end to end."""
+    from oracle import fab as OF
+
+    g = golden("fab_attack")
+    model = surrogate_from(g)
+    x01, y = T(g["x01"]), T(g["labels"])
+    rows = torch.tensor([0, 1, 3, 4, 5])  # row 2 is misclassified from the start and never enters the run
+    x0, la = x01[rows], y[rows]
+    for name in ("linf", "linf_eta10"):
+        eta = float(g[f"{name}_params"][0])
+        trace = T(g[f"{name}_x1"])
+        adv, res2 = x0.clone(), torch.full((5,), 1e10)
+        for k in range(trace.shape[0] - 1):
+            nxt, adv, res2 = OF.fab_iteration(model, trace[k], x0, la, adv, res2, "Linf", eta, 0.9, 0.1)
+            assert (nxt - trace[k + 1]).abs().max() <= 2e-6, (name, k, (nxt - trace[k + 1]).abs().max())
