@@ -1,6 +1,6 @@
 """Attack registry: CLI name -> (attack class, kwargs)  (reference: src/aa/aa_types.py:5-24).
 
-The reference's members are kept verbatim except FAB (out of the hot-path scope).
+The reference's members are kept verbatim, FAB included.
 Additive members carry the configurations BASELINE.json names, which the reference's enum cannot express
 (SURVEY.md F7): 40-step PGD at eps = 0.003, 40-step PGDL2, and CW."""
 from enum import Enum
@@ -10,7 +10,7 @@ from .. import torchattacks
 
 class AttackEnum(Enum):
 
-    # --- reference members (aa_types.py:8-18) ---
+    # --- reference members (aa_types.py:8-22) ---
     PGD = (torchattacks.PGD, {"eps": 0.0005, "steps": 10})
     PGD_eps00075 = (torchattacks.PGD, {"eps": 0.00075, "steps": 10})
     PGD_eps001 = (torchattacks.PGD, {"eps": 0.001, "steps": 10})
@@ -22,6 +22,10 @@ class AttackEnum(Enum):
     FGSM = (torchattacks.FGSM, {"eps": 0.0005})
     FGSM_eps00075 = (torchattacks.FGSM, {"eps": 0.00075})
     FGSM_eps001 = (torchattacks.FGSM, {"eps": 0.001})
+
+    FAB = (torchattacks.FAB, {"n_classes": 2, "eta": 10})
+    FAB_eta20 = (torchattacks.FAB, {"n_classes": 2, "eta": 20})
+    FAB_eta30 = (torchattacks.FAB, {"n_classes": 2, "eta": 30})
 
     # --- additive members for BASELINE.json's configurations ---
     PGD40_eps003 = (torchattacks.PGD, {"eps": 0.003, "steps": 40})          # configs 2 and 5 (alpha default 2/255)

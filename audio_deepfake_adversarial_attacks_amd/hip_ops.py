@@ -324,3 +324,97 @@ def ce2_loss_grad(z, labels, scale: float = 1.0):
                                                    scale, _stream(z.device))
     _lib.check(st, "advstep_ce2_loss_grad_f32")
     return dz, loss
+
+
+# ---------------------------------------------------------------------------------------------------------
+# f3: FAB (include/advstep_fab.h; reference adversarial_attacks/torchattacks/attacks/fab.py:208-292, 562-717)
+# ---------------------------------------------------------------------------------------------------------
+
+FAB_NORMS = {"Linf": 0, "L2": 1, "L1": 2}
+
+
+def _fab_kind(norm: str) -> int:
+    try:
+        return FAB_NORMS[norm]
+    except KeyError:
+        raise ValueError("norm not supported") from None    # fab.py:224
+
+
+def fab_hyperplane(gz, x, z=None, labels=None, norm: str = "Linf"):
+    """Row statistics of the logit gradient + the closest-boundary selection for cat([-z, z]) (fab.py:90-112, 210-229).
+    Returns (wscale, b, gnorm, gdot), each (B); wscale / b are None when z / labels are not given."""
+    _require(gz, "gz"), _require(x, "x")
+    _same_shape(("gz", gz), ("x", x))
+    B, T = _rows(gz, "gz")
+    dev = gz.device
+    gnorm, gdot = torch.empty(B, device=dev), torch.empty(B, device=dev)
+    wscale = b = None
+    zp = lp = wp = bp = None
+    if z is not None:
+        _require(z, "z"), _require(labels, "labels", torch.int64)
+        if z.numel() != B or labels.numel() != B:
+            raise ValueError(f"z / labels must hold one value per row ({B})")
+        wscale, b = torch.empty(B, device=dev), torch.empty(B, device=dev)
+        zp, lp, wp, bp = z.data_ptr(), labels.data_ptr(), wscale.data_ptr(), b.data_ptr()
+    with _Launch("fab_hyperplane", dev):
+        st = _lib.load().advstep_fab_hyperplane_f32(gz.data_ptr(), x.data_ptr(), zp, lp, wp, bp, gnorm.data_ptr(),
+                                                    gdot.data_ptr(), B, T, _fab_kind(norm), _stream(dev))
+    _lib.check(st, "advstep_fab_hyperplane_f32")
+    return wscale, b, gnorm, gdot
+
+
+def fab_projection(points, w, b, norm: str = "Linf", wscale=None, out=None):
+    """projection_{linf,l2,l1}(points, w, b) (fab.py:562-717) for R rows: returns (d (R, T), its attack norm (R)).
+    w may hold fewer rows than points (R % w_rows == 0): row r uses w[r % w_rows] * wscale[r % w_rows]."""
+    _require(points, "points"), _require(w, "w"), _require(b, "b")
+    R, _ = _rows(points, "points")
+    w_rows, _ = _rows(w, "w")
+    T, Tw = points[0].numel() if R else w.shape[1:].numel(), w.shape[1:].numel()
+    if Tw != T or w_rows == 0 or R % w_rows or b.numel() != R or w.device != points.device:
+        raise ValueError(f"points {tuple(points.shape)}, w {tuple(w.shape)}, b {tuple(b.shape)} do not line up")
+    if wscale is not None:
+        _require(wscale, "wscale")
+        if wscale.numel() != w_rows:
+            raise ValueError(f"wscale must hold one value per row of w ({w_rows})")
+    d = _out_like(points, out, "out")
+    dnorm = torch.empty(R, device=points.device)
+    with _Launch("fab_projection", points.device):
+        st = _lib.load().advstep_fab_projection_f32(points.data_ptr(), w.data_ptr(),
+                                                    None if wscale is None else wscale.data_ptr(), b.data_ptr(),
+                                                    d.data_ptr(), dnorm.data_ptr(), R, w_rows, T, _fab_kind(norm),
+                                                    _stream(points.device))
+    _lib.check(st, "advstep_fab_projection_f32")
+    return d, dnorm
+
+
+def fab_combine(x1, x0, d1, d2, n1, n2, eta: float, alpha_max: float, out=None):
+    """clamp((x1 + eta d1)(1 - alpha) + (x0 + eta d2) alpha, 0, 1), alpha from the two move norms (fab.py:257-267)."""
+    for name, t in (("x1", x1), ("x0", x0), ("d1", d1), ("d2", d2), ("n1", n1), ("n2", n2)):
+        _require(t, name)
+    _same_shape(("x1", x1), ("x0", x0), ("d1", d1), ("d2", d2))
+    B, T = _rows(x1, "x1")
+    if n1.numel() != B or n2.numel() != B:
+        raise ValueError(f"n1 / n2 must hold one value per row ({B})")
+    res = _out_like(x1, out, "out")
+    with _Launch("fab_combine", x1.device):
+        st = _lib.load().advstep_fab_combine_f32(x1.data_ptr(), x0.data_ptr(), d1.data_ptr(), d2.data_ptr(), n1.data_ptr(),
+                                                 n2.data_ptr(), res.data_ptr(), B, T, eta, alpha_max, _stream(x1.device))
+    _lib.check(st, "advstep_fab_combine_f32")
+    return res
+
+
+def fab_backward_step(x1, x0, adv, res2, is_adv, beta: float, norm: str = "Linf") -> None:
+    """In place, rows with is_adv != 0: keep the closest adversarial point so far, then step back towards the clean
+    point by beta (fab.py:271-290).  is_adv (B) uint8 or bool."""
+    _require(x1, "x1"), _require(x0, "x0"), _require(adv, "adv"), _require(res2, "res2")
+    _same_shape(("x1", x1), ("x0", x0), ("adv", adv))
+    B, T = _rows(x1, "x1")
+    if is_adv.dtype == torch.bool:
+        is_adv = is_adv.view(torch.uint8)
+    _require(is_adv, "is_adv", torch.uint8)
+    if res2.numel() != B or is_adv.numel() != B:
+        raise ValueError(f"res2 / is_adv must hold one value per row ({B})")
+    with _Launch("fab_backward_step", x1.device):
+        st = _lib.load().advstep_fab_backward_step_f32(x1.data_ptr(), x0.data_ptr(), adv.data_ptr(), res2.data_ptr(),
+                                                       is_adv.data_ptr(), B, T, beta, _fab_kind(norm), _stream(x1.device))
+    _lib.check(st, "advstep_fab_backward_step_f32")

@@ -166,3 +166,49 @@ class CheckedOps:
         _close("ce2_loss_grad.loss", loss, np.array([wloss]), atol=1e-7, rtol=CE_RTOL)
         self.calls["ce2_loss_grad"] += 1
         return dz, loss
+
+    # f3: FAB — floating-point parity against the float64 oracle (tolerances: oracle/fab.py header) ------------------
+    def fab_hyperplane(self, gz, x, z=None, labels=None, norm="Linf"):
+        from . import torch_ops as O
+
+        got = self.hip.fab_hyperplane(gz, x, z, labels, norm)
+        want = O.fab_hyperplane(gz.cpu(), x.cpu(), None if z is None else z.cpu(), None if labels is None else labels.cpu(), norm)
+        for name, g, w in zip(("wscale", "b", "gnorm", "gdot"), got, want):
+            if g is not None:
+                scale = float(np.abs(_np(want[2])).max()) if name in ("b", "gdot") else 0.0
+                _close("fab_hyperplane." + name, g, _np(w), atol=1e-6 * scale + 1e-6, rtol=2e-5)
+        self.calls["fab_hyperplane"] += 1
+        return got
+
+    def fab_projection(self, points, w, b, norm="Linf", wscale=None, out=None):
+        from . import torch_ops as O
+
+        pin, win, bin_ = points.cpu().clone(), w.cpu().clone(), b.cpu().clone()
+        sin = None if wscale is None else wscale.cpu().clone()
+        d, dn = self.hip.fab_projection(points, w, b, norm, wscale, out)
+        wd, wdn = O.fab_projection(pin, win, bin_, norm, sin)
+        tol = {"Linf": 2e-5, "L2": 2e-5, "L1": 8e-3}[norm]
+        _close("fab_projection.d", d, _np(wd), atol=tol)
+        _close("fab_projection.norm", dn, _np(wdn), atol=tol, rtol=1e-4)
+        self.calls["fab_projection"] += 1
+        return d, dn
+
+    def fab_combine(self, x1, x0, d1, d2, n1, n2, eta, alpha_max, out=None):
+        from . import torch_ops as O
+
+        want = O.fab_combine(x1.cpu(), x0.cpu(), d1.cpu(), d2.cpu(), n1.cpu(), n2.cpu(), eta, alpha_max)
+        got = self.hip.fab_combine(x1, x0, d1, d2, n1, n2, eta, alpha_max, out)
+        _exact("fab_combine", got, _np(want))
+        self.calls["fab_combine"] += 1
+        return got
+
+    def fab_backward_step(self, x1, x0, adv, res2, is_adv, beta, norm="Linf"):
+        from . import torch_ops as O
+
+        c1, ca, cr = x1.cpu().clone(), adv.cpu().clone(), res2.cpu().clone()
+        O.fab_backward_step(c1, x0.cpu(), ca, cr, is_adv.cpu(), beta, norm)
+        self.hip.fab_backward_step(x1, x0, adv, res2, is_adv, beta, norm)
+        _exact("fab_backward_step.x1", x1, _np(c1))
+        _close("fab_backward_step.res2", res2, _np(cr), rtol=1e-5)
+        _exact("fab_backward_step.adv", adv, _np(ca))
+        self.calls["fab_backward_step"] += 1

@@ -90,3 +90,66 @@ def cw_best_update(adv, mask, best):
 def ce2_loss_grad(z, labels, scale=1.0):
     dz, loss = K.ce2_loss_grad(_np(z), _np(labels), scale)
     return _t(dz.reshape(z.shape), z), torch.tensor([loss], dtype=torch.float32, device=z.device)
+
+
+# ---- FAB (oracle/fab.py; float64 arbiter, see its header) ------------------------------------------------------------
+def fab_hyperplane(gz, x, z=None, labels=None, norm="Linf"):
+    from . import fab as F
+
+    g, xx = gz.detach().cpu().double(), x.detach().cpu().double()
+    gnorm = F.dual_norm(g, norm)
+    gdot = (g * xx).reshape(g.shape[0], -1).sum(dim=1)
+    if z is None:
+        return None, None, gnorm.float().to(gz.device), gdot.float().to(gz.device)
+    zz, la = z.detach().cpu().double().reshape(-1), labels.detach().cpu().reshape(-1)
+    y = torch.stack([-zz, zz], dim=1)
+    col = torch.tensor([-1.0, 1.0], dtype=torch.float64)
+    u = torch.arange(g.shape[0])
+    coef = col.unsqueeze(0) - col[la].unsqueeze(1)                 # dg_k = coef_k * gz
+    df = y - y[u, la].unsqueeze(1)
+    df[u, la] = 1e10
+    dist = df.abs() / (1e-12 + coef.abs() * gnorm.unsqueeze(1))
+    ind = dist.min(dim=1)[1]
+    wscale = coef[u, ind]
+    b = -df[u, ind] + wscale * gdot
+    dev = gz.device
+    return wscale.float().to(dev), b.float().to(dev), gnorm.float().to(dev), gdot.float().to(dev)
+
+
+def fab_projection(points, w, b, norm="Linf", wscale=None, out=None):
+    from . import fab as F
+
+    R = points.shape[0]
+    wn = _np(w).reshape(w.shape[0], -1)
+    if wscale is not None:
+        wn = wn * _np(wscale).reshape(-1, 1)
+    wn = np.tile(wn, (R // wn.shape[0], 1))
+    pts = _np(points).reshape(R, -1)
+    d = F.PROJECTIONS[norm](pts, wn, _np(b).reshape(-1))
+    dn = F.row_norm(torch.from_numpy(d.astype(np.float64)), norm).float().to(points.device)
+    return _emit(d, points, out), dn
+
+
+def fab_combine(x1, x0, d1, d2, n1, n2, eta, alpha_max, out=None):
+    a1 = torch.clamp_min(n1.detach().cpu(), 1e-8).reshape(-1, 1)
+    a2 = torch.clamp_min(n2.detach().cpu(), 1e-8).reshape(-1, 1)
+    alpha = torch.clamp(a1 / (a1 + a2), min=0.0, max=alpha_max)
+    p1, p0, m1, m2 = (t.detach().cpu().reshape(t.shape[0], -1) for t in (x1, x0, d1, d2))
+    res = ((p1 + eta * m1) * (1 - alpha) + (p0 + m2 * eta) * alpha).clamp(0.0, 1.0)
+    return _emit(res.numpy(), x1, out)
+
+
+def fab_backward_step(x1, x0, adv, res2, is_adv, beta, norm="Linf"):
+    from . import fab as F
+
+    rows = is_adv.detach().cpu().reshape(-1).bool().nonzero().reshape(-1)
+    if rows.numel() == 0:
+        return
+    p1, p0 = x1.detach().cpu().reshape(x1.shape[0], -1), x0.detach().cpu().reshape(x0.shape[0], -1)
+    t = F.row_norm(p1[rows] - p0[rows], norm)
+    best = res2.detach().cpu().reshape(-1)
+    better = t < best[rows]
+    with torch.no_grad():
+        adv.view(adv.shape[0], -1)[rows[better].to(adv.device)] = p1[rows[better]].to(adv.device)
+        res2.view(-1)[rows[better].to(res2.device)] = t[better].to(res2.device)
+        x1.view(x1.shape[0], -1)[rows.to(x1.device)] = (p0[rows] + (p1[rows] - p0[rows]) * beta).to(x1.device)

@@ -187,12 +187,14 @@ def test_attack_without_library_or_gpu_fails_loudly():
 # ---- registry --------------------------------------------------------------------------------------------------------
 
 def test_attack_enum_keeps_reference_members_and_adds_baseline_configs():
-    ref = {  # src/aa/aa_types.py:8-18,24
+    ref = {  # src/aa/aa_types.py:8-24
         "PGD": ("PGD", {"eps": 0.0005, "steps": 10}), "PGD_eps00075": ("PGD", {"eps": 0.00075, "steps": 10}),
         "PGD_eps001": ("PGD", {"eps": 0.001, "steps": 10}), "PGDL2": ("PGDL2", {"eps": 0.1, "steps": 10}),
         "PGDL2_eps15": ("PGDL2", {"eps": 0.15, "steps": 10}), "PGDL2_eps20": ("PGDL2", {"eps": 0.20, "steps": 10}),
         "FGSM": ("FGSM", {"eps": 0.0005}), "FGSM_eps00075": ("FGSM", {"eps": 0.00075}),
         "FGSM_eps001": ("FGSM", {"eps": 0.001}),
+        "FAB": ("FAB", {"n_classes": 2, "eta": 10}), "FAB_eta20": ("FAB", {"n_classes": 2, "eta": 20}),
+        "FAB_eta30": ("FAB", {"n_classes": 2, "eta": 30}),
     }
     for name, (cls, kw) in ref.items():
         got_cls, got_kw = AttackEnum[name].value
@@ -253,3 +255,83 @@ def test_sharded_sampler_partitions_every_global_batch():
     assert len(set(sum(ref, []))) == (n // gb) * gb                 # drop_last, no repeats
     with pytest.raises(ValueError):
         ShardedBatchSampler(n, 65, 0, 4)
+
+
+# ---- FAB host logic (product class, oracle op table on CPU) against the reference's own runs -------------------------------
+
+def _fab_fixture(golden):
+    g = golden("fab_attack")
+    return g, surrogate_from(g), torch.from_numpy(g["x01"]), torch.from_numpy(g["labels"])
+
+
+def test_fab_class_mirrors_reference_attributes():
+    atk = torchattacks.FAB(Surrogate(), n_classes=2, eta=10)
+    assert (atk.attack, atk.norm, atk.eps, atk.steps, atk.n_restarts) == ("FAB", "Linf", 0.3, 100, 1)
+    assert (atk.alpha_max, atk.eta, atk.beta, atk.seed, atk.verbose) == (0.1, 10, 0.9, 0, False)
+    assert atk.targeted is False and atk.target_class is None and atk.n_target_classes == 1   # fab.py:63,66,67
+    assert torchattacks.FAB(Surrogate(), norm="L2").eps == 1.0 and torchattacks.FAB(Surrogate(), norm="L1").eps == 5.0
+    assert torchattacks.FAB(Surrogate(), targeted=True).targeted is False                      # ignored, as upstream
+    with pytest.raises(ValueError):
+        atk.set_mode_targeted_least_likely()                                                   # _supported_mode: default only
+    with pytest.raises(KeyError):
+        torchattacks.FAB(Surrogate(), norm="L0")
+
+
+def test_fab_whole_runs_match_reference(golden):
+    """FAB.forward / attack_single_run of the product class with the CPU op table: 5e-6 max-abs against the reference's
+    adversarial waveforms (eta = 1.05); untouched rows bit-identical; the eps filter of perturb() rejects like upstream."""
+    g, model, x01, y = _fab_fixture(golden)
+    for name, norm in (("linf", "Linf"), ("linf_tight", "Linf"), ("l2", "L2")):
+        eta, steps, eps = g[f"{name}_params"]
+        atk = torchattacks.FAB(model, norm=norm, n_classes=2, eta=float(eta), steps=int(steps), eps=float(eps))
+        atk.ops = torch_ops
+        atk.set_training_mode(True, False, False)
+        adv = atk(x01, y)
+        assert adv.shape == x01.shape and adv.dtype == torch.float32 and not adv.requires_grad
+        assert np.abs(adv.numpy() - g[f"{name}_adv"]).max() <= 5e-6, name
+        assert np.array_equal(adv[2].numpy(), g["x01"][2])
+        run = atk.attack_single_run(x01, y)
+        assert np.abs(run.numpy() - g[f"{name}_single_run"]).max() <= 5e-6, name
+    assert np.array_equal(g["linf_tight_adv"], g["x01"])
+
+
+def test_fab_l1_forward_works_where_reference_raises(golden):
+    g, model, x01, y = _fab_fixture(golden)
+    assert bool(g["l1_forward_raises"])                       # upstream: UnboundLocalError at fab.py:522
+    atk = torchattacks.FAB(model, norm="L1", n_classes=2, eta=1.05, steps=12, eps=2000.0)
+    atk.ops = torch_ops
+    adv = atk(x01, y)
+    n_mine, n_ref = (adv - x01).abs().sum(1).numpy(), np.abs(g["l1_single_run"] - g["x01"]).sum(axis=1)
+    assert np.allclose(n_mine, n_ref, rtol=5e-4) and n_mine[2] == 0.0
+
+
+def test_fab_restarts_draw_the_reference_random_start(golden):
+    """perturb() re-seeds torch's generators with `seed` and the random start is drawn on the CPU generator then moved
+    (fab.py:504-505,176): a second restart starts from the same points as the reference's would."""
+    g, model, x01, y = _fab_fixture(golden)
+    atk = torchattacks.FAB(model, n_classes=2, eta=1.05, steps=2, eps=0.05, n_restarts=2, seed=5)
+    atk.ops = torch_ops
+    seen = []
+    orig = atk._random_start
+    atk._random_start = lambda x0, res2: seen.append(orig(x0, res2)) or seen[-1]
+    atk(x01, y)
+    assert len(seen) == 1
+    torch.manual_seed(5)
+    rows = [0, 1, 3, 4, 5]
+    t = 2 * torch.rand(5, x01.shape[1]) - 1
+    want = (x01[rows] + 0.05 * t / t.abs().max(dim=1, keepdim=True)[0] * 0.5).clamp(0.0, 1.0)
+    assert torch.equal(seen[0], want)
+
+
+def test_fab_public_gradient_helpers_keep_reference_shapes(golden):
+    g, model, x01, y = _fab_fixture(golden)
+    atk = torchattacks.FAB(model, n_classes=2)
+    df, dg = atk.get_diff_logits_grads_batch(x01, y)
+    assert df.shape == (6, 2) and dg.shape == (6, 2, x01.shape[1])
+    u = torch.arange(6)
+    assert (df[u, y] == 1e10).all() and (dg[u, y] == 0).all()
+    z = model(x01).detach().reshape(-1)
+    assert torch.allclose(df[u, 1 - y], torch.where(y == 0, 2 * z, -2 * z))
+    df_t, dg_t = atk.get_diff_logits_grads_batch_targeted(x01, y, 1 - y)
+    assert df_t.shape == (6, 1) and dg_t.shape == (6, 1, x01.shape[1])
+    assert torch.allclose(df_t[:, 0], df[u, 1 - y]) and torch.allclose(dg_t[:, 0], dg[u, 1 - y])
