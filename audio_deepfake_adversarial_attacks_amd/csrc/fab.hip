@@ -301,105 +301,187 @@ __global__ __launch_bounds__(kRow) void fab_projection_l2_kernel(const float *__
     }
 }
 
-__device__ __forceinline__ uint32_t l1_key(float wi) {  // fab.py:681  r = (1 / w).abs().clamp_max(1e12), as ordered bits
-    const float r = fminf(fabsf(1.0f / wi), kBig);
-    return __float_as_uint(r);
+__device__ __forceinline__ float l1_ratio(float wi) {  // fab.py:681  r = (1 / w).abs().clamp_max(1e12)
+    return fminf(fabsf(1.0f / wi), kBig);
+}
+__device__ __forceinline__ float l1_gain(float ti, float wi) { return fminf(-wi * ti, wi * (1.0f - ti)); }
+__device__ __forceinline__ float l1_face(float ti, float wi) {
+    return (wi != 0.0f) ? ((wi < 0.0f ? 1.0f : 0.0f) - ti) : 0.0f;
 }
 
-// Greedy L1: coordinates in order of increasing key (= decreasing |w|, index order within equal keys) move to their
-// face while the residual stays positive.  Keys are non-negative floats, so their bit patterns order like integers:
-// the last key whose residual-before is positive is found bit by bit (31 streaming passes), then the tie group is
-// walked in index order with a workgroup prefix scan.
+// Greedy L1: coordinates in order of increasing key r = |1/w| (= decreasing |w|, index order within equal keys) move to
+// their face while the residual stays positive.  Keys are non-negative floats, so their bit patterns order like
+// integers: the last key whose residual-before is positive is found kDigit bits at a time (a histogram of the gains
+// over the 2^kDigit - 1 candidate prefixes per streaming pass, 11 passes for the 31 key bits), then the tie group is
+// walked in index order with a workgroup prefix scan.  The output row doubles as scratch for the keys (one division
+// per coordinate in total), so d must not alias t or w.
+constexpr int kDigit = 3, kBuckets = (1 << kDigit) - 1;
+
+template <bool VEC>
 __global__ __launch_bounds__(kRow) void fab_projection_l1_kernel(const float *__restrict__ t, const float *__restrict__ w,
                                                                  const float *__restrict__ wscale,
-                                                                 const float *__restrict__ b, float *__restrict__ d,
+                                                                 const float *__restrict__ b, float *d,
                                                                  float *__restrict__ dnorm, int64_t R, int64_t w_rows,
                                                                  int64_t T) {
-    __shared__ float lds[3 * kRowWaves];
+    __shared__ float lds[kBuckets * kRowWaves];
     __shared__ float wave_tot[kRowWaves];
     for (int64_t row = blockIdx.x; row < R; row += gridDim.x) {
         const float *tr = t + row * T, *wr = w + (row % w_rows) * T;
         float *dr = d + row * T;
         const float sc = wscale ? wscale[row % w_rows] : 1.0f;
-        float acc[3] = {0.0f, 0.0f, 0.0f};  // w.t, total gain for either orientation
-        visit2<false>(tr, wr, T, [&](float ti, float wraw) {
+        // pass 1: w.t, total gain for either orientation; keys into the output row
+        float acc[3] = {0.0f, 0.0f, 0.0f};
+        map2<VEC>(tr, wr, dr, T, [&](float ti, float wraw) {
             const float wi = sc * wraw;
             acc[0] += wi * ti;
-            acc[1] += fminf(-wi * ti, wi * (1.0f - ti));
-            acc[2] += fminf(wi * ti, -wi * (1.0f - ti));
+            acc[1] += l1_gain(ti, wi);
+            acc[2] += l1_gain(ti, -wi);
+            return l1_ratio(wi);
         });
         row_reduce<3>(acc, Sum(), lds);
         const float c0 = acc[0] - b[row];
         const float sg = c0 >= 0.0f ? 1.0f : -1.0f;
         const float c = fabsf(c0);
         const float total = c + (sg > 0.0f ? acc[1] : acc[2]);   // s[:, -1]
-        auto gain = [&](float ti, float wi) { return fminf(-wi * ti, wi * (1.0f - ti)); };
-        auto face = [&](float ti, float wi) { return (wi != 0.0f) ? ((wi < 0.0f ? 1.0f : 0.0f) - ti) : 0.0f; };
         float sum_abs[1] = {0.0f};
         if (!(total < 0.0f)) {
             // the farthest corner does not reach the hyperplane: every coordinate to its face (fab.py:686)
-            for (int64_t i = threadIdx.x; i < T; i += kRow) {
-                const float wi = sg * (sc * wr[i]);
-                float di = face(tr[i], wi);
+            map2<VEC>(tr, wr, dr, T, [&](float ti, float wraw) {
+                const float wi = sg * (sc * wraw);
+                float di = l1_face(ti, wi);
                 if (!(fabsf(wi) > 1e-8f)) di = 0.0f;
-                dr[i] = di;
                 sum_abs[0] += fabsf(di);
-            }
+                return di;
+            });
         } else {
-            // largest key bits rho with  c + sum_{key < rho} gain > 0
+            // largest key bits rho with  c + sum_{key < rho} gain > 0;  `before` is that residual
             uint32_t rho = 0;
-            float before = c;   // residual before the tie group of key rho
+            float before = c;
             if (c > 0.0f) {
-                for (int bit = 30; bit >= 0; --bit) {
-                    const uint32_t cand = rho | (1u << bit);
-                    float v[1] = {0.0f};
-                    visit2<false>(tr, wr, T, [&](float ti, float wraw) {
-                        const float wi = sg * (sc * wraw);
-                        if (l1_key(wi) < cand) v[0] += gain(ti, wi);
-                    });
-                    row_reduce<1>(v, Sum(), lds);
-                    if (c + v[0] > 0.0f) {
-                        rho = cand;
-                        before = c + v[0];
+                for (int top = 31; top > 0; top -= kDigit) {          // bits [shift, top) of the key
+                    const int shift = top >= kDigit ? top - kDigit : 0;
+                    const uint32_t limit = (1u << (top - shift)) - 1u; // candidates j = 1 .. limit
+                    float h[kBuckets];
+#pragma unroll
+                    for (int q = 0; q < kBuckets; ++q) h[q] = 0.0f;
+                    auto tally = [&](float ti, float wraw, float ri) {
+                        const uint32_t key = __float_as_uint(ri);
+                        if (key >= rho) {
+                            const uint32_t q = (key - rho) >> shift;   // contributes to every candidate j > q
+                            const float gn = l1_gain(ti, sg * (sc * wraw));
+#pragma unroll
+                            for (int k = 0; k < kBuckets; ++k) h[k] += (q == (uint32_t)k) ? gn : 0.0f;
+                        }
+                    };
+                    if constexpr (VEC) {
+                        const int64_t n4 = T >> 2;
+                        for (int64_t q4 = threadIdx.x; q4 < n4; q4 += kRow) {
+                            const float4 a = reinterpret_cast<const float4 *>(tr)[q4];
+                            const float4 e = reinterpret_cast<const float4 *>(wr)[q4];
+                            const float4 r = reinterpret_cast<const float4 *>(dr)[q4];
+                            tally(a.x, e.x, r.x);
+                            tally(a.y, e.y, r.y);
+                            tally(a.z, e.z, r.z);
+                            tally(a.w, e.w, r.w);
+                        }
+                    } else {
+                        for (int64_t i = threadIdx.x; i < T; i += kRow) tally(tr[i], wr[i], dr[i]);
                     }
+                    row_reduce<kBuckets>(h, Sum(), lds);
+                    float run = before;
+                    uint32_t pick = 0;
+                    for (uint32_t j = 1; j <= limit; ++j) {            // residual before candidate j = before + h[0..j)
+                        run += h[j - 1];
+                        if (run > 0.0f) {
+                            pick = j;
+                            before = run;
+                        } else {
+                            break;
+                        }
+                    }
+                    rho |= pick << shift;
+                    if (shift == 0) break;
                 }
             }
-            // walk the row in index order: contiguous chunk per thread, exclusive prefix of the tie group's gains
-            const int64_t chunk = (T + kRow - 1) / kRow;
-            const int64_t lo = (int64_t)threadIdx.x * chunk, hi = lo + chunk < T ? lo + chunk : T;
-            float local = 0.0f;
-            for (int64_t i = lo; i < hi; ++i) {
-                const float wi = sg * (sc * wr[i]);
-                if (l1_key(wi) == rho) local += gain(tr[i], wi);
-            }
-            const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-            float incl = local;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const float up = __shfl_up(incl, off, 64);
-                if (lane >= off) incl += up;
-            }
-            if (lane == 63) wave_tot[wave] = incl;
-            __syncthreads();
-            float run = before;
-            for (int wv = 0; wv < wave; ++wv) run += wave_tot[wv];
-            run += incl - local;
-            __syncthreads();
-            for (int64_t i = lo; i < hi; ++i) {
-                const float ti = tr[i], wi = sg * (sc * wr[i]);
-                const uint32_t key = l1_key(wi);
+            // every key below rho moves to its face, every key above stays; the tie group at rho holds the coordinate
+            // that crosses the hyperplane.  One coalesced pass writes everything but the tie group and counts it.
+            float ties[1] = {0.0f};
+            float tie_t = 0.0f, tie_w = 0.0f;
+            int64_t tie_i = -1;
+            auto settle = [&](int64_t i, float ti, float wraw, float ri) {
+                const float wi = sg * (sc * wraw);
+                const uint32_t key = __float_as_uint(ri);
                 float di = 0.0f;
-                if (key < rho) {
-                    di = face(ti, wi);
-                } else if (key == rho) {
-                    const float after = run + gain(ti, wi);
-                    if (after > 0.0f) di = face(ti, wi);          // still short of the hyperplane: full move
-                    else if (run > 0.0f) di = -run / wi;          // the coordinate that would overshoot (fab.py:711,715)
-                    run = after;
+                if (key < rho) di = l1_face(ti, wi);
+                if (key == rho) {
+                    ties[0] += 1.0f;
+                    tie_i = i;
+                    tie_t = ti;
+                    tie_w = wi;
                 }
                 if (!(fabsf(wi) > 1e-8f)) di = 0.0f;
-                dr[i] = di;
                 sum_abs[0] += fabsf(di);
+                return di;
+            };
+            if constexpr (VEC) {
+                const int64_t n4 = T >> 2;
+                for (int64_t q4 = threadIdx.x; q4 < n4; q4 += kRow) {
+                    const float4 a = reinterpret_cast<const float4 *>(tr)[q4];
+                    const float4 e = reinterpret_cast<const float4 *>(wr)[q4];
+                    const float4 r = reinterpret_cast<const float4 *>(dr)[q4];
+                    float4 o;
+                    o.x = settle(4 * q4, a.x, e.x, r.x);
+                    o.y = settle(4 * q4 + 1, a.y, e.y, r.y);
+                    o.z = settle(4 * q4 + 2, a.z, e.z, r.z);
+                    o.w = settle(4 * q4 + 3, a.w, e.w, r.w);
+                    reinterpret_cast<float4 *>(dr)[q4] = o;
+                }
+            } else {
+                for (int64_t i = threadIdx.x; i < T; i += kRow) dr[i] = settle(i, tr[i], wr[i], dr[i]);
+            }
+            row_reduce<1>(ties, Sum(), lds);
+            if (ties[0] == 1.0f) {
+                // the usual case: the tie group is one coordinate, the one that would overshoot (fab.py:711,715)
+                if (tie_i >= 0) {
+                    const float after = before + l1_gain(tie_t, tie_w);
+                    float di = after > 0.0f ? l1_face(tie_t, tie_w) : (before > 0.0f ? -before / tie_w : 0.0f);
+                    if (!(fabsf(tie_w) > 1e-8f)) di = 0.0f;
+                    dr[tie_i] = di;
+                    sum_abs[0] += fabsf(di);
+                }
+            } else if (ties[0] > 1.0f) {
+                // equal keys: walk the group in index order (contiguous chunk per thread, exclusive workgroup prefix of
+                // the group's gains); keys are recomputed, the output row no longer holds them
+                __syncthreads();
+                const int64_t chunk = (T + kRow - 1) / kRow;
+                const int64_t lo = (int64_t)threadIdx.x * chunk, hi = lo + chunk < T ? lo + chunk : T;
+                float local = 0.0f;
+                for (int64_t i = lo; i < hi; ++i) {
+                    const float wi = sg * (sc * wr[i]);
+                    if (__float_as_uint(l1_ratio(wi)) == rho) local += l1_gain(tr[i], wi);
+                }
+                const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+                float incl = local;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const float up = __shfl_up(incl, off, 64);
+                    if (lane >= off) incl += up;
+                }
+                if (lane == 63) wave_tot[wave] = incl;
+                __syncthreads();
+                float run = before;
+                for (int wv = 0; wv < wave; ++wv) run += wave_tot[wv];
+                run += incl - local;
+                for (int64_t i = lo; i < hi; ++i) {
+                    const float ti = tr[i], wi = sg * (sc * wr[i]);
+                    if (__float_as_uint(l1_ratio(wi)) != rho) continue;
+                    const float after = run + l1_gain(ti, wi);
+                    float di = after > 0.0f ? l1_face(ti, wi) : (run > 0.0f ? -run / wi : 0.0f);
+                    run = after;
+                    if (!(fabsf(wi) > 1e-8f)) di = 0.0f;
+                    dr[i] = di;
+                    sum_abs[0] += fabsf(di);
+                }
             }
         }
         row_reduce<1>(sum_abs, Sum(), lds);
@@ -510,7 +592,7 @@ int advstep_fab_projection_f32(const float *t, const float *w, const float *wsca
                                advstep_stream_t stream) {
     FAB_REQUIRE(R >= 0 && T >= 0 && w_rows >= 0 && norm_kind >= 0 && norm_kind <= 2);
     if (R == 0) return ADVSTEP_OK;
-    FAB_REQUIRE(t && w && b && d && w_rows >= 1 && T >= 1 && T < (int64_t(1) << 24));
+    FAB_REQUIRE(t && w && b && d && d != t && d != w && w_rows >= 1 && T >= 1 && T < (int64_t(1) << 24));
     const bool vec = (T % 4 == 0) && aligned16(t) && aligned16(w) && aligned16(d);
     const dim3 grid(grid_rows(R)), block(kRow);
     hipStream_t st = as_stream(stream);
@@ -521,7 +603,8 @@ int advstep_fab_projection_f32(const float *t, const float *w, const float *wsca
         if (vec) hipLaunchKernelGGL(fab_projection_l2_kernel<true>, grid, block, 0, st, t, w, wscale, b, d, dnorm, R, w_rows, T);
         else hipLaunchKernelGGL(fab_projection_l2_kernel<false>, grid, block, 0, st, t, w, wscale, b, d, dnorm, R, w_rows, T);
     } else {
-        hipLaunchKernelGGL(fab_projection_l1_kernel, grid, block, 0, st, t, w, wscale, b, d, dnorm, R, w_rows, T);
+        if (vec) hipLaunchKernelGGL(fab_projection_l1_kernel<true>, grid, block, 0, st, t, w, wscale, b, d, dnorm, R, w_rows, T);
+        else hipLaunchKernelGGL(fab_projection_l1_kernel<false>, grid, block, 0, st, t, w, wscale, b, d, dnorm, R, w_rows, T);
     }
     return status_after_launch();
 }

@@ -9,8 +9,8 @@
  *      smallest ||d||_p  with  w.(t + d) = b,  0 <= t + d <= 1      (nearest box corner when out of reach)
  * WITHOUT sorting: the row's optimality condition  sum_i weight_i * min(cap_i, lam) = |w.t - b|  is a concave
  * piecewise-linear equation in one unknown; a monotone fixed-point (Newton) iteration on it converges in a handful of
- * streaming passes over the row (Linf, L2), and a bit-wise bisection over the float keys |1/w| does the greedy L1
- * selection.  One workgroup of 1024 threads owns one row (T = 64 600 floats = 258 KB, L2-resident between passes);
+ * streaming passes over the row (Linf, L2), and a radix selection over the float keys |1/w| (3 key bits per streaming
+ * pass, 11 passes) does the greedy L1 selection.  One workgroup of 1024 threads owns one row (T = 64 600 floats = 258 KB, L2-resident between passes);
  * all reductions are fixed-order trees: results are deterministic.
  *
  * Parity: floating point.  The reference's own CPU path (float64-accumulated cumsum) and CUDA path (float32 parallel
@@ -49,7 +49,8 @@ int advstep_fab_hyperplane_f32(const float *gz, const float *x, const float *z, 
 /* fab.py:562-614 / :617-669 / :672-717  projection_{linf,l2,l1}(points, w, b) -> d, for R rows.
  * t (R, T) points; the hyperplane normal of row r is  wscale[r % w_rows] * w[r % w_rows, :]  (w (w_rows, T); wscale may
  * be NULL = 1) — the reference's torch.cat((w, w), 0) is never materialised: pass w_rows = R / 2; b (R).
- * d (R, T) receives the move; dnorm (R) its attack norm (max|d|, sqrt(sum d^2), sum|d|: fab.py:248-256). */
+ * d (R, T) receives the move (it must not alias t or w: the L1 kernel keeps its sort keys there between passes);
+ * dnorm (R) its attack norm (max|d|, sqrt(sum d^2), sum|d|: fab.py:248-256). */
 int advstep_fab_projection_f32(const float *t, const float *w, const float *wscale, const float *b, float *d,
                                float *dnorm, int64_t R, int64_t w_rows, int64_t T, int norm_kind,
                                advstep_stream_t stream);
