@@ -349,6 +349,68 @@ def gen_fab_attack(ta, aa_utils):
     np.savez_compressed(OUT / "fab_attack.npz", **out)
 
 
+class TinyDetectionSet(torch.utils.data.Dataset):
+    """(waveform, sample_rate, label) triples like the reference's DetectionDataset items, held in memory."""
+
+    def __init__(self, n: int, T: int, seed: int):
+        self.x = waveforms(n, T, seed)
+        self.y = torch.randint(0, 2, (n,), generator=torch.Generator().manual_seed(seed + 1))
+
+    def __len__(self):
+        return self.x.shape[0]
+
+    def __getitem__(self, i):
+        return self.x[i], 16_000, int(self.y[i])
+
+
+TRAINER_RUNS = {   # strategy -> attacks (reference AttackEnum names; FGSM only: no random start, bit-reproducible)
+    "RANDOM": ["FGSM", "FGSM_eps00075", "FGSM_eps001"],
+    "EQUAL": ["FGSM_eps001"],
+    "ONLY_ADV": ["FGSM_eps00075"],
+    "ADAPTIVE": ["FGSM", "FGSM_eps001"],
+    "ADAPTIVE_V2": ["FGSM", "FGSM_eps00075", "FGSM_eps001"],
+}
+
+
+def gen_trainer():
+    """src/trainer.py's five adversarial-training strategies, 2 epochs on a tiny in-memory set with the surrogate
+    detector on CPU: final (best) weights, every log line's numbers, the adaptive attack weights."""
+    import logging
+    import random
+
+    from src.aa.aa_trainer_types import AdversarialGDTrainerEnum
+
+    out = {}
+    train, test = TinyDetectionSet(16, 1024, 21), TinyDetectionSet(8, 1024, 22)
+    for strategy, attacks in TRAINER_RUNS.items():
+        model = surrogate(7).train()      # (re-seeds torch: seed the run afterwards)
+        random.seed(3)
+        np.random.seed(3)
+        torch.manual_seed(3)
+        records = []
+        handler = logging.Handler()
+        handler.emit = lambda rec: records.append(rec.getMessage())
+        log = logging.getLogger("src.trainer")
+        log.setLevel(logging.INFO)
+        log.addHandler(handler)
+        try:
+            trainer = AdversarialGDTrainerEnum[strategy].value(epochs=2, batch_size=4, device="cpu",
+                                                               optimizer_kwargs={"lr": 1e-3})
+            trained = trainer.train(dataset=train, model=model, attack_model=model, adversarial_attacks=attacks,
+                                    test_dataset=test)
+        finally:
+            log.removeHandler(handler)
+        for k, v in trained.state_dict().items():
+            out[f"{strategy}_model_{k}"] = npy(v)
+        out[f"{strategy}_log"] = np.array([m for m in records if m.startswith(("Epoch [", "[0"))])
+        if hasattr(trainer, "adv_attacks_weights"):
+            out[f"{strategy}_weights"] = np.array(trainer.adv_attacks_weights, dtype=np.float64)
+    init = surrogate(7)
+    for k, v in init.state_dict().items():
+        out[f"init_model_{k}"] = npy(v)
+    np.savez_compressed(OUT / "trainer.npz", **out)
+
+
 def gen_metrics():
     from src.metrics import calculate_eer
     from sklearn.metrics import precision_recall_fscore_support, roc_auc_score
@@ -442,6 +504,7 @@ def main():
     gen_cw(ta, aa_utils)
     gen_fab_projections()
     gen_fab_attack(ta, aa_utils)
+    gen_trainer()
     gen_metrics()
     gen_model_bodies()
     for p in sorted(OUT.glob("*.npz")):

@@ -50,3 +50,19 @@ def fab_projection_inputs(T: int, seed: int):
     dot = (w * t).sum(1)
     b = dot + torch.tensor([1e-4, -1e-3, 0.05, -0.2, 0.45, 5.0]) * w.abs().sum(1)
     return t, w, b
+
+
+class TinyDetectionSet(torch.utils.data.Dataset):
+    """The in-memory (waveform, sample_rate, label) set tests/golden/generate_golden.py trained the reference's
+    trainers on: waveforms N(0, 0.05^2) clipped to [-1, 1] from torch.Generator(seed), labels from seed + 1."""
+
+    def __init__(self, n: int, T: int, seed: int):
+        g = torch.Generator().manual_seed(seed)
+        self.x = (torch.randn(n, T, generator=g) * 0.05).clamp_(-1.0, 1.0)
+        self.y = torch.randint(0, 2, (n,), generator=torch.Generator().manual_seed(seed + 1))
+
+    def __len__(self):
+        return self.x.shape[0]
+
+    def __getitem__(self, i):
+        return self.x[i], 16_000, int(self.y[i])
