@@ -22,14 +22,19 @@ def synthetic_waveforms(n: int, num_samples: int = NUM_SAMPLES, seed: int = 1234
 
 
 class SyntheticDetectionDataset(Dataset):
-    def __init__(self, n: int, num_samples: int = NUM_SAMPLES, seed: int = 1234):
+    def __init__(self, n: int, num_samples: int = NUM_SAMPLES, seed: int = 1234, return_meta: bool = True):
+        """return_meta as in base_dataset.py:42,185: the evaluation loop asks for the metadata tuple (4 items per
+        utterance), the trainers do not (3 items)."""
         self.x, self.y = synthetic_waveforms(n, num_samples, seed)
         self.seconds = num_samples / SAMPLING_RATE
+        self.return_meta = return_meta
 
     def __len__(self):
         return len(self.y)
 
     def __getitem__(self, index):
         label = int(self.y[index])
+        if not self.return_meta:
+            return [self.x[index], SAMPLING_RATE, label]
         meta = ("-" if label == 1 else "synthetic", f"synthetic/{index:08d}.wav", "val", self.seconds)
         return [self.x[index], SAMPLING_RATE, label, meta]

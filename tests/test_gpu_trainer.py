@@ -29,8 +29,8 @@ def test_adversarial_training_runs_on_lcnn(cuda, strategy, attacks):
     calls = []
     orig = tr._attack_batch
     tr._attack_batch = staticmethod(lambda atk, bx, by: (calls.append(type(atk).__name__), orig(atk, bx, by))[1])
-    out = tr.train(dataset=SyntheticDetectionDataset(24), model=model, attack_model=model, adversarial_attacks=attacks,
-                   test_dataset=SyntheticDetectionDataset(8, seed=99))
+    out = tr.train(dataset=SyntheticDetectionDataset(24, return_meta=False), model=model, attack_model=model, adversarial_attacks=attacks,
+                   test_dataset=SyntheticDetectionDataset(8, seed=99, return_meta=False))
     assert out is model and calls                               # single process: no wrapper; attacks were applied
     assert all(p.requires_grad for p in model.parameters())       # the attacks' parameter freeze is always undone
     changed = [k for k, v in model.state_dict().items() if v.dtype.is_floating_point and not torch.equal(v, before[k])]

@@ -38,7 +38,8 @@ def get_datasets(amount_to_use: Tuple[int, int], synthetic: Optional[Tuple[int, 
         raise SystemExit("real-corpus loading (DetectionDataset) is outside the hot-path scope: pass --synthetic N_TRAIN,N_TEST")
     n_train = min(synthetic[0], amount_to_use[0]) if amount_to_use[0] else synthetic[0]
     n_test = min(synthetic[1], amount_to_use[1]) if amount_to_use[1] else synthetic[1]
-    return SyntheticDetectionDataset(n_train, seed=1234), SyntheticDetectionDataset(n_test, seed=4321)
+    return (SyntheticDetectionDataset(n_train, seed=1234, return_meta=False),
+            SyntheticDetectionDataset(n_test, seed=4321, return_meta=False))
 
 
 def train_nn(batch_size: int, epochs: int, device: str, config: Dict, attack_config: Optional[Dict],
