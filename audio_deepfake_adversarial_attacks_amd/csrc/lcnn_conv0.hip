@@ -8,8 +8,9 @@
 // (B, 32, 202, 40) tensor + one selection byte per output; the backward gathers, for every 2x2 input patch,
 // the <= 9 pooled cells whose winner can reach it, straight from gy + the selection bytes.
 //   forward : thread = one pooled output position, 6x6 input window in registers, loop over the C channel
-//             pairs with the 2 x 25 taps + 2 biases as wave-uniform (scalar) operands: 200 v_fma per pair.
-//   backward: thread = one 2x2 input patch; weights staged in LDS (per-lane tap lookup); no atomics.
+//             pairs with the 2 x 25 taps + 2 biases as wave-uniform (scalar) operands: 100 v_pk_fma_f32 per pair.
+//   backward: thread = one 2x2 input patch; taps staged in LDS as zero-bordered tables (branch-free per-lane lookup);
+//             no atomics.
 // VALU-bound (13.2 GFLOP at B = 128), not HBM-bound; MFMA does not apply (K = 25, one input channel).
 // Accumulation order is fixed (taps row-major, then channels), fma contraction allowed: deterministic, and within
 // float rounding of any other convolution implementation (MIOpen's differs in the last bits as well).
@@ -24,6 +25,7 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr int K = 5, KK = 25, PAD = 2;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 inline hipStream_t as_stream(advstep_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
@@ -72,44 +74,67 @@ __global__ __launch_bounds__(kBlock) void conv5_mfm_pool2_forward_kernel(const f
         }
     }
 
+    // horizontally adjacent conv positions share a tap: (x00, x01) and (x10, x11) accumulate as float2 pairs, one
+    // v_pk_fma_f32 per pair with the tap broadcast from a scalar register (100 packed FMAs per channel pair instead
+    // of 200 scalar ones).  Window pairs are kept at even and at odd column offsets so every operand is an aligned
+    // register pair.
+    f32x2 pe[6][3], po[6][2];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) pe[r][q] = (f32x2){win[r][2 * q], win[r][2 * q + 1]};
+#pragma unroll
+        for (int q = 0; q < 2; ++q) po[r][q] = (f32x2){win[r][2 * q + 1], win[r][2 * q + 2]};
+    }
+
     float *yn = y + n * (int64_t)C * Ho * Wo + p;
     uint8_t *in = idx + n * (int64_t)C * Ho * Wo + p;
     for (int c = 0; c < C; ++c) {
         const float *wa = weight + c * KK;        // wave-uniform addresses: scalar loads
         const float *wb = weight + (c + C) * KK;
-        float a00, a01, a10, a11, b00, b01, b10, b11;
-        a00 = a01 = a10 = a11 = 0.0f;
-        b00 = b01 = b10 = b11 = 0.0f;
+        f32x2 a0 = {0.0f, 0.0f}, a1 = {0.0f, 0.0f}, b0 = {0.0f, 0.0f}, b1 = {0.0f, 0.0f};  // rows 0 / 1 of the 2x2 block
 #pragma unroll
         for (int kh = 0; kh < K; ++kh) {
 #pragma unroll
             for (int kw = 0; kw < K; ++kw) {
                 const float ua = wa[kh * K + kw], ub = wb[kh * K + kw];
-                a00 = fmaf(ua, win[kh][kw], a00);
-                a01 = fmaf(ua, win[kh][kw + 1], a01);
-                a10 = fmaf(ua, win[kh + 1][kw], a10);
-                a11 = fmaf(ua, win[kh + 1][kw + 1], a11);
-                b00 = fmaf(ub, win[kh][kw], b00);
-                b01 = fmaf(ub, win[kh][kw + 1], b01);
-                b10 = fmaf(ub, win[kh + 1][kw], b10);
-                b11 = fmaf(ub, win[kh + 1][kw + 1], b11);
+                const f32x2 t0 = (kw & 1) ? po[kh][kw >> 1] : pe[kh][kw >> 1];
+                const f32x2 t1 = (kw & 1) ? po[kh + 1][kw >> 1] : pe[kh + 1][kw >> 1];
+                a0 = __builtin_elementwise_fma((f32x2){ua, ua}, t0, a0);
+                a1 = __builtin_elementwise_fma((f32x2){ua, ua}, t1, a1);
+                b0 = __builtin_elementwise_fma((f32x2){ub, ub}, t0, b0);
+                b1 = __builtin_elementwise_fma((f32x2){ub, ub}, t1, b1);
             }
         }
         const float ba = bias ? bias[c] : 0.0f, bb = bias ? bias[c + C] : 0.0f;
         int code;
-        const float v = pool_select(a00 + ba, b00 + bb, a01 + ba, b01 + bb, a10 + ba, b10 + bb, a11 + ba, b11 + bb, code);
+        const float v = pool_select(a0.x + ba, b0.x + bb, a0.y + ba, b0.y + bb, a1.x + ba, b1.x + bb, a1.y + ba, b1.y + bb,
+                                    code);
         yn[(int64_t)c * Ho * Wo] = v;
         in[(int64_t)c * Ho * Wo] = (uint8_t)code;
     }
 }
 
 // thread = one pooled-cell footprint (2x2 input patch); gathers from the 3x3 neighbouring pooled cells.
+// Branch-free: the taps live in LDS as zero-bordered 7x7 tables (tap (kh, kw) at [kh + 1][kw + 1]), so a winner that
+// cannot reach a patch pixel reads a 0 weight instead of taking a branch, and out-of-range neighbour cells read a
+// clamped address with their gradient forced to 0.  The two channel halves are kHalfPitch words apart, which puts the
+// 8 (half, dh, dw) variants of one lookup in 8 different LDS banks.
+constexpr int kTab = 7, kTabWords = kTab * kTab;   // 49
+
 __global__ __launch_bounds__(kBlock) void conv5_mfm_pool2_backward_kernel(const float *__restrict__ gy,
                                                                           const uint8_t *__restrict__ idx,
                                                                           const float *__restrict__ weight,
                                                                           float *__restrict__ gx, int C, int H, int W) {
-    extern __shared__ __attribute__((aligned(16))) float wl[];  // 2C * 25 taps
-    for (int i = threadIdx.x; i < 2 * C * KK; i += kBlock) wl[i] = weight[i];
+    extern __shared__ __attribute__((aligned(16))) float wl[];  // [2][C][7][7] + 4 words between the halves
+    const int half_pitch = C * kTabWords + 4;
+    for (int i = threadIdx.x; i < 2 * half_pitch; i += kBlock) wl[i] = 0.0f;
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C * KK; i += kBlock) {
+        const int ch = i / KK, tap = i - ch * KK, kh = tap / K, kw = tap - kh * K;
+        const int half = ch >= C, c = ch - half * C;
+        wl[half * half_pitch + c * kTabWords + (kh + 1) * kTab + (kw + 1)] = weight[i];
+    }
     __syncthreads();
 
     const int Ho = H >> 1, Wo = W >> 1;
@@ -121,46 +146,55 @@ __global__ __launch_bounds__(kBlock) void conv5_mfm_pool2_backward_kernel(const 
     const float *gn = gy + n * (int64_t)C * Ho * Wo;
     const uint8_t *in = idx + n * (int64_t)C * Ho * Wo;
 
-    float acc[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
+    // the 9 neighbour cells: clamped 32-bit offsets + validity, hoisted out of the channel loop
+    uint32_t cell_off[9];
+    bool cell_ok[9];
+#pragma unroll
+    for (int dh = -1; dh <= 1; ++dh) {
+#pragma unroll
+        for (int dw = -1; dw <= 1; ++dw) {
+            const int ho = hp + dh, wo = wp + dw;
+            const bool ok = ho >= 0 && ho < Ho && wo >= 0 && wo < Wo;
+            cell_ok[(dh + 1) * 3 + dw + 1] = ok;
+            cell_off[(dh + 1) * 3 + dw + 1] = ok ? (uint32_t)(ho * Wo + wo) : 0u;
+        }
+    }
+
+    // (x00, x01) and (x10, x11) accumulate as float2 pairs: the two taps a winner sends to one patch row are adjacent
+    // words of the bordered table (one ds_read2_b32 = an aligned register pair), the gradient is the broadcast operand
+    f32x2 acc0 = {0.0f, 0.0f}, acc1 = {0.0f, 0.0f};
+    const uint32_t plane = (uint32_t)(Ho * Wo);
     for (int c = 0; c < C; ++c) {
-        const float *gc = gn + (int64_t)c * Ho * Wo;
-        const uint8_t *ic = in + (int64_t)c * Ho * Wo;
+        const float *gc = gn + (size_t)c * plane;      // wave-uniform bases: scalar registers + 32-bit lane offsets
+        const uint8_t *ic = in + (size_t)c * plane;
+        const float *wc = wl + c * kTabWords;
 #pragma unroll
         for (int dh = -1; dh <= 1; ++dh) {
-            const int ho = hp + dh;
-            if (ho < 0 || ho >= Ho) continue;
 #pragma unroll
             for (int dw = -1; dw <= 1; ++dw) {
-                const int wo = wp + dw;
-                if (wo < 0 || wo >= Wo) continue;
-                const int code = ic[ho * Wo + wo];
-                const float g = gc[ho * Wo + wo];
-                const float *wsel = wl + (c + ((code & 4) ? C : 0)) * KK;
-                // winner's conv position relative to this patch's origin (2hp, 2wp)
-                const int rh = 2 * dh + ((code >> 1) & 1), rw = 2 * dw + (code & 1);
-                // d conv[h'] / d in[h] has tap kh = h - h' + PAD
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int kh = i - rh + PAD;
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const int kw = j - rw + PAD;
-                        if (kh >= 0 && kh < K && kw >= 0 && kw < K) acc[i][j] = fmaf(g, wsel[kh * K + kw], acc[i][j]);
-                    }
-                }
+                const int q = (dh + 1) * 3 + dw + 1;
+                const uint32_t code = ic[cell_off[q]];
+                const float gl = gc[cell_off[q]];              // unconditional (clamped address), then masked
+                const float g = cell_ok[q] ? gl : 0.0f;
+                // winner's conv position relative to the patch origin: (2 dh + ph, 2 dw + pw); patch pixel (i, j) sees
+                // tap (i - rh + 2, j - rw + 2), stored at [i - rh + 3][j - rw + 3] of the bordered table: a constant
+                // per neighbour minus a term that depends on the 3 code bits only
+                const int by_code = ((code & 4u) ? half_pitch : 0) - kTab * (int)((code >> 1) & 1u) - (int)(code & 1u);
+                const float *t0 = wc + ((3 - 2 * dh) * kTab + (3 - 2 * dw)) + by_code;
+                const f32x2 gg = {g, g};
+                acc0 = __builtin_elementwise_fma(gg, (f32x2){t0[0], t0[1]}, acc0);
+                acc1 = __builtin_elementwise_fma(gg, (f32x2){t0[kTab], t0[kTab + 1]}, acc1);
             }
         }
     }
+    const float acc00 = acc0.x, acc01 = acc0.y, acc10 = acc1.x, acc11 = acc1.y;
     float *xn = gx + n * (int64_t)H * W;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int h = 2 * hp + i;
-        if (h >= H) continue;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int w = 2 * wp + j;
-            if (w < W) xn[(int64_t)h * W + w] = acc[i][j];
-        }
+    const int h0 = 2 * hp, w0 = 2 * wp;
+    xn[(int64_t)h0 * W + w0] = acc00;
+    if (w0 + 1 < W) xn[(int64_t)h0 * W + w0 + 1] = acc01;
+    if (h0 + 1 < H) {
+        xn[(int64_t)(h0 + 1) * W + w0] = acc10;
+        if (w0 + 1 < W) xn[(int64_t)(h0 + 1) * W + w0 + 1] = acc11;
     }
 }
 
@@ -191,14 +225,14 @@ int advstep_conv5_mfm_pool2_backward_f32(const float *gy, const uint8_t *idx, co
                                          int64_t C, int64_t H, int64_t W, advstep_stream_t stream) {
     CONV0_REQUIRE(N >= 0 && C >= 0 && H >= 0 && W >= 0);
     if (N == 0 || H == 0 || W == 0) return ADVSTEP_OK;
-    CONV0_REQUIRE(gx && N <= kMaxGridY && C <= 256 && H * W <= INT32_MAX);
+    CONV0_REQUIRE(gx && N <= kMaxGridY && C <= 96 && H * W <= INT32_MAX);   // 2 C bordered 7x7 tables must fit 64 KB of LDS
     hipStream_t st = as_stream(stream);
     if (C == 0 || H / 2 == 0 || W / 2 == 0)
         return hipMemsetAsync(gx, 0, (size_t)N * H * W * sizeof(float), st) == hipSuccess ? ADVSTEP_OK : ADVSTEP_ELAUNCH;
     CONV0_REQUIRE(gy && idx && weight);
     const int64_t patches = ((H + 1) / 2) * ((W + 1) / 2);
     const dim3 grid((unsigned)ceil_div(patches, kBlock), (unsigned)N);
-    const size_t lds = (size_t)2 * C * KK * sizeof(float);
+    const size_t lds = (size_t)2 * (C * kTabWords + 4) * sizeof(float);
     hipLaunchKernelGGL(conv5_mfm_pool2_backward_kernel, grid, dim3(kBlock), lds, st, gy, idx, weight, gx, (int)C, (int)H,
                        (int)W);
     return status_after_launch();
