@@ -1,0 +1,368 @@
+// lcnn_wino.hip — LCNN's 3x3 convolution blocks on the fp32 matrix cores (C ABI: include/advstep_lcnn.h):
+//     Conv2d(Cin, 2C, (3, 3), padding 1) -> MaxFeatureMap2D -> MaxPool2d(2, 2) [-> BatchNorm2d(eval, affine=False)]
+//     (src/models/lcnn.py:128-131, 135-137, 149-154)  as ONE kernel, and the matching input-gradient convolution.
+//
+// These blocks are where an attack iteration spends its time (2 x 93 GFLOP per iteration at B = 128).  MIOpen runs them
+// as a VALU Winograd kernel (miopenSp3AsmConv..f2x3, ~98 TFLOP/s direct-conv equivalent) whose 2C-channel output is
+// written, re-read by the max-feature-map + pool kernel, and written again.  Here: Winograd F(2x2, 3x3) with the 16
+// per-position GEMMs on v_mfma_f32_16x16x4_f32 (fp32 in, fp32 accumulate), max-feature-map + pool + BatchNorm in
+// the epilogue, so the conv output never exists.
+//
+//   * wave tile: 16 Winograd tiles (2x2 outputs each) x 32 output channels x all 16 positions = 128 accumulator
+//     registers.  The matrix instruction's B operand — V[xi][cin][tile] — is computed by the lane that feeds it: lane
+//     (g, n) loads the 4x4 input patch of (cin = 4 s + g, tile n) and applies B^T d B in registers (32 adds), which
+//     yields exactly its B values for all 16 positions of k-step s.  No LDS round trip for the input.
+//   * zero padding comes from the buffer descriptor: out-of-image taps get an out-of-range offset and read as 0.
+//   * the transformed weights U = G g G^T (prepared once per weight version, advstep_conv3x3_prepare_f32) stream
+//     through LDS in 16-channel chunks laid out so one ds_read_b64 fetches a lane's A values for both accumulator
+//     tiles; K <= 64 stays resident, larger K (the input-gradient convolutions, K = 2C) is double-buffered.
+//   * forward: the 32 channels of a workgroup are 16 max-feature-map PAIRS (c, c + C): both halves of a pair land in
+//     the same lane and register slot, and a Winograd tile is exactly one 2x2 pooling window, so
+//     bias -> pair max -> pool -> BatchNorm is register-only; selection goes out as one byte per pooled output (the
+//     format of advstep_mfm_pool2_forward_f32, consumed by advstep_mfm_pool2_backward_f32).
+//   * input gradient: the same kernel with U built from the rotated, transposed weights and a plain 2x2 store.
+// Winograd in fp32 rounds differently from a direct convolution (as MIOpen's own Winograd does): tests compare against
+// ATen / MIOpen with a tolerance, selection flips are counted.
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "advstep_lcnn.h"
+
+namespace {
+
+constexpr int kWaves = 8, kThreads = kWaves * 64;
+constexpr int kChunkCin = 16;                         // input channels per LDS chunk
+constexpr int kChunkFloats = 16 * kChunkCin * 32;     // [xi][cin][16 j][2 m] = 32 KB
+constexpr int kMaxResident = 4;                       // chunks kept in LDS when K <= 64
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+inline hipStream_t as_stream(advstep_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+inline int status_after_launch() { return hipGetLastError() == hipSuccess ? ADVSTEP_OK : ADVSTEP_ELAUNCH; }
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+__device__ __forceinline__ bool mfm_takes_b(float a, float b) { return !(a != a) && !(a >= b); }
+
+// same selection rule as lcnn_mfm.hip::pool_select
+__device__ __forceinline__ float pool_select(float a00, float b00, float a01, float b01, float a10, float b10,
+                                             float a11, float b11, int &code) {
+    const bool t00 = mfm_takes_b(a00, b00), t01 = mfm_takes_b(a01, b01);
+    const bool t10 = mfm_takes_b(a10, b10), t11 = mfm_takes_b(a11, b11);
+    const float m00 = t00 ? b00 : a00, m01 = t01 ? b01 : a01, m10 = t10 ? b10 : a10, m11 = t11 ? b11 : a11;
+    float best = -INFINITY;
+    int pos = 0;
+    bool tb = t00;
+    if (m00 > best || m00 != m00) { best = m00; pos = 0; tb = t00; }
+    if (m01 > best || m01 != m01) { best = m01; pos = 1; tb = t01; }
+    if (m10 > best || m10 != m10) { best = m10; pos = 2; tb = t10; }
+    if (m11 > best || m11 != m11) { best = m11; pos = 3; tb = t11; }
+    code = ((int)tb << 2) | pos;
+    return best;
+}
+
+// ---- weight transform: U = G g G^T into the chunked layout ------------------------------------------------------------
+// mode 0 (forward, max-feature-map pairs): output row (slice, j, m) = conv channel m * C + slice * 16 + j, g = weight.
+// mode 1 (input gradient): the convolution that maps d(conv out) (2C channels) to d(conv in) (Cin channels) has kernel
+//         g'[ci][co][a][b] = weight[co][ci][2 - a][2 - b]; output row (slice, j, m) = input channel slice*32 + m*16 + j.
+// U: [slice][chunk][xi][16 cin][16 j][2 m], zero where a row / channel does not exist.
+__global__ void wino_prepare_kernel(const float *__restrict__ weight, float *__restrict__ U, int Cin, int Cout, int mode,
+                                    int slices, int chunks) {
+    const int K = mode == 0 ? Cin : Cout;        // reduction channels
+    const int total = slices * 32 * K;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int k = i % K, row = i / K, slice = row / 32, jm = row % 32, j = jm % 16, m = jm / 16;
+    float g[3][3];
+    bool live;
+    if (mode == 0) {
+        const int C = Cout / 2, c = slice * 16 + j;
+        live = c < C;
+        const int co = m * C + c;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) g[a][b] = live ? weight[((int64_t)co * Cin + k) * 9 + a * 3 + b] : 0.0f;
+    } else {
+        const int ci = slice * 32 + m * 16 + j;
+        live = ci < Cin;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) g[a][b] = live ? weight[((int64_t)k * Cin + ci) * 9 + (2 - a) * 3 + (2 - b)] : 0.0f;
+    }
+    // G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
+    float t[4][3], u[4][4];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        t[0][b] = g[0][b];
+        t[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]);
+        t[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
+        t[3][b] = g[2][b];
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        u[a][0] = t[a][0];
+        u[a][1] = 0.5f * (t[a][0] + t[a][1] + t[a][2]);
+        u[a][2] = 0.5f * (t[a][0] - t[a][1] + t[a][2]);
+        u[a][3] = t[a][2];
+    }
+    const int chunk = k / kChunkCin, kc = k % kChunkCin;
+    float *dst = U + ((int64_t)(slice * chunks + chunk)) * kChunkFloats + (kc * 16 + j) * 2 + m;
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi) dst[xi * (kChunkCin * 32)] = u[xi >> 2][xi & 3];
+}
+
+// ---- the convolution ---------------------------------------------------------------------------------------------------
+// EPI 0: plain store of min(32, Cout - slice * 32) channels per slice (the input-gradient convolution).
+// EPI 1: bias + max-feature-map + 2x2 pool [+ BatchNorm]; Cout = number of max-feature-map channels C.
+// STREAM: K > 64, U chunks double-buffered through LDS (one barrier per chunk); otherwise all chunks stay resident.
+// grid = slices * ranges workgroups; workgroup b: slice b % slices, tile range b / slices.
+template <int EPI, bool STREAM>
+__global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restrict__ x, const float *__restrict__ U,
+                                                           const float *__restrict__ bias,
+                                                           const float *__restrict__ bn_mean,
+                                                           const float *__restrict__ bn_invstd, float *__restrict__ y,
+                                                           uint8_t *__restrict__ idx, int N, int K, int H, int W, int Cout,
+                                                           int slices, int ranges) {
+    extern __shared__ __attribute__((aligned(16))) float u_s[];
+    const int slice = blockIdx.x % slices, range = blockIdx.x / slices;
+    const int chunks = K / kChunkCin, steps = K / 4;
+    const float *Usl = U + (int64_t)slice * chunks * kChunkFloats;
+    auto copy_chunk = [&](int chunk, int buf) {
+        const float4 *src = reinterpret_cast<const float4 *>(Usl + (int64_t)chunk * kChunkFloats);
+        float4 *dst = reinterpret_cast<float4 *>(u_s + buf * kChunkFloats);
+#pragma unroll
+        for (int i = 0; i < kChunkFloats / 4 / kThreads; ++i) dst[threadIdx.x + i * kThreads] = src[threadIdx.x + i * kThreads];
+    };
+    if (!STREAM) {
+        for (int c = 0; c < chunks; ++c) copy_chunk(c, c);
+        __syncthreads();
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, nl = lane & 15;
+    const int TH = (H + 1) >> 1, TW = (W + 1) >> 1;
+    const int tiles = N * TH * TW, groups = (tiles + 15) >> 4;
+    const int iters = (groups + ranges * kWaves - 1) / (ranges * kWaves);   // the same for every workgroup
+    const uint32_t plane = (uint32_t)(H * W);
+    // raw buffer over x: an out-of-range offset reads as 0 — the convolution's zero padding, for free
+    const __amdgpu_buffer_rsrc_t xr =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x), 0, (int)((size_t)N * K * plane * 4), 0x00020000);
+
+    for (int it = 0; it < iters; ++it) {
+        const int grp = (it * ranges + range) * kWaves + wave;
+        const int t = grp * 16 + nl;
+        const bool valid = grp < groups && t < tiles;
+        const int tt = valid ? t : 0;
+        const int n = tt / (TH * TW), rem = tt - n * (TH * TW), th = rem / TW, tw = rem - th * TW;
+        uint32_t voff[4][4];
+        const uint32_t lane_base = ((uint32_t)(n * K + g)) * plane;
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int hh = 2 * th - 1 + p, ww = 2 * tw - 1 + q;
+                const bool ok = valid && hh >= 0 && hh < H && ww >= 0 && ww < W;
+                voff[p][q] = ok ? (lane_base + (uint32_t)(hh * W + ww)) * 4u : 0x80000000u;
+            }
+        f32x4 acc[16][2];
+
+        auto load_patch = [&](float (&dst)[4][4], int s) {
+            const uint32_t soff = (uint32_t)(4 * s) * plane * 4u;
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    dst[p][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, voff[p][q], soff, 0));
+        };
+        // one k-step: V = B^T d B for this lane's (cin, tile), then 32 matrix instructions
+        auto step = [&](const float (&d)[4][4], const float *us, auto first) {
+            float tr[4][4], v[4][4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                tr[0][q] = d[0][q] - d[2][q];
+                tr[1][q] = d[1][q] + d[2][q];
+                tr[2][q] = d[2][q] - d[1][q];
+                tr[3][q] = d[1][q] - d[3][q];
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                v[a][0] = tr[a][0] - tr[a][2];
+                v[a][1] = tr[a][1] + tr[a][2];
+                v[a][2] = tr[a][2] - tr[a][1];
+                v[a][3] = tr[a][1] - tr[a][3];
+            }
+#pragma unroll
+            for (int xi = 0; xi < 16; ++xi) {
+                const f32x2 a = *reinterpret_cast<const f32x2 *>(us + xi * (kChunkCin * 32));
+                const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+                acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, v[xi >> 2][xi & 3], decltype(first)::value ? zero : acc[xi][0], 0, 0, 0);
+                acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, v[xi >> 2][xi & 3], decltype(first)::value ? zero : acc[xi][1], 0, 0, 0);
+            }
+        };
+        // lane's A address inside a chunk buffer for k-step s: cin_in_chunk = (s & 3) * 4 + g
+        auto a_ptr = [&](int s, int buf) { return u_s + buf * kChunkFloats + (((s & 3) * 4 + g) * 16 + nl) * 2; };
+
+        float da[4][4], db[4][4];
+        if (STREAM) {
+            __syncthreads();            // previous iteration's readers are done with both buffers
+            copy_chunk(0, 0);
+            __syncthreads();
+        }
+        load_patch(da, 0);
+        load_patch(db, 1);
+        step(da, a_ptr(0, 0), std::true_type{});
+        load_patch(da, 2);
+        step(db, a_ptr(1, 0), std::false_type{});
+        if (STREAM) copy_chunk(1, 1);   // chunks >= 2 always here; lands while chunk 0's last steps run
+#pragma unroll 1
+        for (int s = 2; s < steps; s += 2) {
+            if (STREAM && (s & 3) == 0) {
+                __syncthreads();        // chunk s/4 is complete in its buffer; chunk s/4 - 1 is free
+                if (s / 4 + 1 < chunks) copy_chunk(s / 4 + 1, (s / 4 + 1) & 1);
+            }
+            const int buf = STREAM ? ((s >> 2) & 1) : (s >> 2);
+            load_patch(db, s + 1);      // in flight while this step's matrix instructions run
+            step(da, a_ptr(s, buf), std::false_type{});
+            if (s + 2 < steps) load_patch(da, s + 2);
+            step(db, a_ptr(s + 1, buf), std::false_type{});
+        }
+
+        // epilogue: Y = A^T M A per (channel, tile)
+        const int Ho = H >> 1, Wo = W >> 1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float yy[2][2][2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                float s0[4], s1[4];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    s0[b] = acc[0 + b][m][r] + acc[4 + b][m][r] + acc[8 + b][m][r];
+                    s1[b] = acc[4 + b][m][r] - acc[8 + b][m][r] - acc[12 + b][m][r];
+                }
+                yy[m][0][0] = s0[0] + s0[1] + s0[2];
+                yy[m][0][1] = s0[1] - s0[2] - s0[3];
+                yy[m][1][0] = s1[0] + s1[1] + s1[2];
+                yy[m][1][1] = s1[1] - s1[2] - s1[3];
+            }
+            if (EPI == 1) {
+                const int ch = slice * 16 + 4 * g + r;
+                const bool live = ch < Cout;
+                const int chs = live ? ch : 0;
+                const float ba = bias ? bias[chs] : 0.0f, bb = bias ? bias[chs + Cout] : 0.0f;
+                int code;
+                float vbest = pool_select(yy[0][0][0] + ba, yy[1][0][0] + bb, yy[0][0][1] + ba, yy[1][0][1] + bb,
+                                          yy[0][1][0] + ba, yy[1][1][0] + bb, yy[0][1][1] + ba, yy[1][1][1] + bb, code);
+                if (bn_mean) vbest = (vbest - bn_mean[chs]) * bn_invstd[chs];
+                if (valid && live && th < Ho && tw < Wo) {
+                    const size_t o = ((size_t)n * Cout + ch) * Ho * Wo + (size_t)th * Wo + tw;
+                    y[o] = vbest;
+                    idx[o] = (uint8_t)code;
+                }
+            } else {
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const int ch = slice * 32 + m * 16 + 4 * g + r;
+                    if (!(valid && ch < Cout)) continue;
+                    float *o = y + (((size_t)n * Cout + ch) * H + 2 * th) * W + 2 * tw;
+                    const bool h1 = 2 * th + 1 < H;
+                    if ((W & 1) == 0) {   // rows are 8-byte aligned: one 64-bit store per tile row
+                        *reinterpret_cast<f32x2 *>(o) = (f32x2){yy[m][0][0], yy[m][0][1]};
+                        if (h1) *reinterpret_cast<f32x2 *>(o + W) = (f32x2){yy[m][1][0], yy[m][1][1]};
+                    } else {
+                        const bool w1 = 2 * tw + 1 < W;
+                        o[0] = yy[m][0][0];
+                        if (w1) o[1] = yy[m][0][1];
+                        if (h1) {
+                            o[W] = yy[m][1][0];
+                            if (w1) o[W + 1] = yy[m][1][1];
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int EPI>
+int launch_wino(const float *x, const float *U, const float *bias, const float *bn_mean, const float *bn_invstd, float *y,
+                uint8_t *idx, int64_t N, int64_t K, int64_t H, int64_t W, int64_t Cout, int slices, hipStream_t st) {
+    int cus = 256;
+    const int chunks = (int)(K / kChunkCin);
+    const bool stream = chunks > kMaxResident;
+    int ranges = cus / slices;
+    const int64_t groups = ceil_div(N * ((H + 1) / 2) * ((W + 1) / 2), 16);
+    if ((int64_t)ranges * kWaves > groups) ranges = (int)ceil_div(groups, kWaves);
+    if (ranges < 1) ranges = 1;
+    const size_t lds = (size_t)(stream ? 2 : chunks) * kChunkFloats * sizeof(float);
+    const dim3 grid((unsigned)(slices * ranges)), block(kThreads);
+    if (stream) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(wino3x3_kernel<EPI, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((wino3x3_kernel<EPI, true>), grid, block, lds, st, x, U, bias, bn_mean, bn_invstd, y, idx, (int)N,
+                           (int)K, (int)H, (int)W, (int)Cout, slices, ranges);
+    } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(wino3x3_kernel<EPI, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((wino3x3_kernel<EPI, false>), grid, block, lds, st, x, U, bias, bn_mean, bn_invstd, y, idx, (int)N,
+                           (int)K, (int)H, (int)W, (int)Cout, slices, ranges);
+    }
+    return status_after_launch();
+}
+
+}  // namespace
+
+#define WINO_REQUIRE(cond) \
+    do {                   \
+        if (!(cond)) return ADVSTEP_EINVAL; \
+    } while (0)
+
+extern "C" {
+
+int advstep_conv3x3_supported(int64_t Cin, int64_t Cout) {
+    return Cin >= 32 && Cin % 16 == 0 && Cout >= 32 && Cout % 32 == 0 && Cin <= 256 && Cout <= 256;
+}
+
+size_t advstep_conv3x3_prepared_floats(int64_t Cin, int64_t Cout, int mode) {
+    if (!advstep_conv3x3_supported(Cin, Cout) || (mode != 0 && mode != 1)) return 0;
+    const int64_t K = mode == 0 ? Cin : Cout;
+    const int64_t slices = mode == 0 ? ceil_div(Cout / 2, 16) : ceil_div(Cin, 32);
+    return (size_t)(slices * (K / kChunkCin) * kChunkFloats);
+}
+
+int advstep_conv3x3_prepare_f32(const float *weight, float *U, int64_t Cin, int64_t Cout, int mode,
+                                advstep_stream_t stream) {
+    WINO_REQUIRE(weight && U && advstep_conv3x3_supported(Cin, Cout) && (mode == 0 || mode == 1));
+    const int K = (int)(mode == 0 ? Cin : Cout);
+    const int slices = (int)(mode == 0 ? ceil_div(Cout / 2, 16) : ceil_div(Cin, 32));
+    const int total = slices * 32 * K;
+    hipLaunchKernelGGL(wino_prepare_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, as_stream(stream), weight, U,
+                       (int)Cin, (int)Cout, mode, slices, K / kChunkCin);
+    return status_after_launch();
+}
+
+int advstep_conv3x3_mfm_pool2_forward_f32(const float *x, const float *U, const float *bias, const float *bn_mean,
+                                          const float *bn_invstd, float *y, uint8_t *idx, int64_t N, int64_t Cin, int64_t C,
+                                          int64_t H, int64_t W, advstep_stream_t stream) {
+    WINO_REQUIRE(N >= 0 && H >= 0 && W >= 0 && advstep_conv3x3_supported(Cin, 2 * C));
+    if (N == 0 || H / 2 == 0 || W / 2 == 0) return ADVSTEP_OK;
+    WINO_REQUIRE(x && U && y && idx && (bn_mean == nullptr) == (bn_invstd == nullptr));
+    WINO_REQUIRE((uint64_t)N * Cin * H * W * 4 < (1ull << 31) && (uint64_t)N * ((H + 1) / 2) * ((W + 1) / 2) < (1ull << 31));
+    return launch_wino<1>(x, U, bias, bn_mean, bn_invstd, y, idx, N, Cin, H, W, C, (int)ceil_div(C, 16), as_stream(stream));
+}
+
+int advstep_conv3x3_backward_data_f32(const float *gout, const float *U, float *gx, int64_t N, int64_t Cin, int64_t Cout,
+                                      int64_t H, int64_t W, advstep_stream_t stream) {
+    WINO_REQUIRE(N >= 0 && H >= 0 && W >= 0 && advstep_conv3x3_supported(Cin, Cout));
+    if (N == 0 || H == 0 || W == 0) return ADVSTEP_OK;
+    WINO_REQUIRE(gout && U && gx);
+    WINO_REQUIRE((uint64_t)N * Cout * H * W * 4 < (1ull << 31) && (uint64_t)N * ((H + 1) / 2) * ((W + 1) / 2) < (1ull << 31));
+    return launch_wino<0>(gout, U, nullptr, nullptr, nullptr, gx, nullptr, N, Cout, H, W, Cin, (int)ceil_div(Cin, 32),
+                          as_stream(stream));
+}
+
+}  // extern "C"

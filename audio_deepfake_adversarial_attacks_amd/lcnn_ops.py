@@ -206,6 +206,95 @@ def conv1x1_mfm(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tens
     return _Conv1x1Mfm.apply(x.contiguous(), weight.contiguous(), bias, bn)
 
 
+# ---- 3x3 blocks on the matrix cores (csrc/lcnn_wino.hip) -------------------------------------------------------------------
+
+def _prepared_weights(weight: torch.Tensor, mode: int) -> torch.Tensor:
+    """U = G g G^T in the kernel's layout.  Cached ON the weight tensor object (a model's Parameter lives as long as the
+    model) and keyed by its version counter, which every in-place update — optimizer step, load_state_dict — bumps."""
+    cache = getattr(weight, "_advstep_wino", None)
+    if cache is None or cache[0] != (weight._version, weight.data_ptr()):
+        cache = ((weight._version, weight.data_ptr()), {})
+        try:
+            weight._advstep_wino = cache
+        except AttributeError:      # exotic tensor subclasses without a __dict__: just do not cache
+            pass
+    U = cache[1].get(mode)
+    if U is None:
+        Cout, Cin = weight.shape[0], weight.shape[1]
+        lib = _lib.load()
+        U = torch.empty(lib.advstep_conv3x3_prepared_floats(Cin, Cout, mode), dtype=torch.float32, device=weight.device)
+        with _Launch("conv3x3_prepare", weight.device):
+            st = lib.advstep_conv3x3_prepare_f32(weight.data_ptr(), U.data_ptr(), Cin, Cout, mode, _stream(weight.device))
+        _lib.check(st, "advstep_conv3x3_prepare_f32")
+        cache[1][mode] = U
+    return U
+
+
+def _batch_chunks(N: int, per_sample_floats: int):
+    """The kernels address a tensor through a 32-bit buffer descriptor: < 2 GiB per call, split the batch otherwise."""
+    step = max(1, ((1 << 31) - 1) // (4 * per_sample_floats))
+    return [(lo, min(N, lo + step)) for lo in range(0, N, step)]
+
+
+class _Conv3x3MfmPool2(torch.autograd.Function):
+    """Conv2d(3x3, pad 1) + bias + max-feature-map + 2x2 pool [+ eval BatchNorm] in one kernel; differentiable w.r.t.
+    the input only (the weights must not require grad: the attacks freeze them)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, bn, U, U_grad):
+        _require(x, "x"), _require(weight, "weight")
+        if bias is not None:
+            _require(bias, "bias")
+        N, Cin, H, W = x.shape
+        C = weight.shape[0] // 2
+        bn_mean, bn_invstd = _bn_ptrs(bn)
+        y = torch.empty((N, C, H // 2, W // 2), dtype=x.dtype, device=x.device)
+        idx = torch.empty(max(y.numel(), 2), dtype=torch.uint8, device=x.device)
+        lib = _lib.load()
+        per_out = C * (H // 2) * (W // 2)
+        for lo, hi in _batch_chunks(N, max(Cin * H * W, 1)):
+            with _Launch("conv3x3_mfm_pool2_forward", x.device):
+                st = lib.advstep_conv3x3_mfm_pool2_forward_f32(
+                    x[lo:hi].data_ptr(), U.data_ptr(), bias.data_ptr() if bias is not None else None, bn_mean, bn_invstd,
+                    y[lo:hi].data_ptr() if hi > lo else None, idx.data_ptr() + lo * per_out, hi - lo, Cin, C, H, W,
+                    _stream(x.device))
+            _lib.check(st, "advstep_conv3x3_mfm_pool2_forward_f32")
+        ctx.save_for_backward(idx, U_grad, *([bn[1]] if bn is not None else []))
+        ctx.shape = (N, Cin, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        idx, U, *scale = ctx.saved_tensors
+        N, Cin, C, H, W = ctx.shape
+        gy = gy.contiguous()
+        lib = _lib.load()
+        # d(conv out) (N, 2C, H, W): the pooled gradient goes to the winning position of the winning half
+        gconv = torch.empty((N, 2 * C, H, W), dtype=gy.dtype, device=gy.device)
+        with _Launch("mfm_pool2_backward", gy.device):
+            st = lib.advstep_mfm_pool2_backward_f32(gy.data_ptr(), idx.data_ptr(), scale[0].data_ptr() if scale else None,
+                                                    gconv.data_ptr(), N, C, H, W, _stream(gy.device))
+        _lib.check(st, "advstep_mfm_pool2_backward_f32")
+        gx = torch.empty((N, Cin, H, W), dtype=gy.dtype, device=gy.device)
+        for lo, hi in _batch_chunks(N, max(2 * C * H * W, 1)):
+            with _Launch("conv3x3_backward_data", gy.device):
+                st = lib.advstep_conv3x3_backward_data_f32(gconv[lo:hi].data_ptr(), U.data_ptr(), gx[lo:hi].data_ptr(), hi - lo,
+                                                           Cin, 2 * C, H, W, _stream(gy.device))
+            _lib.check(st, "advstep_conv3x3_backward_data_f32")
+        return gx, None, None, None, None, None
+
+
+def conv3x3_supported(in_channels: int, out_channels: int) -> bool:
+    return bool(_lib.load().advstep_conv3x3_supported(in_channels, out_channels))
+
+
+def conv3x3_mfm_pool2(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn=None) -> torch.Tensor:
+    """MaxPool2d(2, 2)(MFM(conv2d(x, weight, bias, padding=1))) [then eval BatchNorm], Winograd on the matrix cores."""
+    weight = weight if weight.is_contiguous() else weight.contiguous()
+    return _Conv3x3MfmPool2.apply(x.contiguous(), weight, bias, bn, _prepared_weights(weight, 0), _prepared_weights(weight, 1))
+
+
+
 class _LstmLayer(torch.autograd.Function):
     """One (bi)directional LSTM layer, sequence-first, zero initial state; input gradient only."""
 

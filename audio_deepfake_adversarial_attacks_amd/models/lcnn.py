@@ -135,6 +135,16 @@ def _fused_conv1x1_enabled() -> bool:
     return os.environ.get("ADVSTEP_LCNN_CONV1X1", "1") != "0"
 
 
+def _fused_conv3x3_enabled() -> bool:
+    """ADVSTEP_LCNN_CONV3X3=0 keeps MIOpen's convolution for the 3x3 + pool blocks (A/B measurements); default on."""
+    return os.environ.get("ADVSTEP_LCNN_CONV3X3", "1") != "0"
+
+
+def _is_same_conv3x3(conv: nn.Conv2d) -> bool:
+    return (_pair(conv.kernel_size) == (3, 3) and _pair(conv.stride) == (1, 1) and _pair(conv.padding) == (1, 1)
+            and _pair(conv.dilation) == (1, 1) and conv.groups == 1)
+
+
 def _is_pointwise_conv(conv: nn.Conv2d) -> bool:
     return (_pair(conv.kernel_size) == (1, 1) and _pair(conv.stride) == (1, 1) and _pair(conv.padding) == (0, 0)
             and _pair(conv.dilation) == (1, 1) and conv.groups == 1 and conv.out_channels % 2 == 0)
@@ -206,6 +216,12 @@ class BaseLCNN(nn.Module):
                         and not isinstance(after, nn.MaxPool2d) and _fused_conv1x1_enabled()):
                     # 1x1 conv + bias + MFM (+ BN) in ONE kernel: the 2C-channel conv output never exists
                     x = lcnn_ops.conv1x1_mfm(x, m.weight, m.bias, bn)
+                    i += consumed
+                    continue
+                if (params_frozen and pooled and _is_same_conv3x3(m) and _fused_conv3x3_enabled()
+                        and lcnn_ops.conv3x3_supported(m.in_channels, m.out_channels)):
+                    # 3x3 conv (Winograd on the matrix cores) + bias + MFM + pool (+ BN) in ONE kernel
+                    x = lcnn_ops.conv3x3_mfm_pool2(x, m.weight, m.bias, bn)
                     i += consumed
                     continue
                 fold_bias = m.bias is not None and not (torch.is_grad_enabled() and m.bias.requires_grad)

@@ -89,6 +89,32 @@ int advstep_conv1x1_mfm_forward_f32(const float *x, const float *weight, const f
 int advstep_conv1x1_mfm_backward_f32(const float *gy, const void *sel, const float *weight, const float *gscale,
                                      float *gx, int64_t N, int64_t Cin, int64_t C, int64_t P, advstep_stream_t stream);
 
+/* ---- 3x3 blocks fused on the matrix cores: Conv2d(Cin, 2C, (3,3), padding 1) -> MaxFeatureMap2D -> MaxPool2d(2, 2)
+ * [-> BatchNorm2d(eval, affine=False)]   (src/models/lcnn.py:128-131, 135-137, 149-154)
+ * Winograd F(2x2, 3x3): the 16 per-position GEMMs run on v_mfma_f32_16x16x4_f32 (fp32 in / fp32 accumulate), the
+ * max-feature-map pair maximum, the pool and the BatchNorm are the kernel's epilogue: the 2C-channel conv output is never
+ * written.  Rounds like any fp32 Winograd convolution (MIOpen's included), i.e. not bit-equal to a direct convolution.
+ *
+ * The weights enter pre-transformed (U = G g G^T in the kernel's chunked LDS layout); prepare once per weight version:
+ *   mode 0: forward operand, from weight (2C, Cin, 3, 3);
+ *   mode 1: operand of the input-gradient convolution (rotated, transposed kernel), from the same weight tensor.
+ * advstep_conv3x3_prepared_floats() floats are written.  Cin % 16 == 0, Cin >= 32, (2C) % 32 == 0 (LCNN: 32/48/64 ->
+ * 96/128/64); every tensor of a call must be smaller than 2 GiB (the caller splits the batch otherwise). */
+int advstep_conv3x3_supported(int64_t Cin, int64_t Cout);
+size_t advstep_conv3x3_prepared_floats(int64_t Cin, int64_t Cout, int mode);
+int advstep_conv3x3_prepare_f32(const float *weight, float *U, int64_t Cin, int64_t Cout, int mode,
+                                advstep_stream_t stream);
+
+/* x (N, Cin, H, W), U (mode 0), bias (2C) or NULL, bn_mean / bn_invstd (C) or both NULL -> y (N, C, H/2, W/2) and one
+ * selection byte per output (the encoding of advstep_mfm_pool2_forward_f32: its backward kernel consumes it). */
+int advstep_conv3x3_mfm_pool2_forward_f32(const float *x, const float *U, const float *bias, const float *bn_mean,
+                                          const float *bn_invstd, float *y, uint8_t *idx, int64_t N, int64_t Cin,
+                                          int64_t C, int64_t H, int64_t W, advstep_stream_t stream);
+
+/* Input gradient of a Conv2d(Cin, Cout, (3,3), padding 1): gx (N, Cin, H, W) from gout (N, Cout, H, W) and U (mode 1). */
+int advstep_conv3x3_backward_data_f32(const float *gout, const float *U, float *gx, int64_t N, int64_t Cin, int64_t Cout,
+                                      int64_t H, int64_t W, advstep_stream_t stream);
+
 /* ---- recurrent part of a (bi)directional LSTM layer  (src/models/lcnn.py:24-46: nn.LSTM(160, 80, bidirectional)) ------
  * The input projections are computed by the caller with one GEMM:
  *   gx (T, B, D, 4H) = W_ih x_t + b_ih + b_hh per direction d (D = 1 or 2; d = 1 runs over time in reverse),

@@ -120,6 +120,7 @@ def test_fused_lcnn_is_bit_identical_to_plain_lcnn(cuda, monkeypatch):
     # the convolution-fusing kernels round differently from MIOpen; this test isolates the max-feature-map kernels
     monkeypatch.setenv("ADVSTEP_LCNN_CONV0", "0")
     monkeypatch.setenv("ADVSTEP_LCNN_CONV1X1", "0")
+    monkeypatch.setenv("ADVSTEP_LCNN_CONV3X3", "0")
     monkeypatch.setenv("ADVSTEP_LCNN_LSTM", "0")
     monkeypatch.setenv("ADVSTEP_LCNN_BN", "0")
     monkeypatch.setenv("ADVSTEP_FUSED_LFCC", "0")
@@ -209,6 +210,7 @@ def test_lcnn_with_fused_first_block_agrees_with_miopen_path(cuda, monkeypatch):
     def run(conv0):
         monkeypatch.setenv("ADVSTEP_LCNN_CONV0", "1" if conv0 else "0")
         monkeypatch.setenv("ADVSTEP_LCNN_CONV1X1", "1" if conv0 else "0")
+        monkeypatch.setenv("ADVSTEP_LCNN_CONV3X3", "1" if conv0 else "0")
         monkeypatch.setenv("ADVSTEP_LCNN_LSTM", "1" if conv0 else "0")
         a = spec.clone().requires_grad_(True)
         z = model._compute_embedding(a)
@@ -337,3 +339,71 @@ def test_folded_batchnorm_matches_aten(L, cuda, kind):
     (g_got,) = torch.autograd.grad(got, x, gy)
     assert (got - ref).abs().max().item() <= tol * max(ref.abs().max().item(), 1.0)
     assert (g_got - g_ref).abs().max().item() <= max(tol, 2e-6) * max(g_ref.abs().max().item(), 1.0)
+
+
+# ---- fused 3x3 blocks on the matrix cores: Conv2d(Cin, 2C, 3x3, pad 1) -> MFM -> MaxPool2d(2, 2) [-> BN] ---------------------
+
+@pytest.mark.parametrize("N,Cin,C,H,W", [(2, 32, 48, 12, 10), (1, 48, 64, 11, 9), (2, 64, 32, 50, 10), (3, 32, 32, 6, 8),
+                                         (2, 32, 48, 202, 40), (1, 48, 64, 101, 20), (5, 32, 16, 2, 2)])
+@pytest.mark.parametrize("with_bias,with_bn", [(True, True), (False, False)])
+def test_conv3x3_mfm_pool2_matches_float64_reference(L, cuda, N, Cin, C, H, W, with_bias, with_bn):
+    """Winograd F(2x2, 3x3) in fp32 against a float64 direct convolution: values within 1e-5 of the output scale (the
+    same error class as MIOpen's own fp32 Winograd kernel); the input gradient is compared through the kernel's OWN
+    selection (a last-bit difference may pick another pooling winner at a near tie, which is a different, equally valid
+    subgradient), so the float64 reference is evaluated with the recorded winners."""
+    g = torch.Generator().manual_seed(N * 1000 + Cin * 10 + C + H)
+    x = torch.randn(N, Cin, H, W, generator=g).to(cuda)
+    weight = (torch.randn(2 * C, Cin, 3, 3, generator=g) * 0.1).to(cuda)
+    bias = torch.randn(2 * C, generator=g).to(cuda) if with_bias else None
+    bn = None
+    if with_bn:
+        mean = torch.randn(C, generator=g).to(cuda)
+        var = (torch.rand(C, generator=g) + 0.5).to(cuda)
+        bn = (mean, (1.0 / torch.sqrt(var + 1e-5)).contiguous())
+    xr = x.double().requires_grad_(True)
+    conv = torch.nn.functional.conv2d(xr, weight.double(), bias.double() if with_bias else None, padding=1)
+    y_ref = ref_mfm_pool(conv)
+    if with_bn:
+        y_ref = (y_ref - bn[0].double().view(1, -1, 1, 1)) * bn[1].double().view(1, -1, 1, 1)
+    xa = x.clone().requires_grad_(True)
+    y = L.conv3x3_mfm_pool2(xa, weight, bias, bn)
+    assert y.shape == y_ref.shape == (N, C, H // 2, W // 2)
+    scale = max(y_ref.abs().max().item(), 1.0)
+    assert (y.double() - y_ref).abs().max().item() <= 1e-5 * scale
+    if y.numel() == 0:
+        return
+    gy = torch.randn(y_ref.shape, generator=g).to(cuda)
+    (gx,) = torch.autograd.grad(y, xa, gy)
+    (gx_ref,) = torch.autograd.grad(y_ref, xr, gy.double())
+    err = (gx.double() - gx_ref).abs()
+    tol = 2e-5 * max(gx_ref.abs().max().item(), 1.0)
+    # at most a handful of pooling windows may resolve a near tie differently
+    assert (err > tol).float().mean().item() <= 1e-3, ((err > tol).sum().item(), err.max().item())
+    assert (err.max().item() <= tol) or (err > tol).sum().item() <= 9 * 8 * Cin
+
+
+def test_conv3x3_backward_data_matches_aten(L, cuda):
+    """The input-gradient convolution on its own (K = 96 and K = 128: the double-buffered weight stream)."""
+    from audio_deepfake_adversarial_attacks_amd import _lib
+    from audio_deepfake_adversarial_attacks_amd.lcnn_ops import _prepared_weights
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(5)
+    for N, Cin, Cout, H, W in ((2, 32, 96, 20, 12), (1, 48, 128, 13, 7), (3, 32, 64, 10, 10)):
+        weight = (torch.randn(Cout, Cin, 3, 3, generator=g) * 0.1).to(cuda)
+        gout = torch.randn(N, Cout, H, W, generator=g).to(cuda)
+        want = torch.nn.grad.conv2d_input((N, Cin, H, W), weight.double(), gout.double(), padding=1)
+        gx = torch.empty(N, Cin, H, W, device=cuda)
+        st = lib.advstep_conv3x3_backward_data_f32(gout.data_ptr(), _prepared_weights(weight, 1).data_ptr(), gx.data_ptr(), N, Cin,
+                                                   Cout, H, W, torch.cuda.current_stream().cuda_stream)
+        assert st == 0
+        assert (gx.double() - want).abs().max().item() <= 1e-5 * max(want.abs().max().item(), 1.0), (N, Cin, Cout)
+
+
+def test_conv3x3_rejects_unsupported(L, cuda):
+    assert L.conv3x3_supported(32, 96) and L.conv3x3_supported(48, 128) and L.conv3x3_supported(64, 64)
+    assert not L.conv3x3_supported(1, 64) and not L.conv3x3_supported(32, 48) and not L.conv3x3_supported(40, 64)
+    x = torch.randn(1, 32, 4, 4, device=cuda, requires_grad=True)
+    w = torch.randn(64, 32, 3, 3, device=cuda, requires_grad=True)
+    y = L.conv3x3_mfm_pool2(x, w, None)
+    (gx,) = torch.autograd.grad(y.sum(), x)          # input gradient only: the weight gets none
+    assert gx.shape == x.shape

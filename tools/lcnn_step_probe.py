@@ -22,7 +22,7 @@ def main():
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--repeats", type=int, default=3)
-    ap.add_argument("--arms", default="plain,fused_frozen_torchfft,fused_frozen")
+    ap.add_argument("--arms", default="plain,fused_frozen_miopen3x3,fused_frozen")
     a = ap.parse_args()
     from audio_deepfake_adversarial_attacks_amd.models.models import get_model
     from audio_deepfake_adversarial_attacks_amd.utils import set_seed
@@ -44,6 +44,7 @@ def main():
         os.environ["ADVSTEP_DIRECT_FFT"] = "0" if "torchfft" in arm else "1"
         os.environ["ADVSTEP_LCNN_BN"] = "0" if "nobn" in arm else "1"
         os.environ["ADVSTEP_LCNN_CONV0"] = "0" if "noconv0" in arm else "1"
+        os.environ["ADVSTEP_LCNN_CONV3X3"] = "0" if ("miopen3x3" in arm or arm.startswith("plain")) else "1"
         os.environ["ADVSTEP_LCNN_CONV1X1"] = "0" if ("no1x1" in arm or "noconv0" in arm) else "1"
         frozen = "frozen" in arm
         for p in model.parameters():
