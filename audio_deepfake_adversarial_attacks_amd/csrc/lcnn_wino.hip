@@ -158,15 +158,16 @@ __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restri
         const bool valid = grp < groups && t < tiles;
         const int tt = valid ? t : 0;
         const int n = tt / (TH * TW), rem = tt - n * (TH * TW), th = rem / TW, tw = rem - th * TW;
-        uint32_t voff[4][4];
-        const uint32_t lane_base = ((uint32_t)(n * K + g)) * plane;
+        // patch addressing: one lane base + compile-time (p, q) strides; the 16 validity flags live in scalar registers
+        // as lane masks, and an invalid tap gets an out-of-range offset (reads 0) when the load is issued
+        const uint32_t lane_base = (((uint32_t)(n * K + g)) * plane + (uint32_t)((2 * th - 1) * W + (2 * tw - 1))) * 4u;
+        bool ok[4][4];
 #pragma unroll
         for (int p = 0; p < 4; ++p)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int hh = 2 * th - 1 + p, ww = 2 * tw - 1 + q;
-                const bool ok = valid && hh >= 0 && hh < H && ww >= 0 && ww < W;
-                voff[p][q] = ok ? (lane_base + (uint32_t)(hh * W + ww)) * 4u : 0x80000000u;
+                ok[p][q] = valid && hh >= 0 && hh < H && ww >= 0 && ww < W;
             }
         f32x4 acc[16][2];
 
@@ -175,11 +176,24 @@ __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restri
 #pragma unroll
             for (int p = 0; p < 4; ++p)
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    dst[p][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, voff[p][q], soff, 0));
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t vo = ok[p][q] ? lane_base + (uint32_t)((p * W + q) * 4) : 0x80000000u;
+                    dst[p][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, vo, soff, 0));
+                }
         };
-        // one k-step: V = B^T d B for this lane's (cin, tile), then 32 matrix instructions
+        // one k-step.  The A operands come from LDS in 8 groups (2 Winograd positions x 2 accumulator tiles = one
+        // ds_read2_b64 each); group i + 2 is requested before the 4 matrix instructions of group i issue, and the input
+        // transform V = B^T d B (32 adds) runs behind the first two requests: the LDS latency is never exposed.  The
+        // scheduling barriers pin that order (left alone, the compiler sinks every read next to its use and waits).
         auto step = [&](const float (&d)[4][4], const float *us, auto first) {
+            f32x2 a[8][2];
+            auto request = [&](int grp) {
+                a[grp][0] = *reinterpret_cast<const f32x2 *>(us + (2 * grp) * (kChunkCin * 32));
+                a[grp][1] = *reinterpret_cast<const f32x2 *>(us + (2 * grp + 1) * (kChunkCin * 32));
+            };
+            request(0);
+            request(1);
+            __builtin_amdgcn_sched_barrier(0);
             float tr[4][4], v[4][4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -189,18 +203,24 @@ __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restri
                 tr[3][q] = d[1][q] - d[3][q];
             }
 #pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                v[a][0] = tr[a][0] - tr[a][2];
-                v[a][1] = tr[a][1] + tr[a][2];
-                v[a][2] = tr[a][2] - tr[a][1];
-                v[a][3] = tr[a][1] - tr[a][3];
+            for (int a4 = 0; a4 < 4; ++a4) {
+                v[a4][0] = tr[a4][0] - tr[a4][2];
+                v[a4][1] = tr[a4][1] + tr[a4][2];
+                v[a4][2] = tr[a4][2] - tr[a4][1];
+                v[a4][3] = tr[a4][1] - tr[a4][3];
             }
+            __builtin_amdgcn_sched_barrier(0);
+            const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-            for (int xi = 0; xi < 16; ++xi) {
-                const f32x2 a = *reinterpret_cast<const f32x2 *>(us + xi * (kChunkCin * 32));
-                const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
-                acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, v[xi >> 2][xi & 3], decltype(first)::value ? zero : acc[xi][0], 0, 0, 0);
-                acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, v[xi >> 2][xi & 3], decltype(first)::value ? zero : acc[xi][1], 0, 0, 0);
+            for (int grp = 0; grp < 8; ++grp) {
+                if (grp + 2 < 8) request(grp + 2);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int xi = 2 * grp + e;
+                    acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[grp][e].x, v[xi >> 2][xi & 3], decltype(first)::value ? zero : acc[xi][0], 0, 0, 0);
+                    acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[grp][e].y, v[xi >> 2][xi & 3], decltype(first)::value ? zero : acc[xi][1], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         };
         // lane's A address inside a chunk buffer for k-step s: cin_in_chunk = (s & 3) * 4 + g
