@@ -82,6 +82,27 @@ def main():
             yy.data_ptr(), sel.data_ptr(), ww.data_ptr(), invstd.data_ptr(), gxx.data_ptr(), B, cin, c, P, st),
             bytes_moved=moved)
 
+    # ---- 3x3 blocks on the matrix cores (Winograd): conv + bias + MFM + pool (+BN) forward, input-gradient convolution
+    for name, cin, c, h, wd in (("L6 ", 32, 48, 202, 40), ("L13", 48, 64, 101, 20), ("L25", 32, 32, 50, 10)):
+        xx = torch.randn(B, cin, h, wd, device=dev)
+        ww = torch.randn(2 * c, cin, 3, 3, device=dev) * 0.1
+        bb = torch.randn(2 * c, device=dev)
+        mean, invstd = torch.randn(c, device=dev), torch.rand(c, device=dev) + 0.5
+        yy = torch.empty(B, c, h // 2, wd // 2, device=dev)
+        ii = torch.empty(yy.numel(), dtype=torch.uint8, device=dev)
+        u0 = torch.empty(lib.advstep_conv3x3_prepared_floats(cin, 2 * c, 0), device=dev)
+        u1 = torch.empty(lib.advstep_conv3x3_prepared_floats(cin, 2 * c, 1), device=dev)
+        lib.advstep_conv3x3_prepare_f32(ww.data_ptr(), u0.data_ptr(), cin, 2 * c, 0, st)
+        lib.advstep_conv3x3_prepare_f32(ww.data_ptr(), u1.data_ptr(), cin, 2 * c, 1, st)
+        gout = torch.randn(B, 2 * c, h, wd, device=dev)
+        gxx = torch.empty_like(xx)
+        fl = 2.0 * B * h * wd * cin * 2 * c * 9
+        timeit(f"conv3x3_mfm_pool2_forward {name} ({cin}->{2 * c}, {h}x{wd})", lambda: lib.advstep_conv3x3_mfm_pool2_forward_f32(
+            xx.data_ptr(), u0.data_ptr(), bb.data_ptr(), mean.data_ptr(), invstd.data_ptr(), yy.data_ptr(), ii.data_ptr(), B, cin,
+            c, h, wd, st), flops=fl)
+        timeit(f"conv3x3_backward_data     {name} ({2 * c}->{cin}, {h}x{wd})", lambda: lib.advstep_conv3x3_backward_data_f32(
+            gout.data_ptr(), u1.data_ptr(), gxx.data_ptr(), B, cin, 2 * c, h, wd, st), flops=fl)
+
     # ---- MFM + pool after the 3x3 convolutions
     for name, c, h, wd in (("L6 ", 48, 202, 40), ("L13", 64, 101, 20), ("L25", 32, 50, 10)):
         xx = torch.randn(B, 2 * c, h, wd, device=dev)
