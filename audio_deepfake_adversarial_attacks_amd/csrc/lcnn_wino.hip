@@ -70,8 +70,8 @@ __device__ __forceinline__ float pool_select(float a00, float b00, float a01, fl
 // mode 1 (input gradient): the convolution that maps d(conv out) (2C channels) to d(conv in) (Cin channels) has kernel
 //         g'[ci][co][a][b] = weight[co][ci][2 - a][2 - b]; output row (slice, j, m) = input channel slice*32 + m*16 + j.
 // U: [slice][chunk][xi][16 cin][16 j][2 m], zero where a row / channel does not exist.
-__global__ void wino_prepare_kernel(const float *__restrict__ weight, float *__restrict__ U, int Cin, int Cout, int mode,
-                                    int slices, int chunks) {
+__global__ void wino_prepare_kernel(const float *__restrict__ weight, const float *__restrict__ kscale,
+                                    float *__restrict__ U, int Cin, int Cout, int mode, int slices, int chunks) {
     const int K = mode == 0 ? Cin : Cout;        // reduction channels
     const int total = slices * 32 * K;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -94,6 +94,15 @@ __global__ void wino_prepare_kernel(const float *__restrict__ weight, float *__r
         for (int a = 0; a < 3; ++a)
 #pragma unroll
             for (int b = 0; b < 3; ++b) g[a][b] = live ? weight[((int64_t)k * Cin + ci) * 9 + (2 - a) * 3 + (2 - b)] : 0.0f;
+        // a per-channel factor on d(conv out) — the folded BatchNorm's invstd of max-feature-map channel k % C — is a
+        // factor on row k of the operand
+        if (kscale) {
+            const float f = kscale[k % (Cout / 2)];
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) g[a][b] *= f;
+        }
     }
     // G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
     float t[4][3], u[4][4];
@@ -122,8 +131,14 @@ __global__ void wino_prepare_kernel(const float *__restrict__ weight, float *__r
 // EPI 1: bias + max-feature-map + 2x2 pool [+ BatchNorm]; Cout = number of max-feature-map channels C.
 // STREAM: K > 64, U chunks double-buffered through LDS (one barrier per chunk); otherwise all chunks stay resident.
 // grid = slices * ranges workgroups; workgroup b: slice b % slices, tile range b / slices.
-template <int EPI, bool STREAM>
-__global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restrict__ x, const float *__restrict__ U,
+// SRC 0: the input is a dense tensor x (N, K, H, W).
+// SRC 1: the input is d(conv out) of a max-feature-map + 2x2 pool block, given in its compact form — the pooled gradient
+//        gy (N, C, H/2, W/2) and the selection bytes (advstep_mfm_pool2_forward_f32's encoding), K = 2C: channel k of
+//        half k / C at conv position (h, w) carries gy[k % C][h/2][w/2] if that position of that half won, else 0.  The
+//        4x4 patch of a lane is expanded from the 3x3 pooled cells around its tile; the dense gradient never exists.
+template <int EPI, bool STREAM, int SRC>
+__global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restrict__ x, const uint8_t *__restrict__ xsel,
+                                                           const float *__restrict__ U,
                                                            const float *__restrict__ bias,
                                                            const float *__restrict__ bn_mean,
                                                            const float *__restrict__ bn_invstd, float *__restrict__ y,
@@ -149,8 +164,14 @@ __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restri
     const int iters = (groups + ranges * kWaves - 1) / (ranges * kWaves);   // the same for every workgroup
     const uint32_t plane = (uint32_t)(H * W);
     // raw buffer over x: an out-of-range offset reads as 0 — the convolution's zero padding, for free
+    const int Hs = H >> 1, Ws = W >> 1, Cs = K >> 1;      // SRC 1: pooled grid, max-feature-map channels
+    const uint32_t cplane = (uint32_t)(Hs * Ws);
+    const size_t src_elems = SRC == 0 ? (size_t)N * K * plane : (size_t)N * Cs * cplane;
     const __amdgpu_buffer_rsrc_t xr =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x), 0, (int)((size_t)N * K * plane * 4), 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x), 0, (int)(src_elems * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t sr =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(SRC == 1 ? xsel : reinterpret_cast<const uint8_t *>(x)), 0,
+                                          (int)src_elems, 0x00020000);
 
     for (int it = 0; it < iters; ++it) {
         const int grp = (it * ranges + range) * kWaves + wave;
@@ -162,30 +183,77 @@ __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restri
         // as lane masks, and an invalid tap gets an out-of-range offset (reads 0) when the load is issued
         const uint32_t lane_base = (((uint32_t)(n * K + g)) * plane + (uint32_t)((2 * th - 1) * W + (2 * tw - 1))) * 4u;
         bool ok[4][4];
-#pragma unroll
-        for (int p = 0; p < 4; ++p)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int hh = 2 * th - 1 + p, ww = 2 * tw - 1 + q;
-                ok[p][q] = valid && hh >= 0 && hh < H && ww >= 0 && ww < W;
-            }
-        f32x4 acc[16][2];
-
-        auto load_patch = [&](float (&dst)[4][4], int s) {
-            const uint32_t soff = (uint32_t)(4 * s) * plane * 4u;
+        uint32_t cell[3][3];     // SRC 1: element offsets of the 3x3 pooled cells around the tile (0x20000000 = outside)
+        if (SRC == 0) {
 #pragma unroll
             for (int p = 0; p < 4; ++p)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const uint32_t vo = ok[p][q] ? lane_base + (uint32_t)((p * W + q) * 4) : 0x80000000u;
-                    dst[p][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, vo, soff, 0));
+                    const int hh = 2 * th - 1 + p, ww = 2 * tw - 1 + q;
+                    ok[p][q] = valid && hh >= 0 && hh < H && ww >= 0 && ww < W;
                 }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int ci = th - 1 + i, cj = tw - 1 + j;
+                    const bool in = valid && ci >= 0 && ci < Hs && cj >= 0 && cj < Ws;
+                    cell[i][j] = in ? ((uint32_t)(n * Cs + g)) * cplane + (uint32_t)(ci * Ws + cj) : 0x20000000u;
+                }
+        }
+        f32x4 acc[16][2];
+
+        // a patch in flight: SRC 0 the 16 taps; SRC 1 the 9 pooled gradients + their 9 selection bytes
+        struct Patch {
+            float v[SRC == 0 ? 16 : 9];
+            uint32_t code[SRC == 0 ? 1 : 9];
+        };
+        auto load_patch = [&](Patch &dst, int s) {
+            if (SRC == 0) {
+                const uint32_t soff = (uint32_t)(4 * s) * plane * 4u;
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const uint32_t vo = ok[p][q] ? lane_base + (uint32_t)((p * W + q) * 4) : 0x80000000u;
+                        dst.v[p * 4 + q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, vo, soff, 0));
+                    }
+            } else {
+                const int k0 = 4 * s, c0 = k0 >= Cs ? k0 - Cs : k0;      // wave-uniform: channel of lane group 0
+                const uint32_t soff = (uint32_t)c0 * cplane;
+#pragma unroll
+                for (int i = 0; i < 9; ++i) {
+                    const uint32_t e = cell[i / 3][i % 3];
+                    dst.v[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, e << 2, soff << 2, 0));
+                    dst.code[i] = __builtin_amdgcn_raw_buffer_load_b8(sr, e, soff, 0);
+                }
+            }
+        };
+        // the 4x4 taps of a patch: SRC 1 routes each pooled gradient to the one conv position (of the one half) that won
+        auto taps = [&](const Patch &src, int s, float (&d)[4][4]) {
+            if (SRC == 0) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) d[p][q] = src.v[p * 4 + q];
+            } else {
+                const uint32_t half_bit = 4 * s >= Cs ? 4u : 0u;         // wave-uniform
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int i = ((p + 1) >> 1) * 3 + ((q + 1) >> 1);
+                        const uint32_t want = half_bit | (uint32_t)((((p + 1) & 1) << 1) | ((q + 1) & 1));
+                        d[p][q] = src.code[i] == want ? src.v[i] : 0.0f;
+                    }
+            }
         };
         // one k-step.  The A operands come from LDS in 8 groups (2 Winograd positions x 2 accumulator tiles = one
         // ds_read2_b64 each); group i + 2 is requested before the 4 matrix instructions of group i issue, and the input
         // transform V = B^T d B (32 adds) runs behind the first two requests: the LDS latency is never exposed.  The
         // scheduling barriers pin that order (left alone, the compiler sinks every read next to its use and waits).
-        auto step = [&](const float (&d)[4][4], const float *us, auto first) {
+        auto step = [&](const Patch &patch, int s_idx, const float *us, auto first) {
             f32x2 a[8][2];
             auto request = [&](int grp) {
                 a[grp][0] = *reinterpret_cast<const f32x2 *>(us + (2 * grp) * (kChunkCin * 32));
@@ -194,7 +262,8 @@ __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restri
             request(0);
             request(1);
             __builtin_amdgcn_sched_barrier(0);
-            float tr[4][4], v[4][4];
+            float d[4][4], tr[4][4], v[4][4];
+            taps(patch, s_idx, d);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 tr[0][q] = d[0][q] - d[2][q];
@@ -226,7 +295,7 @@ __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restri
         // lane's A address inside a chunk buffer for k-step s: cin_in_chunk = (s & 3) * 4 + g
         auto a_ptr = [&](int s, int buf) { return u_s + buf * kChunkFloats + (((s & 3) * 4 + g) * 16 + nl) * 2; };
 
-        float da[4][4], db[4][4];
+        Patch da, db;
         if (STREAM) {
             __syncthreads();            // previous iteration's readers are done with both buffers
             copy_chunk(0, 0);
@@ -234,9 +303,9 @@ __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restri
         }
         load_patch(da, 0);
         load_patch(db, 1);
-        step(da, a_ptr(0, 0), std::true_type{});
+        step(da, 0, a_ptr(0, 0), std::true_type{});
         load_patch(da, 2);
-        step(db, a_ptr(1, 0), std::false_type{});
+        step(db, 1, a_ptr(1, 0), std::false_type{});
         if (STREAM) copy_chunk(1, 1);   // chunks >= 2 always here; lands while chunk 0's last steps run
 #pragma unroll 1
         for (int s = 2; s < steps; s += 2) {
@@ -246,9 +315,9 @@ __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restri
             }
             const int buf = STREAM ? ((s >> 2) & 1) : (s >> 2);
             load_patch(db, s + 1);      // in flight while this step's matrix instructions run
-            step(da, a_ptr(s, buf), std::false_type{});
+            step(da, s, a_ptr(s, buf), std::false_type{});
             if (s + 2 < steps) load_patch(da, s + 2);
-            step(db, a_ptr(s + 1, buf), std::false_type{});
+            step(db, s + 1, a_ptr(s + 1, buf), std::false_type{});
         }
 
         // epilogue: Y = A^T M A per (channel, tile)
@@ -308,10 +377,11 @@ __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restri
     }
 }
 
-template <int EPI>
-int launch_wino(const float *x, const float *U, const float *bias, const float *bn_mean, const float *bn_invstd, float *y,
-                uint8_t *idx, int64_t N, int64_t K, int64_t H, int64_t W, int64_t Cout, int slices, hipStream_t st) {
-    int cus = 256;
+template <int EPI, int SRC>
+int launch_wino(const float *x, const uint8_t *xsel, const float *U, const float *bias, const float *bn_mean,
+                const float *bn_invstd, float *y, uint8_t *idx, int64_t N, int64_t K, int64_t H, int64_t W, int64_t Cout,
+                int slices, hipStream_t st) {
+    const int cus = 256;
     const int chunks = (int)(K / kChunkCin);
     const bool stream = chunks > kMaxResident;
     int ranges = cus / slices;
@@ -320,17 +390,13 @@ int launch_wino(const float *x, const float *U, const float *bias, const float *
     if (ranges < 1) ranges = 1;
     const size_t lds = (size_t)(stream ? 2 : chunks) * kChunkFloats * sizeof(float);
     const dim3 grid((unsigned)(slices * ranges)), block(kThreads);
-    if (stream) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(wino3x3_kernel<EPI, true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((wino3x3_kernel<EPI, true>), grid, block, lds, st, x, U, bias, bn_mean, bn_invstd, y, idx, (int)N,
-                           (int)K, (int)H, (int)W, (int)Cout, slices, ranges);
-    } else {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(wino3x3_kernel<EPI, false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((wino3x3_kernel<EPI, false>), grid, block, lds, st, x, U, bias, bn_mean, bn_invstd, y, idx, (int)N,
-                           (int)K, (int)H, (int)W, (int)Cout, slices, ranges);
-    }
+    auto go = [&](auto kernel) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kernel, grid, block, lds, st, x, xsel, U, bias, bn_mean, bn_invstd, y, idx, (int)N, (int)K, (int)H,
+                           (int)W, (int)Cout, slices, ranges);
+    };
+    if (stream) go(wino3x3_kernel<EPI, true, SRC>);
+    else go(wino3x3_kernel<EPI, false, SRC>);
     return status_after_launch();
 }
 
@@ -354,14 +420,15 @@ size_t advstep_conv3x3_prepared_floats(int64_t Cin, int64_t Cout, int mode) {
     return (size_t)(slices * (K / kChunkCin) * kChunkFloats);
 }
 
-int advstep_conv3x3_prepare_f32(const float *weight, float *U, int64_t Cin, int64_t Cout, int mode,
+int advstep_conv3x3_prepare_f32(const float *weight, const float *gscale, float *U, int64_t Cin, int64_t Cout, int mode,
                                 advstep_stream_t stream) {
     WINO_REQUIRE(weight && U && advstep_conv3x3_supported(Cin, Cout) && (mode == 0 || mode == 1));
+    WINO_REQUIRE(gscale == nullptr || mode == 1);
     const int K = (int)(mode == 0 ? Cin : Cout);
     const int slices = (int)(mode == 0 ? ceil_div(Cout / 2, 16) : ceil_div(Cin, 32));
     const int total = slices * 32 * K;
-    hipLaunchKernelGGL(wino_prepare_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, as_stream(stream), weight, U,
-                       (int)Cin, (int)Cout, mode, slices, K / kChunkCin);
+    hipLaunchKernelGGL(wino_prepare_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, as_stream(stream), weight,
+                       gscale, U, (int)Cin, (int)Cout, mode, slices, K / kChunkCin);
     return status_after_launch();
 }
 
@@ -372,7 +439,8 @@ int advstep_conv3x3_mfm_pool2_forward_f32(const float *x, const float *U, const 
     if (N == 0 || H / 2 == 0 || W / 2 == 0) return ADVSTEP_OK;
     WINO_REQUIRE(x && U && y && idx && (bn_mean == nullptr) == (bn_invstd == nullptr));
     WINO_REQUIRE((uint64_t)N * Cin * H * W * 4 < (1ull << 31) && (uint64_t)N * ((H + 1) / 2) * ((W + 1) / 2) < (1ull << 31));
-    return launch_wino<1>(x, U, bias, bn_mean, bn_invstd, y, idx, N, Cin, H, W, C, (int)ceil_div(C, 16), as_stream(stream));
+    return launch_wino<1, 0>(x, nullptr, U, bias, bn_mean, bn_invstd, y, idx, N, Cin, H, W, C, (int)ceil_div(C, 16),
+                             as_stream(stream));
 }
 
 int advstep_conv3x3_backward_data_f32(const float *gout, const float *U, float *gx, int64_t N, int64_t Cin, int64_t Cout,
@@ -381,8 +449,22 @@ int advstep_conv3x3_backward_data_f32(const float *gout, const float *U, float *
     if (N == 0 || H == 0 || W == 0) return ADVSTEP_OK;
     WINO_REQUIRE(gout && U && gx);
     WINO_REQUIRE((uint64_t)N * Cout * H * W * 4 < (1ull << 31) && (uint64_t)N * ((H + 1) / 2) * ((W + 1) / 2) < (1ull << 31));
-    return launch_wino<0>(gout, U, nullptr, nullptr, nullptr, gx, nullptr, N, Cout, H, W, Cin, (int)ceil_div(Cin, 32),
-                          as_stream(stream));
+    return launch_wino<0, 0>(gout, nullptr, U, nullptr, nullptr, nullptr, gx, nullptr, N, Cout, H, W, Cin,
+                             (int)ceil_div(Cin, 32), as_stream(stream));
+}
+
+int advstep_conv3x3_mfm_pool2_backward_f32(const float *gy, const uint8_t *idx, const float *U, float *gx, int64_t N,
+                                           int64_t Cin, int64_t C, int64_t H, int64_t W, advstep_stream_t stream) {
+    WINO_REQUIRE(N >= 0 && H >= 0 && W >= 0 && advstep_conv3x3_supported(Cin, 2 * C));
+    if (N == 0 || H == 0 || W == 0) return ADVSTEP_OK;
+    WINO_REQUIRE(gx);
+    if (H / 2 == 0 || W / 2 == 0)
+        return hipMemsetAsync(gx, 0, (size_t)N * Cin * H * W * sizeof(float), as_stream(stream)) == hipSuccess ? ADVSTEP_OK
+                                                                                                               : ADVSTEP_ELAUNCH;
+    WINO_REQUIRE(gy && idx && U);
+    WINO_REQUIRE((uint64_t)N * C * (H / 2) * (W / 2) < (1ull << 29) && (uint64_t)N * ((H + 1) / 2) * ((W + 1) / 2) < (1ull << 31));
+    return launch_wino<0, 1>(gy, idx, U, nullptr, nullptr, nullptr, gx, nullptr, N, 2 * C, H, W, Cin, (int)ceil_div(Cin, 32),
+                             as_stream(stream));
 }
 
 }  // extern "C"

@@ -208,7 +208,7 @@ def conv1x1_mfm(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tens
 
 # ---- 3x3 blocks on the matrix cores (csrc/lcnn_wino.hip) -------------------------------------------------------------------
 
-def _prepared_weights(weight: torch.Tensor, mode: int) -> torch.Tensor:
+def _prepared_weights(weight: torch.Tensor, mode: int, gscale: Optional[torch.Tensor] = None) -> torch.Tensor:
     """U = G g G^T in the kernel's layout.  Cached ON the weight tensor object (a model's Parameter lives as long as the
     model) and keyed by its version counter, which every in-place update — optimizer step, load_state_dict — bumps."""
     cache = getattr(weight, "_advstep_wino", None)
@@ -218,16 +218,21 @@ def _prepared_weights(weight: torch.Tensor, mode: int) -> torch.Tensor:
             weight._advstep_wino = cache
         except AttributeError:      # exotic tensor subclasses without a __dict__: just do not cache
             pass
-    U = cache[1].get(mode)
+    slot = (mode, None if gscale is None else (gscale.data_ptr(), gscale._version))
+    U = cache[1].get(slot)
     if U is None:
         Cout, Cin = weight.shape[0], weight.shape[1]
         lib = _lib.load()
         U = torch.empty(lib.advstep_conv3x3_prepared_floats(Cin, Cout, mode), dtype=torch.float32, device=weight.device)
         with _Launch("conv3x3_prepare", weight.device):
-            st = lib.advstep_conv3x3_prepare_f32(weight.data_ptr(), U.data_ptr(), Cin, Cout, mode, _stream(weight.device))
+            st = lib.advstep_conv3x3_prepare_f32(weight.data_ptr(), None if gscale is None else gscale.data_ptr(), U.data_ptr(),
+                                                 Cin, Cout, mode, _stream(weight.device))
         _lib.check(st, "advstep_conv3x3_prepare_f32")
-        cache[1][mode] = U
-    return U
+        if len(cache[1]) >= 8:
+            cache[1].clear()
+        cache[1][slot] = (U, gscale)       # keeps the scale tensor alive: its address is part of the key
+        return U
+    return U[0]
 
 
 def _batch_chunks(N: int, per_sample_floats: int):
@@ -259,28 +264,26 @@ class _Conv3x3MfmPool2(torch.autograd.Function):
                     y[lo:hi].data_ptr() if hi > lo else None, idx.data_ptr() + lo * per_out, hi - lo, Cin, C, H, W,
                     _stream(x.device))
             _lib.check(st, "advstep_conv3x3_mfm_pool2_forward_f32")
-        ctx.save_for_backward(idx, U_grad, *([bn[1]] if bn is not None else []))
+        ctx.save_for_backward(idx, U_grad)
         ctx.shape = (N, Cin, C, H, W)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        idx, U, *scale = ctx.saved_tensors
+        idx, U = ctx.saved_tensors
         N, Cin, C, H, W = ctx.shape
         gy = gy.contiguous()
         lib = _lib.load()
-        # d(conv out) (N, 2C, H, W): the pooled gradient goes to the winning position of the winning half
-        gconv = torch.empty((N, 2 * C, H, W), dtype=gy.dtype, device=gy.device)
-        with _Launch("mfm_pool2_backward", gy.device):
-            st = lib.advstep_mfm_pool2_backward_f32(gy.data_ptr(), idx.data_ptr(), scale[0].data_ptr() if scale else None,
-                                                    gconv.data_ptr(), N, C, H, W, _stream(gy.device))
-        _lib.check(st, "advstep_mfm_pool2_backward_f32")
+        # d(conv out) — gy routed to the winning position of the winning half — is expanded inside the kernel's operand
+        # load; the BatchNorm scale is folded into the prepared weights
         gx = torch.empty((N, Cin, H, W), dtype=gy.dtype, device=gy.device)
-        for lo, hi in _batch_chunks(N, max(2 * C * H * W, 1)):
-            with _Launch("conv3x3_backward_data", gy.device):
-                st = lib.advstep_conv3x3_backward_data_f32(gconv[lo:hi].data_ptr(), U.data_ptr(), gx[lo:hi].data_ptr(), hi - lo,
-                                                           Cin, 2 * C, H, W, _stream(gy.device))
-            _lib.check(st, "advstep_conv3x3_backward_data_f32")
+        per_cell = C * (H // 2) * (W // 2)
+        for lo, hi in _batch_chunks(N, max(4 * per_cell, Cin * H * W, 1)):
+            with _Launch("conv3x3_mfm_pool2_backward", gy.device):
+                st = lib.advstep_conv3x3_mfm_pool2_backward_f32(gy[lo:hi].data_ptr(), idx.data_ptr() + lo * per_cell,
+                                                                U.data_ptr(), gx[lo:hi].data_ptr(), hi - lo, Cin, C, H, W,
+                                                                _stream(gy.device))
+            _lib.check(st, "advstep_conv3x3_mfm_pool2_backward_f32")
         return gx, None, None, None, None, None
 
 
@@ -291,7 +294,8 @@ def conv3x3_supported(in_channels: int, out_channels: int) -> bool:
 def conv3x3_mfm_pool2(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn=None) -> torch.Tensor:
     """MaxPool2d(2, 2)(MFM(conv2d(x, weight, bias, padding=1))) [then eval BatchNorm], Winograd on the matrix cores."""
     weight = weight if weight.is_contiguous() else weight.contiguous()
-    return _Conv3x3MfmPool2.apply(x.contiguous(), weight, bias, bn, _prepared_weights(weight, 0), _prepared_weights(weight, 1))
+    return _Conv3x3MfmPool2.apply(x.contiguous(), weight, bias, bn, _prepared_weights(weight, 0),
+                                  _prepared_weights(weight, 1, None if bn is None else bn[1]))
 
 
 

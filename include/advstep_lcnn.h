@@ -97,12 +97,14 @@ int advstep_conv1x1_mfm_backward_f32(const float *gy, const void *sel, const flo
  *
  * The weights enter pre-transformed (U = G g G^T in the kernel's chunked LDS layout); prepare once per weight version:
  *   mode 0: forward operand, from weight (2C, Cin, 3, 3);
- *   mode 1: operand of the input-gradient convolution (rotated, transposed kernel), from the same weight tensor.
+ *   mode 1: operand of the input-gradient convolution (rotated, transposed kernel), from the same weight tensor;
+ *           gscale (C = Cout / 2 floats, or NULL) multiplies the rows of conv channels c and c + C: the invstd of the
+ *           eval-mode BatchNorm folded behind the block, so the backward kernel needs no separate scaling pass.
  * advstep_conv3x3_prepared_floats() floats are written.  Cin % 16 == 0, Cin >= 32, (2C) % 32 == 0 (LCNN: 32/48/64 ->
  * 96/128/64); every tensor of a call must be smaller than 2 GiB (the caller splits the batch otherwise). */
 int advstep_conv3x3_supported(int64_t Cin, int64_t Cout);
 size_t advstep_conv3x3_prepared_floats(int64_t Cin, int64_t Cout, int mode);
-int advstep_conv3x3_prepare_f32(const float *weight, float *U, int64_t Cin, int64_t Cout, int mode,
+int advstep_conv3x3_prepare_f32(const float *weight, const float *gscale, float *U, int64_t Cin, int64_t Cout, int mode,
                                 advstep_stream_t stream);
 
 /* x (N, Cin, H, W), U (mode 0), bias (2C) or NULL, bn_mean / bn_invstd (C) or both NULL -> y (N, C, H/2, W/2) and one
@@ -114,6 +116,12 @@ int advstep_conv3x3_mfm_pool2_forward_f32(const float *x, const float *U, const 
 /* Input gradient of a Conv2d(Cin, Cout, (3,3), padding 1): gx (N, Cin, H, W) from gout (N, Cout, H, W) and U (mode 1). */
 int advstep_conv3x3_backward_data_f32(const float *gout, const float *U, float *gx, int64_t N, int64_t Cin, int64_t Cout,
                                       int64_t H, int64_t W, advstep_stream_t stream);
+
+/* Input gradient of the WHOLE block from its compact state: gy (N, C, H/2, W/2) and the forward's selection bytes.  The
+ * (N, 2C, H, W) gradient of the conv output — gy routed to the winning position of the winning half, zero elsewhere —
+ * is expanded on the fly inside the kernel's operand load and never written.  U: mode 1 (with the BatchNorm scale). */
+int advstep_conv3x3_mfm_pool2_backward_f32(const float *gy, const uint8_t *idx, const float *U, float *gx, int64_t N,
+                                           int64_t Cin, int64_t C, int64_t H, int64_t W, advstep_stream_t stream);
 
 /* ---- recurrent part of a (bi)directional LSTM layer  (src/models/lcnn.py:24-46: nn.LSTM(160, 80, bidirectional)) ------
  * The input projections are computed by the caller with one GEMM:
