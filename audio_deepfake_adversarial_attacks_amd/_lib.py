@@ -54,6 +54,9 @@ SIGNATURES = {
     "advstep_conv3x3_prepare_f32": (ctypes.c_int, [_p, _p, _p, _i64, _i64, ctypes.c_int, _p]),
     "advstep_conv3x3_mfm_pool2_forward_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p]),
     "advstep_conv3x3_mfm_pool2_backward_f32": (ctypes.c_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p]),
+    "advstep_conv3x3_mfm_sel_bytes": (_sz, [_i64, _i64, _i64, _i64]),
+    "advstep_conv3x3_mfm_forward_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p]),
+    "advstep_conv3x3_mfm_backward_f32": (ctypes.c_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _p]),
     "advstep_conv3x3_backward_data_f32": (ctypes.c_int, [_p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p]),
     # include/advstep_frontend.h
     "advstep_lfcc_block_count": (_sz, [_i64, _i64, _i64]),

@@ -129,6 +129,7 @@ __global__ void wino_prepare_kernel(const float *__restrict__ weight, const floa
 // ---- the convolution ---------------------------------------------------------------------------------------------------
 // EPI 0: plain store of min(32, Cout - slice * 32) channels per slice (the input-gradient convolution).
 // EPI 1: bias + max-feature-map + 2x2 pool [+ BatchNorm]; Cout = number of max-feature-map channels C.
+// EPI 2: bias + max-feature-map [+ BatchNorm] without the pool; one selection byte per 2x2 tile.
 // STREAM: K > 64, U chunks double-buffered through LDS (one barrier per chunk); otherwise all chunks stay resident.
 // grid = slices * ranges workgroups; workgroup b: slice b % slices, tile range b / slices.
 // SRC 0: the input is a dense tensor x (N, K, H, W).
@@ -352,6 +353,36 @@ __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restri
                     y[o] = vbest;
                     idx[o] = (uint8_t)code;
                 }
+            } else if (EPI == 2) {
+                // bias + max-feature-map [+ BatchNorm], no pool: the tile's 2x2 outputs and one byte with their 4
+                // "second half won" bits (bit = 2 * row + col), (N, C, TH, TW)
+                const int ch = slice * 16 + 4 * g + r;
+                const bool live = ch < Cout;
+                const int chs = live ? ch : 0;
+                const float ba = bias ? bias[chs] : 0.0f, bb = bias ? bias[chs + Cout] : 0.0f;
+                const float mu = bn_mean ? bn_mean[chs] : 0.0f, sc = bn_mean ? bn_invstd[chs] : 1.0f;
+                float out[2][2];
+                uint32_t bits = 0;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const float va = yy[0][i][j] + ba, vb = yy[1][i][j] + bb;
+                        const bool tb = mfm_takes_b(va, vb);
+                        bits |= (uint32_t)tb << (2 * i + j);
+                        out[i][j] = ((tb ? vb : va) - mu) * sc;
+                    }
+                if (valid && live) {
+                    float *o = y + (((size_t)n * Cout + ch) * H + 2 * th) * W + 2 * tw;
+                    const bool h1 = 2 * th + 1 < H, w1 = 2 * tw + 1 < W;
+                    o[0] = out[0][0];
+                    if (w1) o[1] = out[0][1];
+                    if (h1) {
+                        o[W] = out[1][0];
+                        if (w1) o[W + 1] = out[1][1];
+                    }
+                    idx[((size_t)n * Cout + ch) * TH * TW + (size_t)th * TW + tw] = (uint8_t)bits;
+                }
             } else {
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
@@ -374,6 +405,25 @@ __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restri
                 }
             }
         }
+    }
+}
+
+// d(conv out) (N, 2C, H, W) of the un-pooled block: gy * gscale goes to the half the tile byte names, 0 to the other.
+__global__ __launch_bounds__(256) void wino_mfm_backward_kernel(const float *__restrict__ gy, const uint8_t *__restrict__ sel,
+                                                                const float *__restrict__ gscale, float *__restrict__ gout,
+                                                                int C, int H, int W, int64_t total) {
+    const int TH = (H + 1) >> 1, TW = (W + 1) >> 1;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int w = (int)(i % W), h = (int)((i / W) % H);
+        const int64_t nc = i / ((int64_t)W * H);
+        const int c = (int)(nc % C);
+        const int64_t n = nc / C;
+        const uint32_t bits = sel[(nc * TH + (h >> 1)) * TW + (w >> 1)];
+        const bool tb = (bits >> (2 * (h & 1) + (w & 1))) & 1u;
+        const float gv = gy[i] * (gscale ? gscale[c] : 1.0f);
+        const int64_t o = ((n * 2 * C + c) * H + h) * W + w;
+        gout[o] = tb ? 0.0f : gv;
+        gout[o + (int64_t)C * H * W] = tb ? gv : 0.0f;
     }
 }
 
@@ -441,6 +491,34 @@ int advstep_conv3x3_mfm_pool2_forward_f32(const float *x, const float *U, const 
     WINO_REQUIRE((uint64_t)N * Cin * H * W * 4 < (1ull << 31) && (uint64_t)N * ((H + 1) / 2) * ((W + 1) / 2) < (1ull << 31));
     return launch_wino<1, 0>(x, nullptr, U, bias, bn_mean, bn_invstd, y, idx, N, Cin, H, W, C, (int)ceil_div(C, 16),
                              as_stream(stream));
+}
+
+size_t advstep_conv3x3_mfm_sel_bytes(int64_t N, int64_t C, int64_t H, int64_t W) {
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0) return 0;
+    return (size_t)(N * C * ((H + 1) / 2) * ((W + 1) / 2));
+}
+
+int advstep_conv3x3_mfm_forward_f32(const float *x, const float *U, const float *bias, const float *bn_mean,
+                                    const float *bn_invstd, float *y, uint8_t *sel, int64_t N, int64_t Cin, int64_t C,
+                                    int64_t H, int64_t W, advstep_stream_t stream) {
+    WINO_REQUIRE(N >= 0 && H >= 0 && W >= 0 && advstep_conv3x3_supported(Cin, 2 * C));
+    if (N == 0 || H == 0 || W == 0) return ADVSTEP_OK;
+    WINO_REQUIRE(x && U && y && sel && (bn_mean == nullptr) == (bn_invstd == nullptr));
+    WINO_REQUIRE((uint64_t)N * Cin * H * W * 4 < (1ull << 31) && (uint64_t)N * ((H + 1) / 2) * ((W + 1) / 2) < (1ull << 31));
+    return launch_wino<2, 0>(x, nullptr, U, bias, bn_mean, bn_invstd, y, sel, N, Cin, H, W, C, (int)ceil_div(C, 16),
+                             as_stream(stream));
+}
+
+int advstep_conv3x3_mfm_backward_f32(const float *gy, const uint8_t *sel, const float *gscale, float *gout, int64_t N,
+                                     int64_t C, int64_t H, int64_t W, advstep_stream_t stream) {
+    WINO_REQUIRE(N >= 0 && C >= 0 && H >= 0 && W >= 0);
+    const int64_t total = N * C * H * W;
+    if (total == 0) return ADVSTEP_OK;
+    WINO_REQUIRE(gy && sel && gout);
+    const int64_t blocks = ceil_div(total, 256);
+    hipLaunchKernelGGL(wino_mfm_backward_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0,
+                       as_stream(stream), gy, sel, gscale, gout, (int)C, (int)H, (int)W, total);
+    return status_after_launch();
 }
 
 int advstep_conv3x3_backward_data_f32(const float *gout, const float *U, float *gx, int64_t N, int64_t Cin, int64_t Cout,

@@ -287,6 +287,57 @@ class _Conv3x3MfmPool2(torch.autograd.Function):
         return gx, None, None, None, None, None
 
 
+class _Conv3x3Mfm(torch.autograd.Function):
+    """Conv2d(3x3, pad 1) + bias + max-feature-map [+ eval BatchNorm], no pool; input gradient only."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, bn, U, U_grad):
+        _require(x, "x"), _require(weight, "weight")
+        if bias is not None:
+            _require(bias, "bias")
+        N, Cin, H, W = x.shape
+        C = weight.shape[0] // 2
+        bn_mean, bn_invstd = _bn_ptrs(bn)
+        lib = _lib.load()
+        y = torch.empty((N, C, H, W), dtype=x.dtype, device=x.device)
+        per_sel = C * ((H + 1) // 2) * ((W + 1) // 2)
+        sel = torch.empty(max(N * per_sel, 1), dtype=torch.uint8, device=x.device)
+        for lo, hi in _batch_chunks(N, max(Cin * H * W, 1)):
+            with _Launch("conv3x3_mfm_forward", x.device):
+                st = lib.advstep_conv3x3_mfm_forward_f32(
+                    x[lo:hi].data_ptr(), U.data_ptr(), bias.data_ptr() if bias is not None else None, bn_mean, bn_invstd,
+                    y[lo:hi].data_ptr(), sel.data_ptr() + lo * per_sel, hi - lo, Cin, C, H, W, _stream(x.device))
+            _lib.check(st, "advstep_conv3x3_mfm_forward_f32")
+        ctx.save_for_backward(sel, U_grad, *([bn[1]] if bn is not None else []))
+        ctx.shape = (N, Cin, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        sel, U, *scale = ctx.saved_tensors
+        N, Cin, C, H, W = ctx.shape
+        gy = gy.contiguous()
+        lib = _lib.load()
+        gconv = torch.empty((N, 2 * C, H, W), dtype=gy.dtype, device=gy.device)
+        with _Launch("conv3x3_mfm_backward", gy.device):
+            st = lib.advstep_conv3x3_mfm_backward_f32(gy.data_ptr(), sel.data_ptr(), scale[0].data_ptr() if scale else None,
+                                                      gconv.data_ptr(), N, C, H, W, _stream(gy.device))
+        _lib.check(st, "advstep_conv3x3_mfm_backward_f32")
+        gx = torch.empty((N, Cin, H, W), dtype=gy.dtype, device=gy.device)
+        for lo, hi in _batch_chunks(N, max(2 * C * H * W, 1)):
+            with _Launch("conv3x3_backward_data", gy.device):
+                st = lib.advstep_conv3x3_backward_data_f32(gconv[lo:hi].data_ptr(), U.data_ptr(), gx[lo:hi].data_ptr(), hi - lo,
+                                                           Cin, 2 * C, H, W, _stream(gy.device))
+            _lib.check(st, "advstep_conv3x3_backward_data_f32")
+        return gx, None, None, None, None, None
+
+
+def conv3x3_mfm(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn=None) -> torch.Tensor:
+    """MFM(conv2d(x, weight, bias, padding=1)) [then eval BatchNorm], Winograd on the matrix cores."""
+    weight = weight if weight.is_contiguous() else weight.contiguous()
+    return _Conv3x3Mfm.apply(x.contiguous(), weight, bias, bn, _prepared_weights(weight, 0), _prepared_weights(weight, 1))
+
+
 def conv3x3_supported(in_channels: int, out_channels: int) -> bool:
     return bool(_lib.load().advstep_conv3x3_supported(in_channels, out_channels))
 

@@ -218,10 +218,10 @@ class BaseLCNN(nn.Module):
                     x = lcnn_ops.conv1x1_mfm(x, m.weight, m.bias, bn)
                     i += consumed
                     continue
-                if (params_frozen and pooled and _is_same_conv3x3(m) and _fused_conv3x3_enabled()
+                if (params_frozen and _is_same_conv3x3(m) and _fused_conv3x3_enabled()
                         and lcnn_ops.conv3x3_supported(m.in_channels, m.out_channels)):
-                    # 3x3 conv (Winograd on the matrix cores) + bias + MFM + pool (+ BN) in ONE kernel
-                    x = lcnn_ops.conv3x3_mfm_pool2(x, m.weight, m.bias, bn)
+                    # 3x3 conv (Winograd on the matrix cores) + bias + MFM [+ pool] (+ BN) in ONE kernel
+                    x = (lcnn_ops.conv3x3_mfm_pool2 if pooled else lcnn_ops.conv3x3_mfm)(x, m.weight, m.bias, bn)
                     i += consumed
                     continue
                 fold_bias = m.bias is not None and not (torch.is_grad_enabled() and m.bias.requires_grad)

@@ -113,6 +113,17 @@ int advstep_conv3x3_mfm_pool2_forward_f32(const float *x, const float *U, const 
                                           const float *bn_invstd, float *y, uint8_t *idx, int64_t N, int64_t Cin,
                                           int64_t C, int64_t H, int64_t W, advstep_stream_t stream);
 
+/* The same block WITHOUT the pool (src/models/lcnn.py:142-144: Conv2d -> MFM -> BatchNorm): y (N, C, H, W) and one byte
+ * per 2x2 tile (advstep_conv3x3_mfm_sel_bytes() bytes, bit 2*row + col set when the second channel half won). */
+size_t advstep_conv3x3_mfm_sel_bytes(int64_t N, int64_t C, int64_t H, int64_t W);
+int advstep_conv3x3_mfm_forward_f32(const float *x, const float *U, const float *bias, const float *bn_mean,
+                                    const float *bn_invstd, float *y, uint8_t *sel, int64_t N, int64_t Cin, int64_t C,
+                                    int64_t H, int64_t W, advstep_stream_t stream);
+/* ... and its max-feature-map backward: gout (N, 2C, H, W) = gy (N, C, H, W) [* gscale (C)] routed to the selected half,
+ * zero in the other; the input gradient then follows from advstep_conv3x3_backward_data_f32. */
+int advstep_conv3x3_mfm_backward_f32(const float *gy, const uint8_t *sel, const float *gscale, float *gout, int64_t N,
+                                     int64_t C, int64_t H, int64_t W, advstep_stream_t stream);
+
 /* Input gradient of a Conv2d(Cin, Cout, (3,3), padding 1): gx (N, Cin, H, W) from gout (N, Cout, H, W) and U (mode 1). */
 int advstep_conv3x3_backward_data_f32(const float *gout, const float *U, float *gx, int64_t N, int64_t Cin, int64_t Cout,
                                       int64_t H, int64_t W, advstep_stream_t stream);

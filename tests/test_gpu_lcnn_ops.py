@@ -407,3 +407,33 @@ def test_conv3x3_rejects_unsupported(L, cuda):
     y = L.conv3x3_mfm_pool2(x, w, None)
     (gx,) = torch.autograd.grad(y.sum(), x)          # input gradient only: the weight gets none
     assert gx.shape == x.shape
+
+
+@pytest.mark.parametrize("N,Cin,C,H,W", [(2, 64, 32, 50, 10), (3, 32, 16, 7, 9), (1, 48, 64, 4, 6)])
+@pytest.mark.parametrize("with_bn", [True, False])
+def test_conv3x3_mfm_without_pool_matches_float64_reference(L, cuda, N, Cin, C, H, W, with_bn):
+    """The un-pooled block (lcnn.py:142-144): same Winograd kernel, max-feature-map + BatchNorm epilogue, one selection
+    byte per 2x2 tile; 1e-5 of the output scale, gradient within 2e-5 except at near-tie flips."""
+    g = torch.Generator().manual_seed(N * 100 + Cin + C + H)
+    x = torch.randn(N, Cin, H, W, generator=g).to(cuda)
+    weight = (torch.randn(2 * C, Cin, 3, 3, generator=g) * 0.1).to(cuda)
+    bias = torch.randn(2 * C, generator=g).to(cuda)
+    bn = None
+    if with_bn:
+        mean = torch.randn(C, generator=g).to(cuda)
+        var = (torch.rand(C, generator=g) + 0.5).to(cuda)
+        bn = (mean, (1.0 / torch.sqrt(var + 1e-5)).contiguous())
+    xr = x.double().requires_grad_(True)
+    y_ref = ref_mfm(torch.nn.functional.conv2d(xr, weight.double(), bias.double(), padding=1))
+    if with_bn:
+        y_ref = (y_ref - bn[0].double().view(1, -1, 1, 1)) * bn[1].double().view(1, -1, 1, 1)
+    xa = x.clone().requires_grad_(True)
+    y = L.conv3x3_mfm(xa, weight, bias, bn)
+    assert y.shape == y_ref.shape
+    assert (y.double() - y_ref).abs().max().item() <= 1e-5 * max(y_ref.abs().max().item(), 1.0)
+    gy = torch.randn(y_ref.shape, generator=g).to(cuda)
+    (gx,) = torch.autograd.grad(y, xa, gy)
+    (gx_ref,) = torch.autograd.grad(y_ref, xr, gy.double())
+    err = (gx.double() - gx_ref).abs()
+    tol = 2e-5 * max(gx_ref.abs().max().item(), 1.0)
+    assert (err > tol).float().mean().item() <= 1e-3
