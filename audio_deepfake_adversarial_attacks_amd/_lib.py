@@ -68,6 +68,10 @@ SIGNATURES = {
     "advstep_lfcc_bands_backward_f32": (ctypes.c_int, [_p, _p, _p, _p, _i64, _p, _i64, _i64, _i64, _i64, ctypes.c_int, _p]),
     "advstep_stft_frames_f32": (ctypes.c_int, [_p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p]),
     "advstep_stft_overlap_add_f32": (ctypes.c_int, [_p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p]),
+    "advstep_stft_bands_block_count": (_sz, [_i64, _i64]),
+    "advstep_stft_bands_supported": (ctypes.c_int, [_i64, _i64, _i64]),
+    "advstep_stft_bands_f32": (ctypes.c_int, [_p, _p, _p, _p, _i64, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _p]),
+    "advstep_stft_bands_backward_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _p, _i64, _i64, _i64, _i64, _i64, _i64, _p]),
     # include/advstep_fab.h
     "advstep_fab_hyperplane_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, ctypes.c_int, _p]),
     "advstep_fab_projection_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, ctypes.c_int, _p]),

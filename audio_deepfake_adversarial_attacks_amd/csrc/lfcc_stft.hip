@@ -1,0 +1,406 @@
+// lfcc_stft.hip — the STFT end of the LFCC frontend fused around an in-LDS FFT (C ABI: include/advstep_frontend.h).
+//
+// Reference op chain (src/frontends.py:24-32 -> torchaudio LFCC): torch.stft(n_fft 512, hop 160, hann 400 centred,
+// center=True, reflect) -> |.|^2 -> linear filterbank (257 -> 128) -> 10 log10, and its backward.  Done with library
+// FFTs this is framing kernel -> rocFFT r2c (2 kernels) -> filterbank kernel, with the (B, NF, 512) frames and the
+// (B, NF, 257) complex spectrum (106 MB each at B = 128) written and re-read in between — and the mirror image on the
+// way back.  Here ONE kernel per direction: a wave owns a frame, gathers its 512 windowed samples straight from the
+// waveform (33 MB, L2-resident), runs a 256-point complex radix-4 Stockham FFT in LDS (the real 512-point transform
+// by even/odd packing), and
+//   forward : power -> sparse filterbank -> dB -> band_db row (512 B, coalesced) + the workgroup maximum;
+//   backward: recomputes the frame's spectrum (same code, same bits: nothing was saved), forms
+//             d|X|^2 = 2 X (fb^T dband), inverse-transforms, applies the window and overlap-adds.  A workgroup owns 8
+//             consecutive frames: their windowed gradients meet in LDS and every output sample is summed in frame
+//             order (deterministic); the <= 2 workgroups that share a border sample combine with one float atomic
+//             each (two operands: commutative, so still deterministic).  dx must be zeroed by the caller.
+// HBM traffic per direction: waveform + band rows (33 + 26 MB) instead of ~0.5 GB.
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "advstep_frontend.h"
+
+namespace {
+
+constexpr int kN = 256;            // complex FFT length (n_fft = 512 real samples)
+constexpr int kNfft = 2 * kN;
+constexpr int kBins = kN + 1;      // one-sided spectrum
+constexpr int kWavesPerBlock = 4;
+constexpr int kThreads = kWavesPerBlock * 64;
+constexpr int kFramesPerBlockBwd = 8;
+constexpr float kAmin = 1e-10f;
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+inline hipStream_t as_stream(advstep_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+inline int status_after_launch() { return hipGetLastError() == hipSuccess ? ADVSTEP_OK : ADVSTEP_ELAUNCH; }
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 conjf2(float2 a) { return make_float2(a.x, -a.y); }
+
+// The FFT buffers of a wave are private to it, and a wave's LDS instructions execute in program order: ordering one
+// stage's writes before the next stage's reads needs no s_barrier, only that the compiler keeps the order and waits for
+// the outstanding LDS operations (workgroup-scope fences on LDS lower to s_waitcnt lgkmcnt(0)).
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+__device__ __forceinline__ float max_nan(float a, float b) {
+    if (a != a) return a;
+    if (b != b) return b;
+    return a > b ? a : b;
+}
+
+// 256-point complex FFT of one wave's frame, radix 4, Stockham autosort: 4 stages ping-ponging between `a` and `b`
+// (float2[256] each, private to the wave).  tw[m] = exp(-2 pi i m / 256).  INV conjugates the twiddles and the
+// butterfly (unnormalised inverse).  Result in `a` (4 stages = even number of swaps).  One wave-level sync per stage
+// orders this stage's writes before the next stage's reads (and, the buffers alternating, the next-but-one stage's
+// writes after this stage's reads).  `a` must be complete (and synced) on entry.
+// LDS index padding: one extra float2 every 16.  The Stockham writes of the first stages stride by 4 and 16 elements;
+// unpadded, 16 lanes land on 4 of the 16 eight-byte slots of an LDS row (4x the conflict-free time), padded they cover
+// all 16.  Every access to an FFT buffer goes through P().
+__device__ __forceinline__ int P(int i) { return i + (i >> 4); }
+constexpr int kNPad = kN + kN / 16;
+
+template <bool INV>
+__device__ __forceinline__ void fft256(float2 *a, float2 *b, const float2 *__restrict__ tw, int lane) {
+#pragma unroll
+    for (int stage = 0; stage < 4; ++stage) {
+        const int Ns = 1 << (2 * stage);
+        const int k = lane & (Ns - 1);
+        float2 v0 = a[P(lane)], v1 = a[P(lane + 64)], v2 = a[P(lane + 128)], v3 = a[P(lane + 192)];
+        if (stage > 0) {
+            const int m = k * (64 >> (2 * stage));       // k * 64 / Ns
+            float2 w1 = tw[m], w2 = tw[2 * m], w3 = tw[3 * m];
+            if (INV) w1 = conjf2(w1), w2 = conjf2(w2), w3 = conjf2(w3);
+            v1 = cmul(v1, w1), v2 = cmul(v2, w2), v3 = cmul(v3, w3);
+        }
+        const float2 s02 = cadd(v0, v2), d02 = csub(v0, v2), s13 = cadd(v1, v3), d13 = csub(v1, v3);
+        // forward: -i * d13 = (d13.y, -d13.x); inverse: +i * d13 = (-d13.y, d13.x)
+        const float2 r = INV ? make_float2(-d13.y, d13.x) : make_float2(d13.y, -d13.x);
+        const int j0 = ((lane - k) << 2) + k;
+        b[P(j0)] = cadd(s02, s13);
+        b[P(j0 + Ns)] = cadd(d02, r);
+        b[P(j0 + 2 * Ns)] = csub(s02, s13);
+        b[P(j0 + 3 * Ns)] = csub(d02, r);
+        wave_lds_sync();
+        float2 *t = a;
+        a = b;
+        b = t;
+    }
+}
+
+// frame f of utterance xb -> z[n] = w[2n] x[.] + i w[2n+1] x[.] (even / odd packing), reflect padding of nfft/2
+__device__ __forceinline__ void load_frame(const float *__restrict__ xb, const float *__restrict__ w, int T, int f,
+                                           int hop, float2 *z, int lane) {
+    const int q_first = f * hop - kN;
+    if (q_first >= 0 && q_first + kNfft <= T && ((q_first & 1) == 0) && ((reinterpret_cast<uintptr_t>(xb) & 7u) == 0)) {
+        // interior frame (all but the first and last two at hop 160): no reflection, 8-byte loads
+        const float2 *x2 = reinterpret_cast<const float2 *>(xb + q_first);
+        const float2 *w2 = reinterpret_cast<const float2 *>(w);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = lane + 64 * i;
+            const float2 xv = x2[n], wv = w2[n];
+            z[P(n)] = make_float2(wv.x * xv.x, wv.y * xv.y);
+        }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = lane + 64 * i;           // complex index; real samples 2n, 2n + 1
+        int q0 = f * hop + 2 * n - kN, q1 = q0 + 1;
+        q0 = q0 < 0 ? -q0 : q0;
+        q0 = q0 >= T ? 2 * (T - 1) - q0 : q0;
+        q1 = q1 < 0 ? -q1 : q1;
+        q1 = q1 >= T ? 2 * (T - 1) - q1 : q1;
+        z[P(n)] = make_float2(w[2 * n] * xb[q0], w[2 * n + 1] * xb[q1]);
+    }
+}
+
+// Z (256-point FFT of the packed frame) -> X[k], k = 0 .. 256, written to xs (float2[257])
+__device__ __forceinline__ void unpack_real(const float2 *Z, const float2 *__restrict__ tw512, float2 *xs, int lane) {
+    // tw512[k] = exp(-2 pi i k / 512), k = 0 .. 255
+    for (int k = lane; k < kN; k += 64) {
+        const float2 zk = Z[P(k)], zc = conjf2(Z[P((kN - k) & (kN - 1))]);
+        const float2 e = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y + zc.y));
+        const float2 d = make_float2(0.5f * (zk.x - zc.x), 0.5f * (zk.y - zc.y));
+        // X[k] = E + W^k * (-i d)
+        const float2 o = cmul(tw512[k], make_float2(d.y, -d.x));
+        xs[k] = cadd(e, o);
+    }
+    if (lane == 0) xs[kN] = make_float2(Z[P(0)].x - Z[P(0)].y, 0.0f);
+}
+
+struct Lds {
+    float2 a[kWavesPerBlock][kNPad];
+    float2 b[kWavesPerBlock][kNPad];
+    float2 xs[kWavesPerBlock][kBins + 7];
+    float2 tw[kN];       // exp(-2 pi i m / 256)
+    float2 tw512[kN];    // exp(-2 pi i k / 512)
+    float red[kWavesPerBlock];
+};
+
+// twiddle table (device global, written once per process by the first launch): [0, 256) exp(-2 pi i m / 256),
+// [256, 512) exp(-2 pi i m / 512)
+__device__ float2 g_twiddles[2 * kN];
+
+__global__ void stft_twiddle_kernel() {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= 2 * kN) return;
+    const double ang = m < kN ? -2.0 * M_PI * m / 256.0 : -2.0 * M_PI * (m - kN) / 512.0;
+    g_twiddles[m] = make_float2((float)cos(ang), (float)sin(ang));
+}
+
+__device__ __forceinline__ void fill_twiddles(Lds &L) {
+    for (int m = threadIdx.x; m < kN; m += kThreads) {
+        L.tw[m] = g_twiddles[m];
+        L.tw512[m] = g_twiddles[kN + m];
+    }
+}
+
+// grid (ceil(NF / 16), B): wave w of workgroup g owns frames 16 g + 4 r + w, r = 0 .. 3
+constexpr int kFramesPerBlockFwd = 16;
+
+__global__ __launch_bounds__(kThreads) void stft_bands_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                              const int32_t *__restrict__ fb_start,
+                                                              const float *__restrict__ fb_w, int span,
+                                                              float *__restrict__ band_db, float *__restrict__ bmax, int T,
+                                                              int NF, int hop, int M) {
+    __shared__ Lds L;
+    fill_twiddles(L);
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t b = blockIdx.y;
+    float vmax = -INFINITY;
+    for (int r = 0; r < kFramesPerBlockFwd / kWavesPerBlock; ++r) {
+        const int f = blockIdx.x * kFramesPerBlockFwd + r * kWavesPerBlock + wave;
+        if (f >= NF) break;                       // wave-uniform; nothing below needs the other waves
+        load_frame(x + b * T, w, T, f, hop, L.a[wave], lane);
+        wave_lds_sync();
+        fft256<false>(L.a[wave], L.b[wave], L.tw, lane);
+        unpack_real(L.a[wave], L.tw512, L.xs[wave], lane);
+        wave_lds_sync();
+        float *row = band_db + (b * NF + f) * M;
+        for (int m = lane; m < M; m += 64) {
+            const int f0 = fb_start[m];
+            float band = 0.0f;
+            for (int j = 0; j < span; ++j) {
+                const int k = f0 + j;
+                if (k < kBins) {
+                    const float2 z = L.xs[wave][k];
+                    band = fmaf(fb_w[m * span + j], fmaf(z.x, z.x, z.y * z.y), band);
+                }
+            }
+            // 10 log10(v) = 3.0103 log2(v): the hardware log2 (1 ulp) keeps the dB value within 1e-6 relative
+            const float db = 3.010299956639812f * __log2f(band > kAmin ? band : (band != band ? band : kAmin));
+            row[m] = db;
+            vmax = max_nan(vmax, db);
+        }
+        wave_lds_sync();                          // xs / a are rewritten by the next frame
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) vmax = max_nan(vmax, __shfl_xor(vmax, off, 64));
+    if (lane == 0) L.red[wave] = vmax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float r = L.red[0];
+        for (int i = 1; i < kWavesPerBlock; ++i) r = max_nan(r, L.red[i]);
+        bmax[b * gridDim.x + blockIdx.x] = r;
+    }
+}
+
+constexpr int kMaxSpanT = 4, kMaxBands = 128;
+
+struct LdsBwd {
+    Lds c;
+    float dframe[kFramesPerBlockBwd][kNfft];   // windowed frame gradients of this workgroup's frames
+    float fbt_w[kBins * kMaxSpanT];            // transposed filterbank, staged once per workgroup
+    int32_t fbt_start[kBins];
+    float drow[kWavesPerBlock][kMaxBands];     // the current frame's band gradients
+};
+
+// grid (ceil(NF / 8), B): a workgroup owns 8 consecutive frames (2 per wave)
+__global__ __launch_bounds__(kThreads) void stft_bands_backward_kernel(const float *__restrict__ x,
+                                                                       const float *__restrict__ w,
+                                                                       const float *__restrict__ dband,
+                                                                       const int32_t *__restrict__ fbt_start,
+                                                                       const float *__restrict__ fbt_w, int span_t,
+                                                                       float *__restrict__ dx, int T, int NF, int hop,
+                                                                       int M) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char raw[];
+    LdsBwd &S = *reinterpret_cast<LdsBwd *>(raw);
+    Lds &L = S.c;
+    fill_twiddles(L);
+    for (int i = threadIdx.x; i < kBins; i += kThreads) S.fbt_start[i] = fbt_start[i];
+    for (int i = threadIdx.x; i < kBins * span_t; i += kThreads) S.fbt_w[i] = fbt_w[i];
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t b = blockIdx.y;
+    const int f_base = blockIdx.x * kFramesPerBlockBwd;
+    const float *xb = x + b * T;
+    for (int r = 0; r < kFramesPerBlockBwd / kWavesPerBlock; ++r) {
+        const int fl = r * kWavesPerBlock + wave;          // local frame index
+        const int f = f_base + fl;
+        const bool live = f < NF;
+        // the frame's spectrum again (bit-identical to the forward pass: same code, same inputs)
+        load_frame(xb, w, T, live ? f : NF - 1, hop, L.a[wave], lane);
+        wave_lds_sync();
+        fft256<false>(L.a[wave], L.b[wave], L.tw, lane);
+        unpack_real(L.a[wave], L.tw512, L.xs[wave], lane);
+        wave_lds_sync();
+        // G[k] = 2 X[k] * sum_j fbt_w[k, j] dband[fbt_start[k] + j], pre-scaled for the one-sided inverse:
+        // interior bins * 1/2, imaginary parts of DC / Nyquist dropped
+        const float *drow_g = dband + (b * NF + (live ? f : NF - 1)) * M;
+        for (int m = lane; m < M; m += 64) S.drow[wave][m] = drow_g[m];
+        wave_lds_sync();
+        const float *drow = S.drow[wave];
+        for (int k = lane; k < kBins; k += 64) {
+            const int m0 = S.fbt_start[k];
+            float dp = 0.0f;
+            for (int j = 0; j < span_t; ++j) {
+                const int m = m0 + j;
+                if (m < M) dp = fmaf(S.fbt_w[k * span_t + j], drow[m], dp);
+            }
+            const float2 z = L.xs[wave][k];
+            float2 gk = make_float2(2.0f * z.x * dp, 2.0f * z.y * dp);
+            if (k == 0 || k == kN) gk.y = 0.0f;
+            else gk.x *= 0.5f, gk.y *= 0.5f;
+            L.xs[wave][k] = gk;
+        }
+        wave_lds_sync();
+        // half spectrum -> packed 256-point input of the inverse: Z'[k] = (G[k] + G*[N-k]) + i W^-k (G[k] - G*[N-k])
+        for (int k = lane; k < kN; k += 64) {
+            const float2 gk = L.xs[wave][k], gc = conjf2(L.xs[wave][kN - k]);
+            const float2 e = cadd(gk, gc), d = csub(gk, gc);
+            const float2 wd = cmul(conjf2(L.tw512[k]), d);
+            L.a[wave][P(k)] = make_float2(e.x - wd.y, e.y + wd.x);    // e + i * wd
+        }
+        wave_lds_sync();
+        fft256<true>(L.a[wave], L.b[wave], L.tw, lane);
+        // z'[n] = dframe[2n] + i dframe[2n + 1]; window, park in LDS
+        for (int n = lane; n < kN; n += 64) {
+            const float2 z = L.a[wave][P(n)];
+            S.dframe[fl][2 * n] = live ? w[2 * n] * z.x : 0.0f;
+            S.dframe[fl][2 * n + 1] = live ? w[2 * n + 1] * z.y : 0.0f;
+        }
+        wave_lds_sync();
+    }
+    __syncthreads();   // all frames' windowed gradients are in LDS
+    // overlap-add: the samples this workgroup's frames touch, each summed over (positions that read it) x (frames) in a
+    // fixed order; positions are padded coordinates p = q + nfft/2
+    const int p_lo = f_base * hop;                                          // first padded position of the first frame
+    const int frames_here = (NF - f_base) < kFramesPerBlockBwd ? (NF - f_base) : kFramesPerBlockBwd;
+    const int p_hi = p_lo + (frames_here - 1) * hop + kNfft;                // one past the last
+    // sample range that can receive something: direct positions and both reflections
+    auto add_from = [&](int p, float &acc) {     // frames in ascending order: a fixed summation order
+        if (p < p_lo || p >= p_hi) return;
+#pragma unroll
+        for (int fl = 0; fl < kFramesPerBlockBwd; ++fl) {
+            const int n = p - p_lo - fl * hop;
+            if (fl < frames_here && n >= 0 && n < kNfft) acc += S.dframe[fl][n];
+        }
+    };
+    // reflections only exist next to the two ends of the signal: wave-uniform, almost always false
+    const bool near_left = p_lo < 2 * kN, near_right = p_hi > T;
+    // direct range of samples: t = p - pad for p in [p_lo, p_hi)
+    const int t_first = p_lo - kN, span_t_all = p_hi - p_lo;
+    for (int i = threadIdx.x; i < span_t_all; i += kThreads) {
+        const int t = t_first + i;
+        if (t < 0 || t >= T) continue;            // padded positions outside the signal are reached by reflection below
+        float acc = 0.0f;
+        add_from(t + kN, acc);
+        if (near_left && t >= 1 && t <= kN) add_from(kN - t, acc);                               // left reflection
+        if (near_right && t <= T - 2 && t >= T - 1 - kN) add_from(2 * (T - 1) - t + kN, acc);    // right reflection
+        if (acc != 0.0f) atomicAdd(dx + b * T + t, acc);
+    }
+    if (!(near_left || near_right)) return;
+    // samples reached ONLY through a reflection from this workgroup's range (their direct position belongs to another
+    // workgroup's range or to none): left edge t = pad - p for p < pad, right edge t = 2 (T - 1) - (p - pad) for p - pad >= T
+    for (int i = threadIdx.x; i < span_t_all; i += kThreads) {
+        const int p = p_lo + i, q = p - kN;
+        int t = -1;
+        if (q < 0) t = -q;
+        else if (q >= T) t = 2 * (T - 1) - q;
+        if (t < 0 || t >= T) continue;
+        // skip if t's direct position is inside this workgroup's range: the first loop already took this contribution
+        const int pd = t + kN;
+        if (pd >= p_lo && pd < p_hi) continue;
+        float acc = 0.0f;
+        add_from(p, acc);
+        if (acc != 0.0f) atomicAdd(dx + b * T + t, acc);
+    }
+}
+
+constexpr int64_t kMaxGridY = 65535;
+
+// The table is a pure function of nothing: writing it again is harmless, so a racy "done" flag per device is enough.
+inline void ensure_twiddles(hipStream_t st) {
+    static bool done[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !done[dev]) {
+        hipLaunchKernelGGL(stft_twiddle_kernel, dim3(2), dim3(256), 0, st);
+        if (dev >= 0 && dev < 64) done[dev] = true;
+    }
+}
+
+}  // namespace
+
+#define STFT_REQUIRE(cond) \
+    do {                   \
+        if (!(cond)) return ADVSTEP_EINVAL; \
+    } while (0)
+
+extern "C" {
+
+size_t advstep_stft_bands_block_count(int64_t B, int64_t NF) {
+    if (B <= 0 || NF <= 0) return 0;
+    return (size_t)(B * ceil_div(NF, kFramesPerBlockFwd));
+}
+
+int advstep_stft_bands_supported(int64_t nfft, int64_t hop, int64_t T) {
+    return nfft == kNfft && hop >= 64 && hop <= kNfft && T > kN + 1;
+}
+
+int advstep_stft_bands_f32(const float *x, const float *window, const int32_t *fb_start, const float *fb_w, int64_t span,
+                           float *band_db, float *block_max, int64_t B, int64_t T, int64_t NF, int64_t hop, int64_t nfft,
+                           int64_t M, advstep_stream_t stream) {
+    STFT_REQUIRE(B >= 0 && NF >= 0 && M >= 0 && span >= 1);
+    if (B == 0 || NF == 0 || M == 0) return ADVSTEP_OK;
+    STFT_REQUIRE(x && window && fb_start && fb_w && band_db && block_max && B <= kMaxGridY);
+    STFT_REQUIRE(advstep_stft_bands_supported(nfft, hop, T) && NF == 1 + T / hop);
+    ensure_twiddles(as_stream(stream));
+    const dim3 grid((unsigned)ceil_div(NF, kFramesPerBlockFwd), (unsigned)B);
+    hipLaunchKernelGGL(stft_bands_kernel, grid, dim3(kThreads), 0, as_stream(stream), x, window, fb_start, fb_w, (int)span,
+                       band_db, block_max, (int)T, (int)NF, (int)hop, (int)M);
+    return status_after_launch();
+}
+
+int advstep_stft_bands_backward_f32(const float *x, const float *window, const float *dband, const int32_t *fbt_start,
+                                    const float *fbt_w, int64_t span_t, float *dx, int64_t B, int64_t T, int64_t NF,
+                                    int64_t hop, int64_t nfft, int64_t M, advstep_stream_t stream) {
+    STFT_REQUIRE(B >= 0 && NF >= 0 && M >= 0 && span_t >= 1);
+    if (B == 0 || T == 0) return ADVSTEP_OK;
+    STFT_REQUIRE(x && window && dband && fbt_start && fbt_w && dx && B <= kMaxGridY);
+    STFT_REQUIRE(advstep_stft_bands_supported(nfft, hop, T) && NF == 1 + T / hop && span_t <= kMaxSpanT && M <= kMaxBands);
+    // a sample may be reached by at most two workgroups (two-operand float atomics commute): a workgroup's frames must
+    // advance by at least the overlap between neighbouring workgroups' ranges
+    STFT_REQUIRE(kFramesPerBlockBwd * hop >= kNfft - hop);
+    hipStream_t st = as_stream(stream);
+    ensure_twiddles(st);
+    if (hipMemsetAsync(dx, 0, (size_t)B * T * sizeof(float), st) != hipSuccess) return ADVSTEP_ELAUNCH;
+    const dim3 grid((unsigned)ceil_div(NF, kFramesPerBlockBwd), (unsigned)B);
+    const size_t lds = sizeof(LdsBwd);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(stft_bands_backward_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(stft_bands_backward_kernel, grid, dim3(kThreads), lds, st, x, window, dband, fbt_start, fbt_w,
+                       (int)span_t, dx, (int)T, (int)NF, (int)hop, (int)M);
+    return status_after_launch();
+}
+
+}  // extern "C"

@@ -184,11 +184,73 @@ class _LfccFromWaveform(torch.autograd.Function):
         return dx, None, None, None, None, None
 
 
+def _inlds_fft_enabled() -> bool:
+    """ADVSTEP_INLDS_FFT=0 keeps framing kernel + hipFFT + filterbank kernel (A/B measurements); default: the fused
+    in-LDS FFT kernels of csrc/lfcc_stft.hip."""
+    return os.environ.get("ADVSTEP_INLDS_FFT", "1") != "0"
+
+
+class _LfccFromWaveformFused(torch.autograd.Function):
+    """The whole LFCC frontend with the STFT inside the kernels: [framing + FFT + power + filterbank + dB] -> max -> [floor
+    + DCT]; backward: [DCT^T + floor] -> [filterbank^T + spectrum recomputed + inverse FFT + window + overlap-add]."""
+
+    @staticmethod
+    def forward(ctx, x, window, hop, tables: FilterbankTables, dct, top_db: float):
+        B, T = x.shape
+        nfft = window.numel()
+        NF = 1 + T // hop
+        M, K = dct.shape
+        dev = x.device
+        lib = _lib.load()
+        band_db = torch.empty((B, NF, M), dtype=torch.float32, device=dev)
+        nblk = lib.advstep_stft_bands_block_count(B, NF)
+        block_max = torch.empty(max(nblk, 1), dtype=torch.float32, device=dev)
+        stats = torch.empty(4, dtype=torch.float32, device=dev)
+        out = torch.empty((B, NF, K), dtype=torch.float32, device=dev)
+        with _Launch("lfcc_forward", dev):
+            st = lib.advstep_stft_bands_f32(x.data_ptr(), window.data_ptr(), tables.fb_start.data_ptr(), tables.fb_w.data_ptr(),
+                                            tables.span, band_db.data_ptr(), block_max.data_ptr(), B, T, NF, hop, nfft, M,
+                                            _stream(dev))
+            _lib.check(st, "advstep_stft_bands_f32")
+            st = lib.advstep_lfcc_reduce_max_f32(block_max.data_ptr(), nblk, stats.data_ptr(), _stream(dev))
+            _lib.check(st, "advstep_lfcc_reduce_max_f32")
+            st = lib.advstep_lfcc_project_f32(band_db.data_ptr(), dct.data_ptr(), stats.data_ptr(), top_db, out.data_ptr(),
+                                              B, M, NF, K, _stream(dev))
+            _lib.check(st, "advstep_lfcc_project_f32")
+        ctx.save_for_backward(x, band_db, stats, dct, tables.fbt_start, tables.fbt_w, window)
+        ctx.meta = (B, T, NF, M, K, tables.span_t, float(top_db), hop, nfft)
+        return out.transpose(1, 2)
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, band_db, stats, dct, fbt_start, fbt_w, window = ctx.saved_tensors
+        B, T, NF, M, K, span_t, top_db, hop, nfft = ctx.meta
+        dev = gout.device
+        go = gout.transpose(1, 2).contiguous()
+        lib = _lib.load()
+        dband = torch.empty((B, NF, M), dtype=torch.float32, device=dev)
+        dx = torch.empty((B, T), dtype=torch.float32, device=dev)
+        with _Launch("lfcc_backward", dev):
+            st = lib.advstep_lfcc_project_backward_f32(go.data_ptr(), dct.data_ptr(), band_db.data_ptr(), stats.data_ptr(),
+                                                       top_db, dband.data_ptr(), B, M, NF, K, _stream(dev))
+            _lib.check(st, "advstep_lfcc_project_backward_f32")
+            st = lib.advstep_lfcc_floor_fixup_f32(band_db.data_ptr(), stats.data_ptr(), dband.data_ptr(), band_db.numel(),
+                                                  _stream(dev))
+            _lib.check(st, "advstep_lfcc_floor_fixup_f32")
+            st = lib.advstep_stft_bands_backward_f32(x.data_ptr(), window.data_ptr(), dband.data_ptr(), fbt_start.data_ptr(),
+                                                     fbt_w.data_ptr(), span_t, dx.data_ptr(), B, T, NF, hop, nfft, M,
+                                                     _stream(dev))
+            _lib.check(st, "advstep_stft_bands_backward_f32")
+        return dx, None, None, None, None, None
+
+
 def lfcc_from_waveform(x: torch.Tensor, window_nfft: torch.Tensor, hop: int, tables: FilterbankTables, dct: torch.Tensor,
                        top_db: float = 80.0) -> torch.Tensor:
     """Waveform (B, T) -> LFCC (B, K, 1 + T // hop); `window_nfft` is the analysis window zero-padded (centred) to n_fft."""
     if not x.is_cuda or x.dtype != torch.float32 or x.dim() != 2:
         raise _lib.AdvstepError("lfcc_from_waveform needs a float32 (B, T) waveform on a HIP device (no CPU fallback)")
+    if _inlds_fft_enabled() and _lib.load().advstep_stft_bands_supported(window_nfft.numel(), hop, x.shape[1]):
+        return _LfccFromWaveformFused.apply(x.contiguous(), window_nfft, hop, tables, dct, top_db)
     return _LfccFromWaveform.apply(x.contiguous(), window_nfft, hop, tables, dct, top_db)
 
 

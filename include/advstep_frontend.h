@@ -76,6 +76,22 @@ int advstep_stft_frames_f32(const float *x, const float *window, float *frames, 
 int advstep_stft_overlap_add_f32(const float *dframes, const float *window, float *dx, int64_t B, int64_t T, int64_t NF,
                                  int64_t hop, int64_t nfft, advstep_stream_t stream);
 
+/* ---- the STFT end fused around an in-LDS FFT (n_fft = 512) -------------------------------------------------------------
+ * torch.stft(center=True, reflect, window) -> |.|^2 -> filterbank -> 10 log10 in ONE kernel: band_db (B, NF, M) and the
+ * per-workgroup maxima (advstep_stft_bands_block_count() floats; feed them to advstep_lfcc_reduce_max_f32).  Frames and
+ * spectrum never touch memory.  x (B, T), window (512: the analysis window centred / zero-padded), fb_* as above. */
+size_t advstep_stft_bands_block_count(int64_t B, int64_t NF);
+int advstep_stft_bands_supported(int64_t nfft, int64_t hop, int64_t T);
+int advstep_stft_bands_f32(const float *x, const float *window, const int32_t *fb_start, const float *fb_w, int64_t span,
+                           float *band_db, float *block_max, int64_t B, int64_t T, int64_t NF, int64_t hop, int64_t nfft,
+                           int64_t M, advstep_stream_t stream);
+
+/* Its backward: dx (B, T) from dband (B, NF, M).  The spectrum is recomputed from x (bit-identical to the forward pass:
+ * nothing was saved), d|X|^2 -> inverse FFT -> window -> overlap-add, summed in a fixed order (deterministic). */
+int advstep_stft_bands_backward_f32(const float *x, const float *window, const float *dband, const int32_t *fbt_start,
+                                    const float *fbt_w, int64_t span_t, float *dx, int64_t B, int64_t T, int64_t NF,
+                                    int64_t hop, int64_t nfft, int64_t M, advstep_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,8 +20,12 @@ def run(lfcc, x, gy, fused, monkeypatch):
     return y.detach(), g
 
 
+@pytest.mark.parametrize("inlds_fft", ["1", "0"])
 @pytest.mark.parametrize("B,T", [(3, 64_600), (2, 8_000), (1, 1_000), (5, 16_160)])
-def test_fused_lfcc_matches_torch_chain(lfcc, cuda, monkeypatch, B, T):
+def test_fused_lfcc_matches_torch_chain(lfcc, cuda, monkeypatch, B, T, inlds_fft):
+    """inlds_fft = 1: framing + FFT + filterbank (and their backward) inside one kernel each (csrc/lfcc_stft.hip);
+    0: framing kernel + hipFFT + filterbank kernel."""
+    monkeypatch.setenv("ADVSTEP_INLDS_FFT", inlds_fft)
     gen = torch.Generator().manual_seed(B * 7 + T)
     x = torch.rand(B, T, generator=gen).to(cuda)
     y0, _ = run(lfcc, x, None, False, monkeypatch) if False else (None, None)
@@ -37,6 +41,9 @@ def test_fused_lfcc_matches_torch_chain(lfcc, cuda, monkeypatch, B, T):
     assert rel <= 1e-4, rel
     # the fused output is frame-major: LCNN's permute(0, 1, 3, 2) of it is contiguous
     assert y.unsqueeze(1).permute(0, 1, 3, 2).is_contiguous()
+    # fixed summation order everywhere (the overlap-add's border atomics have two operands): bit-reproducible
+    y2, g2 = run(lfcc, x, gy, True, monkeypatch)
+    assert torch.equal(y, y2) and torch.equal(g, g2)
 
 
 def test_fused_lfcc_floor_and_amax_gradient_path(lfcc, cuda, monkeypatch):

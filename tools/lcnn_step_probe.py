@@ -42,6 +42,7 @@ def main():
         os.environ["ADVSTEP_FUSED_LFCC"] = "0" if ("nolfcc" in arm or arm.startswith("plain")) else "1"
         os.environ["ADVSTEP_FUSED_STFT"] = "0" if "nostft" in arm else "1"
         os.environ["ADVSTEP_DIRECT_FFT"] = "0" if "torchfft" in arm else "1"
+        os.environ["ADVSTEP_INLDS_FFT"] = "0" if ("hipfft" in arm or "torchfft" in arm) else "1"
         os.environ["ADVSTEP_LCNN_BN"] = "0" if "nobn" in arm else "1"
         os.environ["ADVSTEP_LCNN_CONV0"] = "0" if "noconv0" in arm else "1"
         os.environ["ADVSTEP_LCNN_CONV3X3"] = "0" if ("miopen3x3" in arm or arm.startswith("plain")) else "1"

@@ -170,6 +170,15 @@ def main():
     timeit("stft_overlap_add", lambda: lib.advstep_stft_overlap_add_f32(dfr.data_ptr(), win.data_ptr(), dxx.data_ptr(), B, Tn,
                                                                          NF, 160, 512, st),
            bytes_moved=4.0 * (dfr.numel() + dxx.numel()))
+    # the STFT end fused around an in-LDS FFT: replaces stft_frames + r2c + lfcc_bands / lfcc_bands_backward + c2r + overlap-add
+    nblk2 = lib.advstep_stft_bands_block_count(B, NF)
+    bmax2 = torch.empty(nblk2, device=dev)
+    timeit("stft_bands (framing+FFT+fbank+dB)", lambda: lib.advstep_stft_bands_f32(
+        wav.data_ptr(), win.data_ptr(), tables.fb_start.data_ptr(), tables.fb_w.data_ptr(), tables.span, band.data_ptr(),
+        bmax2.data_ptr(), B, Tn, NF, 160, 512, M, st), bytes_moved=4.0 * (wav.numel() + band.numel()))
+    timeit("stft_bands_backward (fbank^T+FFT+iFFT+OLA)", lambda: lib.advstep_stft_bands_backward_f32(
+        wav.data_ptr(), win.data_ptr(), dband.data_ptr(), tables.fbt_start.data_ptr(), tables.fbt_w.data_ptr(), tables.span_t,
+        dxx.data_ptr(), B, Tn, NF, 160, 512, M, st), bytes_moved=4.0 * (2 * wav.numel() + dband.numel()))
     if a.json:
         Path(a.json).write_text(json.dumps({"batch": B, "kernels": res}, indent=1))
 
