@@ -437,3 +437,25 @@ def test_conv3x3_mfm_without_pool_matches_float64_reference(L, cuda, N, Cin, C, 
     err = (gx.double() - gx_ref).abs()
     tol = 2e-5 * max(gx_ref.abs().max().item(), 1.0)
     assert (err > tol).float().mean().item() <= 1e-3
+
+
+def test_conv3x3_batch_is_split_for_the_32bit_buffer_descriptor(L, cuda, monkeypatch):
+    """The Winograd kernels address a tensor through a 32-bit buffer descriptor (< 2 GiB per call); larger batches are
+    split by the wrapper.  Forcing the split on a small problem must not change a single bit."""
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(5, 32, 12, 10, generator=g).to(cuda)
+    w = (torch.randn(96, 32, 3, 3, generator=g) * 0.1).to(cuda)
+    b = torch.randn(96, generator=g).to(cuda)
+    gy = torch.randn(5, 48, 6, 5, generator=g).to(cuda)
+
+    def run():
+        xa = x.clone().requires_grad_(True)
+        y = L.conv3x3_mfm_pool2(xa, w, b)
+        (gx,) = torch.autograd.grad(y, xa, gy)
+        return y.detach(), gx
+
+    y0, g0 = run()
+    assert L._batch_chunks(5, 1) == [(0, 5)] and L._batch_chunks(5, (1 << 29) // 2) == [(0, 1), (1, 2), (2, 3), (3, 4), (4, 5)]
+    monkeypatch.setattr(L, "_batch_chunks", lambda N, per: [(0, 2), (2, 5)])
+    y1, g1 = run()
+    assert torch.equal(y0, y1) and torch.equal(g0, g1)
