@@ -72,6 +72,9 @@ SIGNATURES = {
     "advstep_stft_bands_supported": (ctypes.c_int, [_i64, _i64, _i64]),
     "advstep_stft_bands_f32": (ctypes.c_int, [_p, _p, _p, _p, _i64, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _p]),
     "advstep_stft_bands_backward_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _p, _i64, _i64, _i64, _i64, _i64, _i64, _p]),
+    "advstep_stft_mel_f32": (ctypes.c_int, [_p, _p, _p, _p, _i64, _p, _i64, _i64, _i64, _i64, _i64, _i64, _p]),
+    "advstep_stft_mel_backward_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _p, _p, _i64, _p, _i64, _i64, _i64, _i64, _i64,
+                                                    _i64, _p]),
     # include/advstep_fab.h
     "advstep_fab_hyperplane_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, ctypes.c_int, _p]),
     "advstep_fab_projection_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, ctypes.c_int, _p]),

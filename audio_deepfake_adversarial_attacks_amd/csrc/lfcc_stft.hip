@@ -216,6 +216,90 @@ __global__ __launch_bounds__(kThreads) void stft_bands_kernel(const float *__res
 
 constexpr int kMaxSpanT = 4, kMaxBands = 128;
 
+// ---- shared pieces of the two backward kernels ------------------------------------------------------------------------
+// frame f -> X[0 .. 256] in L.xs[wave] (bit-identical to the forward pass: same code, same inputs)
+__device__ __forceinline__ void frame_spectrum(const float *__restrict__ xb, const float *__restrict__ w, int T, int f,
+                                               int hop, Lds &L, int wave, int lane) {
+    load_frame(xb, w, T, f, hop, L.a[wave], lane);
+    wave_lds_sync();
+    fft256<false>(L.a[wave], L.b[wave], L.tw, lane);
+    unpack_real(L.a[wave], L.tw512, L.xs[wave], lane);
+    wave_lds_sync();
+}
+
+// L.xs[wave] = gradient w.r.t. the one-sided spectrum (dL/dRe, dL/dIm per bin) -> windowed frame gradient in dst[512].
+// The one-sided inverse counts interior bins twice: they are halved, imaginary parts of DC / Nyquist dropped; then
+// Z'[k] = (G[k] + G*[N-k]) + i W^-k (G[k] - G*[N-k]) is the packed input of the unnormalised 256-point inverse.
+__device__ __forceinline__ void spectrum_grad_to_frame(Lds &L, int wave, int lane, const float *__restrict__ w, float *dst,
+                                                       bool live) {
+    for (int k = lane; k < kBins; k += 64) {
+        float2 gk = L.xs[wave][k];
+        if (k == 0 || k == kN) gk.y = 0.0f;
+        else gk.x *= 0.5f, gk.y *= 0.5f;
+        L.xs[wave][k] = gk;
+    }
+    wave_lds_sync();
+    for (int k = lane; k < kN; k += 64) {
+        const float2 gk = L.xs[wave][k], gc = conjf2(L.xs[wave][kN - k]);
+        const float2 e = cadd(gk, gc), d = csub(gk, gc);
+        const float2 wd = cmul(conjf2(L.tw512[k]), d);
+        L.a[wave][P(k)] = make_float2(e.x - wd.y, e.y + wd.x);    // e + i * wd
+    }
+    wave_lds_sync();
+    fft256<true>(L.a[wave], L.b[wave], L.tw, lane);
+    // z'[n] = dframe[2n] + i dframe[2n + 1]; window, park in LDS
+    for (int n = lane; n < kN; n += 64) {
+        const float2 z = L.a[wave][P(n)];
+        dst[2 * n] = live ? w[2 * n] * z.x : 0.0f;
+        dst[2 * n + 1] = live ? w[2 * n + 1] * z.y : 0.0f;
+    }
+    wave_lds_sync();
+}
+
+// Overlap-add of a workgroup's 8 windowed frame gradients (dframe) into dx: every sample the frames touch is summed over
+// (positions that read it) x (frames) in a fixed order; positions are padded coordinates p = q + nfft/2.  Reflections
+// only exist next to the two ends of the signal.
+__device__ __forceinline__ void overlap_add_block(const float (*dframe)[kNfft], float *__restrict__ dxb, int f_base, int NF,
+                                                  int hop, int T) {
+    const int p_lo = f_base * hop;                                          // first padded position of the first frame
+    const int frames_here = (NF - f_base) < kFramesPerBlockBwd ? (NF - f_base) : kFramesPerBlockBwd;
+    const int p_hi = p_lo + (frames_here - 1) * hop + kNfft;                // one past the last
+    auto add_from = [&](int p, float &acc) {     // frames in ascending order: a fixed summation order
+        if (p < p_lo || p >= p_hi) return;
+#pragma unroll
+        for (int fl = 0; fl < kFramesPerBlockBwd; ++fl) {
+            const int n = p - p_lo - fl * hop;
+            if (fl < frames_here && n >= 0 && n < kNfft) acc += dframe[fl][n];
+        }
+    };
+    const bool near_left = p_lo < 2 * kN, near_right = p_hi > T;            // wave-uniform, almost always false
+    const int t_first = p_lo - kN, span_all = p_hi - p_lo;
+    for (int i = threadIdx.x; i < span_all; i += kThreads) {
+        const int t = t_first + i;
+        if (t < 0 || t >= T) continue;            // padded positions outside the signal are reached by reflection below
+        float acc = 0.0f;
+        add_from(t + kN, acc);
+        if (near_left && t >= 1 && t <= kN) add_from(kN - t, acc);                               // left reflection
+        if (near_right && t <= T - 2 && t >= T - 1 - kN) add_from(2 * (T - 1) - t + kN, acc);    // right reflection
+        if (acc != 0.0f) atomicAdd(dxb + t, acc);
+    }
+    if (!(near_left || near_right)) return;
+    // samples reached ONLY through a reflection from this workgroup's range (their direct position belongs to another
+    // workgroup's range or to none): left edge t = pad - p for p < pad, right edge t = 2 (T - 1) - (p - pad) for p - pad >= T
+    for (int i = threadIdx.x; i < span_all; i += kThreads) {
+        const int p = p_lo + i, q = p - kN;
+        int t = -1;
+        if (q < 0) t = -q;
+        else if (q >= T) t = 2 * (T - 1) - q;
+        if (t < 0 || t >= T) continue;
+        const int pd = t + kN;
+        if (pd >= p_lo && pd < p_hi) continue;    // the first loop already took this contribution
+        float acc = 0.0f;
+        add_from(p, acc);
+        if (acc != 0.0f) atomicAdd(dxb + t, acc);
+    }
+}
+
 struct LdsBwd {
     Lds c;
     float dframe[kFramesPerBlockBwd][kNfft];   // windowed frame gradients of this workgroup's frames
@@ -247,14 +331,8 @@ __global__ __launch_bounds__(kThreads) void stft_bands_backward_kernel(const flo
         const int fl = r * kWavesPerBlock + wave;          // local frame index
         const int f = f_base + fl;
         const bool live = f < NF;
-        // the frame's spectrum again (bit-identical to the forward pass: same code, same inputs)
-        load_frame(xb, w, T, live ? f : NF - 1, hop, L.a[wave], lane);
-        wave_lds_sync();
-        fft256<false>(L.a[wave], L.b[wave], L.tw, lane);
-        unpack_real(L.a[wave], L.tw512, L.xs[wave], lane);
-        wave_lds_sync();
-        // G[k] = 2 X[k] * sum_j fbt_w[k, j] dband[fbt_start[k] + j], pre-scaled for the one-sided inverse:
-        // interior bins * 1/2, imaginary parts of DC / Nyquist dropped
+        frame_spectrum(xb, w, T, live ? f : NF - 1, hop, L, wave, lane);
+        // G[k] = 2 X[k] * sum_j fbt_w[k, j] dband[fbt_start[k] + j]
         const float *drow_g = dband + (b * NF + (live ? f : NF - 1)) * M;
         for (int m = lane; m < M; m += 64) S.drow[wave][m] = drow_g[m];
         wave_lds_sync();
@@ -267,73 +345,146 @@ __global__ __launch_bounds__(kThreads) void stft_bands_backward_kernel(const flo
                 if (m < M) dp = fmaf(S.fbt_w[k * span_t + j], drow[m], dp);
             }
             const float2 z = L.xs[wave][k];
-            float2 gk = make_float2(2.0f * z.x * dp, 2.0f * z.y * dp);
-            if (k == 0 || k == kN) gk.y = 0.0f;
-            else gk.x *= 0.5f, gk.y *= 0.5f;
-            L.xs[wave][k] = gk;
+            L.xs[wave][k] = make_float2(2.0f * z.x * dp, 2.0f * z.y * dp);
         }
         wave_lds_sync();
-        // half spectrum -> packed 256-point input of the inverse: Z'[k] = (G[k] + G*[N-k]) + i W^-k (G[k] - G*[N-k])
-        for (int k = lane; k < kN; k += 64) {
-            const float2 gk = L.xs[wave][k], gc = conjf2(L.xs[wave][kN - k]);
-            const float2 e = cadd(gk, gc), d = csub(gk, gc);
-            const float2 wd = cmul(conjf2(L.tw512[k]), d);
-            L.a[wave][P(k)] = make_float2(e.x - wd.y, e.y + wd.x);    // e + i * wd
-        }
-        wave_lds_sync();
-        fft256<true>(L.a[wave], L.b[wave], L.tw, lane);
-        // z'[n] = dframe[2n] + i dframe[2n + 1]; window, park in LDS
-        for (int n = lane; n < kN; n += 64) {
-            const float2 z = L.a[wave][P(n)];
-            S.dframe[fl][2 * n] = live ? w[2 * n] * z.x : 0.0f;
-            S.dframe[fl][2 * n + 1] = live ? w[2 * n + 1] * z.y : 0.0f;
-        }
-        wave_lds_sync();
+        spectrum_grad_to_frame(L, wave, lane, w, S.dframe[fl], live);
     }
     __syncthreads();   // all frames' windowed gradients are in LDS
-    // overlap-add: the samples this workgroup's frames touch, each summed over (positions that read it) x (frames) in a
-    // fixed order; positions are padded coordinates p = q + nfft/2
-    const int p_lo = f_base * hop;                                          // first padded position of the first frame
-    const int frames_here = (NF - f_base) < kFramesPerBlockBwd ? (NF - f_base) : kFramesPerBlockBwd;
-    const int p_hi = p_lo + (frames_here - 1) * hop + kNfft;                // one past the last
-    // sample range that can receive something: direct positions and both reflections
-    auto add_from = [&](int p, float &acc) {     // frames in ascending order: a fixed summation order
-        if (p < p_lo || p >= p_hi) return;
-#pragma unroll
-        for (int fl = 0; fl < kFramesPerBlockBwd; ++fl) {
-            const int n = p - p_lo - fl * hop;
-            if (fl < frames_here && n >= 0 && n < kNfft) acc += S.dframe[fl][n];
+    overlap_add_block(S.dframe, dx + b * T, f_base, NF, hop, T);
+}
+
+// ---- mel-spec frontend (src/frontends.py:53-79): STFT -> MelScale on the real and imaginary parts -> |.|, angle ----------
+// out (B, 2, M, NF): plane 0 the magnitude, plane 1 the phase of  Y[m] = sum_k fb[k, m] X[k].
+constexpr int kMelMax = 80;
+
+struct LdsMel {
+    Lds c;
+    float2 y[kWavesPerBlock][kMelMax];                       // a frame's complex mel bands
+    float stage[2][kMelMax][kFramesPerBlockFwd + 1];         // (plane, band, frame) tile of the output / its gradient
+};
+
+__device__ __forceinline__ void mel_bands(const Lds &L, int wave, int lane, const int32_t *__restrict__ fb_start,
+                                          const float *__restrict__ fb_w, int span, int M, float2 *y) {
+    for (int m = lane; m < M; m += 64) {
+        const int f0 = fb_start[m];
+        float re = 0.0f, im = 0.0f;
+        for (int j = 0; j < span; ++j) {
+            const int k = f0 + j;
+            if (k < kBins) {
+                const float wj = fb_w[m * span + j];
+                const float2 z = L.xs[wave][k];
+                re = fmaf(wj, z.x, re);
+                im = fmaf(wj, z.y, im);
+            }
         }
-    };
-    // reflections only exist next to the two ends of the signal: wave-uniform, almost always false
-    const bool near_left = p_lo < 2 * kN, near_right = p_hi > T;
-    // direct range of samples: t = p - pad for p in [p_lo, p_hi)
-    const int t_first = p_lo - kN, span_t_all = p_hi - p_lo;
-    for (int i = threadIdx.x; i < span_t_all; i += kThreads) {
-        const int t = t_first + i;
-        if (t < 0 || t >= T) continue;            // padded positions outside the signal are reached by reflection below
-        float acc = 0.0f;
-        add_from(t + kN, acc);
-        if (near_left && t >= 1 && t <= kN) add_from(kN - t, acc);                               // left reflection
-        if (near_right && t <= T - 2 && t >= T - 1 - kN) add_from(2 * (T - 1) - t + kN, acc);    // right reflection
-        if (acc != 0.0f) atomicAdd(dx + b * T + t, acc);
+        y[m] = make_float2(re, im);
     }
-    if (!(near_left || near_right)) return;
-    // samples reached ONLY through a reflection from this workgroup's range (their direct position belongs to another
-    // workgroup's range or to none): left edge t = pad - p for p < pad, right edge t = 2 (T - 1) - (p - pad) for p - pad >= T
-    for (int i = threadIdx.x; i < span_t_all; i += kThreads) {
-        const int p = p_lo + i, q = p - kN;
-        int t = -1;
-        if (q < 0) t = -q;
-        else if (q >= T) t = 2 * (T - 1) - q;
-        if (t < 0 || t >= T) continue;
-        // skip if t's direct position is inside this workgroup's range: the first loop already took this contribution
-        const int pd = t + kN;
-        if (pd >= p_lo && pd < p_hi) continue;
-        float acc = 0.0f;
-        add_from(p, acc);
-        if (acc != 0.0f) atomicAdd(dx + b * T + t, acc);
+}
+
+// grid (ceil(NF / 16), B)
+__global__ __launch_bounds__(kThreads) void stft_mel_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                            const int32_t *__restrict__ fb_start,
+                                                            const float *__restrict__ fb_w, int span,
+                                                            float *__restrict__ out, int T, int NF, int hop, int M) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char raw[];
+    LdsMel &S = *reinterpret_cast<LdsMel *>(raw);
+    Lds &L = S.c;
+    fill_twiddles(L);
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t b = blockIdx.y;
+    const int f_base = blockIdx.x * kFramesPerBlockFwd;
+    for (int r = 0; r < kFramesPerBlockFwd / kWavesPerBlock; ++r) {
+        const int fl = r * kWavesPerBlock + wave, f = f_base + fl;
+        if (f >= NF) break;                       // wave-uniform
+        frame_spectrum(x + b * T, w, T, f, hop, L, wave, lane);
+        mel_bands(L, wave, lane, fb_start, fb_w, span, M, S.y[wave]);
+        wave_lds_sync();
+        for (int m = lane; m < M; m += 64) {
+            const float2 v = S.y[wave][m];
+            S.stage[0][m][fl] = sqrtf(v.x * v.x + v.y * v.y);
+            S.stage[1][m][fl] = atan2f(v.y, v.x);
+        }
+        wave_lds_sync();
     }
+    __syncthreads();
+    // (plane, band) rows of up to 16 consecutive frames
+    const int frames_here = (NF - f_base) < kFramesPerBlockFwd ? (NF - f_base) : kFramesPerBlockFwd;
+    for (int i = threadIdx.x; i < 2 * M * kFramesPerBlockFwd; i += kThreads) {
+        const int fl = i % kFramesPerBlockFwd, row = i / kFramesPerBlockFwd, plane = row / M, m = row - plane * M;
+        if (fl < frames_here) out[((b * 2 + plane) * M + m) * NF + f_base + fl] = S.stage[plane][m][fl];
+    }
+}
+
+struct LdsMelBwd {
+    Lds c;
+    float dframe[kFramesPerBlockBwd][kNfft];
+    float2 y[kWavesPerBlock][kMelMax];
+    float stage[2][kMelMax][kFramesPerBlockBwd + 1];
+};
+
+// grid (ceil(NF / 8), B).  dout (B, 2, M, NF) -> dx (B, T), dx zeroed by the host entry point.
+__global__ __launch_bounds__(kThreads) void stft_mel_backward_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                                     const float *__restrict__ dout,
+                                                                     const int32_t *__restrict__ fb_start,
+                                                                     const float *__restrict__ fb_w, int span,
+                                                                     const int32_t *__restrict__ fbt_start,
+                                                                     const float *__restrict__ fbt_w, int span_t,
+                                                                     float *__restrict__ dx, int T, int NF, int hop, int M) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char raw[];
+    LdsMelBwd &S = *reinterpret_cast<LdsMelBwd *>(raw);
+    Lds &L = S.c;
+    fill_twiddles(L);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t b = blockIdx.y;
+    const int f_base = blockIdx.x * kFramesPerBlockBwd;
+    const int frames_here = (NF - f_base) < kFramesPerBlockBwd ? (NF - f_base) : kFramesPerBlockBwd;
+    for (int i = threadIdx.x; i < 2 * M * kFramesPerBlockBwd; i += kThreads) {
+        const int fl = i % kFramesPerBlockBwd, row = i / kFramesPerBlockBwd, plane = row / M, m = row - plane * M;
+        S.stage[plane][m][fl] = fl < frames_here ? dout[((b * 2 + plane) * M + m) * NF + f_base + fl] : 0.0f;
+    }
+    __syncthreads();
+    const float *xb = x + b * T;
+    for (int r = 0; r < kFramesPerBlockBwd / kWavesPerBlock; ++r) {
+        const int fl = r * kWavesPerBlock + wave, f = f_base + fl;
+        const bool live = f < NF;
+        frame_spectrum(xb, w, T, live ? f : NF - 1, hop, L, wave, lane);
+        mel_bands(L, wave, lane, fb_start, fb_w, span, M, S.y[wave]);
+        wave_lds_sync();
+        // d(|Y|, angle Y) -> (dL/dRe Y, dL/dIm Y): torch's abs / angle backward, 0 at Y = 0
+        for (int m = lane; m < M; m += 64) {
+            const float2 v = S.y[wave][m];
+            const float gm = S.stage[0][m][fl], gp = S.stage[1][m][fl];
+            const float n2 = v.x * v.x + v.y * v.y;
+            float2 gy = make_float2(0.0f, 0.0f);
+            if (n2 > 0.0f) {
+                const float inv = 1.0f / sqrtf(n2), inv2 = 1.0f / n2;
+                gy.x = gm * v.x * inv - gp * v.y * inv2;
+                gy.y = gm * v.y * inv + gp * v.x * inv2;
+            }
+            S.y[wave][m] = gy;
+        }
+        wave_lds_sync();
+        // dX[k] = sum_j fbt_w[k, j] dY[fbt_start[k] + j]
+        for (int k = lane; k < kBins; k += 64) {
+            const int m0 = fbt_start[k];
+            float re = 0.0f, im = 0.0f;
+            for (int j = 0; j < span_t; ++j) {
+                const int m = m0 + j;
+                if (m < M) {
+                    const float wj = fbt_w[k * span_t + j];
+                    re = fmaf(wj, S.y[wave][m].x, re);
+                    im = fmaf(wj, S.y[wave][m].y, im);
+                }
+            }
+            L.xs[wave][k] = make_float2(re, im);
+        }
+        wave_lds_sync();
+        spectrum_grad_to_frame(L, wave, lane, w, S.dframe[fl], live);
+    }
+    __syncthreads();
+    overlap_add_block(S.dframe, dx + b * T, f_base, NF, hop, T);
 }
 
 constexpr int64_t kMaxGridY = 65535;
@@ -400,6 +551,44 @@ int advstep_stft_bands_backward_f32(const float *x, const float *window, const f
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(stft_bands_backward_kernel, grid, dim3(kThreads), lds, st, x, window, dband, fbt_start, fbt_w,
                        (int)span_t, dx, (int)T, (int)NF, (int)hop, (int)M);
+    return status_after_launch();
+}
+
+int advstep_stft_mel_f32(const float *x, const float *window, const int32_t *fb_start, const float *fb_w, int64_t span,
+                         float *out, int64_t B, int64_t T, int64_t NF, int64_t hop, int64_t nfft, int64_t M,
+                         advstep_stream_t stream) {
+    STFT_REQUIRE(B >= 0 && NF >= 0 && M >= 0 && span >= 1);
+    if (B == 0 || NF == 0 || M == 0) return ADVSTEP_OK;
+    STFT_REQUIRE(x && window && fb_start && fb_w && out && B <= kMaxGridY && M <= kMelMax);
+    STFT_REQUIRE(advstep_stft_bands_supported(nfft, hop, T) && NF == 1 + T / hop);
+    hipStream_t st = as_stream(stream);
+    ensure_twiddles(st);
+    const size_t lds = sizeof(LdsMel);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(stft_mel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+    hipLaunchKernelGGL(stft_mel_kernel, dim3((unsigned)ceil_div(NF, kFramesPerBlockFwd), (unsigned)B), dim3(kThreads), lds, st,
+                       x, window, fb_start, fb_w, (int)span, out, (int)T, (int)NF, (int)hop, (int)M);
+    return status_after_launch();
+}
+
+int advstep_stft_mel_backward_f32(const float *x, const float *window, const float *dout, const int32_t *fb_start,
+                                  const float *fb_w, int64_t span, const int32_t *fbt_start, const float *fbt_w,
+                                  int64_t span_t, float *dx, int64_t B, int64_t T, int64_t NF, int64_t hop, int64_t nfft,
+                                  int64_t M, advstep_stream_t stream) {
+    STFT_REQUIRE(B >= 0 && NF >= 0 && M >= 0 && span >= 1 && span_t >= 1);
+    if (B == 0 || T == 0) return ADVSTEP_OK;
+    STFT_REQUIRE(x && window && dout && fb_start && fb_w && fbt_start && fbt_w && dx && B <= kMaxGridY && M <= kMelMax);
+    STFT_REQUIRE(advstep_stft_bands_supported(nfft, hop, T) && NF == 1 + T / hop);
+    STFT_REQUIRE(kFramesPerBlockBwd * hop >= kNfft - hop);
+    hipStream_t st = as_stream(stream);
+    ensure_twiddles(st);
+    if (hipMemsetAsync(dx, 0, (size_t)B * T * sizeof(float), st) != hipSuccess) return ADVSTEP_ELAUNCH;
+    const size_t lds = sizeof(LdsMelBwd);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(stft_mel_backward_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(stft_mel_backward_kernel, dim3((unsigned)ceil_div(NF, kFramesPerBlockBwd), (unsigned)B), dim3(kThreads),
+                       lds, st, x, window, dout, fb_start, fb_w, (int)span, fbt_start, fbt_w, (int)span_t, dx, (int)T, (int)NF,
+                       (int)hop, (int)M);
     return status_after_launch();
 }
 

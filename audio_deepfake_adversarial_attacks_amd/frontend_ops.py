@@ -254,6 +254,52 @@ def lfcc_from_waveform(x: torch.Tensor, window_nfft: torch.Tensor, hop: int, tab
     return _LfccFromWaveform.apply(x.contiguous(), window_nfft, hop, tables, dct, top_db)
 
 
+class _MelSpecFromWaveform(torch.autograd.Function):
+    """The mel-spec frontend (src/frontends.py:53-79) with the STFT inside the kernels: (B, T) -> (B, 2, M, NF)."""
+
+    @staticmethod
+    def forward(ctx, x, window, hop, tables: FilterbankTables):
+        B, T = x.shape
+        nfft = window.numel()
+        NF = 1 + T // hop
+        M = tables.fb_start.numel()
+        dev = x.device
+        out = torch.empty((B, 2, M, NF), dtype=torch.float32, device=dev)
+        with _Launch("stft_mel", dev):
+            st = _lib.load().advstep_stft_mel_f32(x.data_ptr(), window.data_ptr(), tables.fb_start.data_ptr(),
+                                                  tables.fb_w.data_ptr(), tables.span, out.data_ptr(), B, T, NF, hop, nfft, M,
+                                                  _stream(dev))
+        _lib.check(st, "advstep_stft_mel_f32")
+        ctx.save_for_backward(x, window, tables.fb_start, tables.fb_w, tables.fbt_start, tables.fbt_w)
+        ctx.meta = (B, T, NF, M, tables.span, tables.span_t, hop, nfft)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, window, fb_start, fb_w, fbt_start, fbt_w = ctx.saved_tensors
+        B, T, NF, M, span, span_t, hop, nfft = ctx.meta
+        dev = gout.device
+        go = gout.contiguous()
+        dx = torch.empty((B, T), dtype=torch.float32, device=dev)
+        with _Launch("stft_mel_backward", dev):
+            st = _lib.load().advstep_stft_mel_backward_f32(x.data_ptr(), window.data_ptr(), go.data_ptr(), fb_start.data_ptr(),
+                                                           fb_w.data_ptr(), span, fbt_start.data_ptr(), fbt_w.data_ptr(), span_t,
+                                                           dx.data_ptr(), B, T, NF, hop, nfft, M, _stream(dev))
+        _lib.check(st, "advstep_stft_mel_backward_f32")
+        return dx, None, None, None
+
+
+def mel_spec_supported(nfft: int, hop: int, T: int, n_mels: int) -> bool:
+    return bool(_lib.load().advstep_stft_bands_supported(nfft, hop, T)) and n_mels <= 80
+
+
+def mel_spec_from_waveform(x: torch.Tensor, window_nfft: torch.Tensor, hop: int, tables: FilterbankTables) -> torch.Tensor:
+    """Waveform (B, T) -> (B, 2, n_mels, 1 + T // hop): magnitude and phase of the mel-projected complex STFT."""
+    if not x.is_cuda or x.dtype != torch.float32 or x.dim() != 2:
+        raise _lib.AdvstepError("mel_spec_from_waveform needs a float32 (B, T) waveform on a HIP device (no CPU fallback)")
+    return _MelSpecFromWaveform.apply(x.contiguous(), window_nfft, hop, tables)
+
+
 def lfcc_tail(spec: torch.Tensor, tables: FilterbankTables, dct: torch.Tensor, top_db: float = 80.0) -> torch.Tensor:
     """Complex STFT (B, F, NF) -> LFCC (B, K, NF) (view of a frame-major buffer)."""
     return _LfccTail.apply(spec, tables, dct, top_db)

@@ -32,6 +32,12 @@ def _fused_stft_enabled() -> bool:
     return os.environ.get("ADVSTEP_FUSED_STFT", "1") != "0"
 
 
+def _fused_mel_enabled() -> bool:
+    """ADVSTEP_FUSED_MEL=0 keeps the plain torch op chain of the mel-spec frontend on the GPU; default on."""
+    import os
+    return os.environ.get("ADVSTEP_FUSED_MEL", "1") != "0"
+
+
 def _fused_lfcc_enabled() -> bool:
     """ADVSTEP_FUSED_LFCC=0 keeps the plain torch op chain on the GPU (A/B measurements); default on."""
     import os
@@ -225,7 +231,24 @@ class MelSpecFrontend(nn.Module):
         # non-persistent: in the reference this frontend is a plain function (no state_dict entries)
         self.mel_scale = MelScale(80, SAMPLING_RATE, N_FFT // 2 + 1, persistent=False)
 
+    def _fused_state(self, device):
+        """Sparse mel tables + the rectangular window zero-padded (centred) to n_fft, cached per device."""
+        key = (self.mel_scale.fb.data_ptr(), self.mel_scale.fb._version, str(device))
+        if getattr(self, "_fused_key", None) != key:
+            from . import frontend_ops
+            left = (N_FFT - self.win_length) // 2
+            window = torch.zeros(N_FFT, dtype=torch.float32, device=device)
+            window[left:left + self.win_length] = 1.0
+            self._fused_key, self._fused_val = key, (frontend_ops.filterbank_tables(self.mel_scale.fb), window)
+        return self._fused_val
+
     def forward(self, audio: torch.Tensor) -> torch.Tensor:
+        if audio.is_cuda and audio.dim() == 2 and audio.dtype == torch.float32 and _fused_mel_enabled():
+            from . import frontend_ops
+            if frontend_ops.mel_spec_supported(N_FFT, self.hop_length, audio.shape[1], self.mel_scale.fb.shape[1]):
+                # framing + FFT + complex mel projection + magnitude / phase in one kernel each way (SURVEY.md 8-f2)
+                tables, window = self._fused_state(audio.device)
+                return frontend_ops.mel_spec_from_waveform(audio, window, self.hop_length, tables)
         stft = torch.stft(audio, n_fft=N_FFT, return_complex=True, hop_length=self.hop_length,
                           win_length=self.win_length,
                           window=torch.ones(self.win_length, dtype=audio.dtype, device=audio.device))
