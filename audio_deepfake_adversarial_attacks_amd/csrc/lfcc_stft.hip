@@ -214,7 +214,7 @@ __global__ __launch_bounds__(kThreads) void stft_bands_kernel(const float *__res
     }
 }
 
-constexpr int kMaxSpanT = 4, kMaxBands = 128;
+constexpr int kMaxSpanT = 8, kMaxBands = 128;   // bands per bin: 2 for the linear bank, up to 6 for 128 mel bands at low frequencies
 
 // ---- shared pieces of the two backward kernels ------------------------------------------------------------------------
 // frame f -> X[0 .. 256] in L.xs[wave] (bit-identical to the forward pass: same code, same inputs)

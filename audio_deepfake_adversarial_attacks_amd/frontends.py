@@ -127,6 +127,44 @@ class Spectrogram(nn.Module):
         return spec.abs().pow(2.0)
 
 
+def _cached_tables(owner, fb: torch.Tensor):
+    """Sparse filterbank tables for the fused kernels, cached on `owner` until `fb` moves or changes."""
+    key = (fb.data_ptr(), fb._version, str(fb.device))
+    if getattr(owner, "_tables_key", None) != key:
+        from . import frontend_ops
+        owner._tables_key, owner._tables_val = key, frontend_ops.filterbank_tables(fb)
+    return owner._tables_val
+
+
+def _cached_window_nfft(owner, spectrogram) -> torch.Tensor:
+    """The analysis window zero-padded (centred) to n_fft, as torch.stft applies it; cached on `owner`."""
+    w = spectrogram.window
+    key = (w.data_ptr(), w._version, str(w.device))
+    if getattr(owner, "_wpad_key", None) != key:
+        n_fft = spectrogram.n_fft
+        left = (n_fft - w.numel()) // 2
+        padded = torch.zeros(n_fft, dtype=w.dtype, device=w.device)
+        padded[left:left + w.numel()] = w.detach()
+        owner._wpad_key, owner._wpad_val = key, padded
+    return owner._wpad_val
+
+
+def _fused_cepstrum(owner, waveform, spectrogram, fb, dct_mat, top_db):
+    """filterbank -> dB -> DCT of the power STFT through the fused kernels, or None when they do not apply."""
+    if not (waveform.is_cuda and waveform.dim() == 2 and waveform.dtype == torch.float32 and _fused_lfcc_enabled()
+            and dct_mat.shape[0] <= 128 and dct_mat.shape[1] in (20, 40, 80)):
+        return None
+    from . import frontend_ops
+    sg = spectrogram
+    tables = _cached_tables(owner, fb)
+    if waveform.shape[1] > sg.n_fft // 2 and sg.n_fft % 4 == 0 and _fused_stft_enabled():
+        # framing, FFT, filterbank, dB in one kernel; floor + DCT in another (and two more on the way back)
+        return frontend_ops.lfcc_from_waveform(waveform, _cached_window_nfft(owner, sg), sg.hop_length, tables, dct_mat, top_db)
+    spec = torch.stft(waveform, n_fft=sg.n_fft, hop_length=sg.hop_length, win_length=sg.win_length, window=sg.window,
+                      center=True, pad_mode="reflect", normalized=False, onesided=True, return_complex=True)
+    return frontend_ops.lfcc_tail(spec, tables, dct_mat, top_db)
+
+
 class LFCC(nn.Module):
     """torchaudio.transforms.LFCC(sample_rate, n_filter=128, n_lfcc, dct_type=2, norm='ortho', log_lf=False)."""
 
@@ -140,40 +178,15 @@ class LFCC(nn.Module):
         self.register_buffer("dct_mat", create_dct(n_lfcc, n_filter, "ortho"))
 
     def _tables(self):
-        """Sparse filterbank tables for the fused kernels, cached until `filter_mat` moves or changes."""
-        key = (self.filter_mat.data_ptr(), self.filter_mat._version, str(self.filter_mat.device))
-        if getattr(self, "_tables_key", None) != key:
-            from . import frontend_ops
-            self._tables_key, self._tables_val = key, frontend_ops.filterbank_tables(self.filter_mat)
-        return self._tables_val
+        return _cached_tables(self, self.filter_mat)
 
     def _window_nfft(self):
-        """The analysis window zero-padded (centred) to n_fft, as torch.stft applies it; cached."""
-        w = self.Spectrogram.window
-        key = (w.data_ptr(), w._version, str(w.device))
-        if getattr(self, "_wpad_key", None) != key:
-            n_fft = self.Spectrogram.n_fft
-            left = (n_fft - w.numel()) // 2
-            padded = torch.zeros(n_fft, dtype=w.dtype, device=w.device)
-            padded[left:left + w.numel()] = w.detach()
-            self._wpad_key, self._wpad_val = key, padded
-        return self._wpad_val
+        return _cached_window_nfft(self, self.Spectrogram)
 
     def forward(self, waveform: torch.Tensor) -> torch.Tensor:
-        if (waveform.is_cuda and waveform.dim() == 2 and waveform.dtype == torch.float32 and _fused_lfcc_enabled()
-                and self.dct_mat.shape[0] <= 128 and self.dct_mat.shape[1] in (20, 40, 80)):
-            # STFT by PyTorch (reflect pad + framing + rocFFT); everything after it in two kernels (+3 backward),
-            # written frame-major for LCNN's first block (SURVEY.md section 8-f2)
-            from . import frontend_ops
-            sg = self.Spectrogram
-            if waveform.shape[1] > sg.n_fft // 2 and sg.n_fft % 4 == 0 and _fused_stft_enabled():
-                # framing and overlap-add are kernels too; only the batched FFT itself is rocFFT
-                return frontend_ops.lfcc_from_waveform(waveform, self._window_nfft(), sg.hop_length, self._tables(),
-                                                       self.dct_mat, self.top_db)
-            spec = torch.stft(waveform, n_fft=sg.n_fft, hop_length=sg.hop_length, win_length=sg.win_length,
-                              window=sg.window, center=True, pad_mode="reflect", normalized=False, onesided=True,
-                              return_complex=True)
-            return frontend_ops.lfcc_tail(spec, self._tables(), self.dct_mat, self.top_db)
+        fused = _fused_cepstrum(self, waveform, self.Spectrogram, self.filter_mat, self.dct_mat, self.top_db)
+        if fused is not None:     # SURVEY.md section 8-f2; written frame-major for LCNN's first block
+            return fused
         spec = self.Spectrogram(waveform)                                               # (B, 257, frames)
         bands = torch.matmul(spec.transpose(-1, -2), self.filter_mat).transpose(-1, -2)   # (B, 128, frames)
         bands = amplitude_to_db_power(bands, self.top_db)
@@ -216,6 +229,11 @@ class MFCC(nn.Module):
         self.register_buffer("dct_mat", create_dct(n_mfcc, 128, "ortho"))
 
     def forward(self, waveform):
+        # same structure as LFCC (power STFT -> filterbank -> dB -> DCT) with a mel filterbank: same fused kernels
+        fused = _fused_cepstrum(self, waveform, self.MelSpectrogram.spectrogram, self.MelSpectrogram.mel_scale.fb,
+                                self.dct_mat, self.top_db)
+        if fused is not None:
+            return fused
         mel = amplitude_to_db_power(self.MelSpectrogram(waveform), self.top_db)
         return torch.matmul(mel.transpose(-1, -2), self.dct_mat).transpose(-1, -2)
 

@@ -125,3 +125,18 @@ def test_specrnet_uses_fused_mel_frontend(cuda, monkeypatch):
         monkeypatch.setenv("ADVSTEP_FUSED_MEL", "1")
         z1 = model(x)
     assert z0.shape == (2, 1) and (z0 - z1).abs().max().item() <= 1e-3 * max(z0.abs().max().item(), 1.0)
+
+
+def test_fused_mfcc_matches_torch_chain(cuda, monkeypatch):
+    """MFCC = the LFCC structure with a 128-band mel filterbank (up to 6 bands per bin): same fused kernels."""
+    from audio_deepfake_adversarial_attacks_amd.frontends import MFCC
+    fe = MFCC().to(cuda)
+    gen = torch.Generator().manual_seed(21)
+    x = torch.rand(3, 16_000, generator=gen).to(cuda)
+    monkeypatch.setenv("ADVSTEP_FUSED_LFCC", "0")
+    gy = torch.randn(fe(x).shape, generator=gen).to(cuda)
+    y_ref, g_ref = run(fe, x, gy, False, monkeypatch)
+    y, g = run(fe, x, gy, True, monkeypatch)
+    assert y.shape == y_ref.shape == (3, 80, 101)
+    assert (y - y_ref).abs().max().item() <= 2e-3
+    assert (g - g_ref).norm().item() / g_ref.norm().item() <= 1e-4
