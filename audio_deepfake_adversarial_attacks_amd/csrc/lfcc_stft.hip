@@ -9,7 +9,7 @@
 // by even/odd packing), and
 //   forward : power -> sparse filterbank -> dB -> band_db row (512 B, coalesced) + the workgroup maximum;
 //   backward: recomputes the frame's spectrum (same code, same bits: nothing was saved), forms
-//             d|X|^2 = 2 X (fb^T dband), inverse-transforms, applies the window and overlap-adds.  A workgroup owns 8
+//             d|X|^2 = 2 X (fb^T dband), inverse-transforms, applies the window and overlap-adds.  A workgroup owns 4
 //             consecutive frames: their windowed gradients meet in LDS and every output sample is summed in frame
 //             order (deterministic); the <= 2 workgroups that share a border sample combine with one float atomic
 //             each (two operands: commutative, so still deterministic).  dx must be zeroed by the caller.
@@ -28,7 +28,7 @@ constexpr int kNfft = 2 * kN;
 constexpr int kBins = kN + 1;      // one-sided spectrum
 constexpr int kWavesPerBlock = 4;
 constexpr int kThreads = kWavesPerBlock * 64;
-constexpr int kFramesPerBlockBwd = 8;
+constexpr int kFramesPerBlockBwd = 4;   // one per wave: 35 KB of LDS per workgroup = 4 workgroups (16 waves) per CU
 constexpr float kAmin = 1e-10f;
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
@@ -138,8 +138,9 @@ __device__ __forceinline__ void unpack_real(const float2 *Z, const float2 *__res
 
 struct Lds {
     float2 a[kWavesPerBlock][kNPad];
-    float2 b[kWavesPerBlock][kNPad];
-    float2 xs[kWavesPerBlock][kBins + 7];
+    float2 b[kWavesPerBlock][kNPad];   // second FFT buffer; between transforms its first 257 entries hold the half spectrum
+    __device__ __forceinline__ float2 *xs_of(int wave) { return b[wave]; }
+    __device__ __forceinline__ const float2 *xs_of(int wave) const { return b[wave]; }
     float2 tw[kN];       // exp(-2 pi i m / 256)
     float2 tw512[kN];    // exp(-2 pi i k / 512)
     float red[kWavesPerBlock];
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(kThreads) void stft_bands_kernel(const float *__res
         load_frame(x + b * T, w, T, f, hop, L.a[wave], lane);
         wave_lds_sync();
         fft256<false>(L.a[wave], L.b[wave], L.tw, lane);
-        unpack_real(L.a[wave], L.tw512, L.xs[wave], lane);
+        unpack_real(L.a[wave], L.tw512, L.xs_of(wave), lane);
         wave_lds_sync();
         float *row = band_db + (b * NF + f) * M;
         for (int m = lane; m < M; m += 64) {
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(kThreads) void stft_bands_kernel(const float *__res
             for (int j = 0; j < span; ++j) {
                 const int k = f0 + j;
                 if (k < kBins) {
-                    const float2 z = L.xs[wave][k];
+                    const float2 z = L.xs_of(wave)[k];
                     band = fmaf(fb_w[m * span + j], fmaf(z.x, z.x, z.y * z.y), band);
                 }
             }
@@ -217,30 +218,34 @@ __global__ __launch_bounds__(kThreads) void stft_bands_kernel(const float *__res
 constexpr int kMaxSpanT = 8, kMaxBands = 128;   // bands per bin: 2 for the linear bank, up to 6 for 128 mel bands at low frequencies
 
 // ---- shared pieces of the two backward kernels ------------------------------------------------------------------------
-// frame f -> X[0 .. 256] in L.xs[wave] (bit-identical to the forward pass: same code, same inputs)
+// frame f -> X[0 .. 256] in L.xs_of(wave) (bit-identical to the forward pass: same code, same inputs)
 __device__ __forceinline__ void frame_spectrum(const float *__restrict__ xb, const float *__restrict__ w, int T, int f,
                                                int hop, Lds &L, int wave, int lane) {
     load_frame(xb, w, T, f, hop, L.a[wave], lane);
     wave_lds_sync();
     fft256<false>(L.a[wave], L.b[wave], L.tw, lane);
-    unpack_real(L.a[wave], L.tw512, L.xs[wave], lane);
+    unpack_real(L.a[wave], L.tw512, L.xs_of(wave), lane);
     wave_lds_sync();
 }
 
-// L.xs[wave] = gradient w.r.t. the one-sided spectrum (dL/dRe, dL/dIm per bin) -> windowed frame gradient in dst[512].
+// L.xs_of(wave) = gradient w.r.t. the one-sided spectrum (dL/dRe, dL/dIm per bin) -> windowed frame gradient in dst[512].
 // The one-sided inverse counts interior bins twice: they are halved, imaginary parts of DC / Nyquist dropped; then
 // Z'[k] = (G[k] + G*[N-k]) + i W^-k (G[k] - G*[N-k]) is the packed input of the unnormalised 256-point inverse.
+__device__ __forceinline__ float2 one_sided_scale(float2 gk, int k) {
+    if (k == 0 || k == kN) gk.y = 0.0f;
+    else gk.x *= 0.5f, gk.y *= 0.5f;
+    return gk;
+}
+
+template <bool PRESCALED>
 __device__ __forceinline__ void spectrum_grad_to_frame(Lds &L, int wave, int lane, const float *__restrict__ w, float *dst,
                                                        bool live) {
-    for (int k = lane; k < kBins; k += 64) {
-        float2 gk = L.xs[wave][k];
-        if (k == 0 || k == kN) gk.y = 0.0f;
-        else gk.x *= 0.5f, gk.y *= 0.5f;
-        L.xs[wave][k] = gk;
+    if (!PRESCALED) {
+        for (int k = lane; k < kBins; k += 64) L.xs_of(wave)[k] = one_sided_scale(L.xs_of(wave)[k], k);
+        wave_lds_sync();
     }
-    wave_lds_sync();
     for (int k = lane; k < kN; k += 64) {
-        const float2 gk = L.xs[wave][k], gc = conjf2(L.xs[wave][kN - k]);
+        const float2 gk = L.xs_of(wave)[k], gc = conjf2(L.xs_of(wave)[kN - k]);
         const float2 e = cadd(gk, gc), d = csub(gk, gc);
         const float2 wd = cmul(conjf2(L.tw512[k]), d);
         L.a[wave][P(k)] = make_float2(e.x - wd.y, e.y + wd.x);    // e + i * wd
@@ -256,7 +261,7 @@ __device__ __forceinline__ void spectrum_grad_to_frame(Lds &L, int wave, int lan
     wave_lds_sync();
 }
 
-// Overlap-add of a workgroup's 8 windowed frame gradients (dframe) into dx: every sample the frames touch is summed over
+// Overlap-add of a workgroup's windowed frame gradients (dframe) into dx: every sample the frames touch is summed over
 // (positions that read it) x (frames) in a fixed order; positions are padded coordinates p = q + nfft/2.  Reflections
 // only exist next to the two ends of the signal.
 __device__ __forceinline__ void overlap_add_block(const float (*dframe)[kNfft], float *__restrict__ dxb, int f_base, int NF,
@@ -300,15 +305,18 @@ __device__ __forceinline__ void overlap_add_block(const float (*dframe)[kNfft], 
     }
 }
 
+template <int SPAN_CAP>
 struct LdsBwd {
     Lds c;
     float dframe[kFramesPerBlockBwd][kNfft];   // windowed frame gradients of this workgroup's frames
-    float fbt_w[kBins * kMaxSpanT];            // transposed filterbank, staged once per workgroup
+    float fbt_w[kBins * SPAN_CAP];             // transposed filterbank, staged once per workgroup
     int32_t fbt_start[kBins];
     float drow[kWavesPerBlock][kMaxBands];     // the current frame's band gradients
 };
 
-// grid (ceil(NF / 8), B): a workgroup owns 8 consecutive frames (2 per wave)
+// grid (ceil(NF / 4), B): a workgroup owns 4 consecutive frames (one per wave).  SPAN_CAP >= span_t sizes the LDS copy of
+// the transposed filterbank.
+template <int SPAN_CAP>
 __global__ __launch_bounds__(kThreads) void stft_bands_backward_kernel(const float *__restrict__ x,
                                                                        const float *__restrict__ w,
                                                                        const float *__restrict__ dband,
@@ -317,7 +325,7 @@ __global__ __launch_bounds__(kThreads) void stft_bands_backward_kernel(const flo
                                                                        float *__restrict__ dx, int T, int NF, int hop,
                                                                        int M) {
     extern __shared__ __attribute__((aligned(16))) unsigned char raw[];
-    LdsBwd &S = *reinterpret_cast<LdsBwd *>(raw);
+    LdsBwd<SPAN_CAP> &S = *reinterpret_cast<LdsBwd<SPAN_CAP> *>(raw);
     Lds &L = S.c;
     fill_twiddles(L);
     for (int i = threadIdx.x; i < kBins; i += kThreads) S.fbt_start[i] = fbt_start[i];
@@ -331,24 +339,37 @@ __global__ __launch_bounds__(kThreads) void stft_bands_backward_kernel(const flo
         const int fl = r * kWavesPerBlock + wave;          // local frame index
         const int f = f_base + fl;
         const bool live = f < NF;
-        frame_spectrum(xb, w, T, live ? f : NF - 1, hop, L, wave, lane);
-        // G[k] = 2 X[k] * sum_j fbt_w[k, j] dband[fbt_start[k] + j]
+        // band gradients of the frame -> LDS (needed after the FFT; the load latency hides behind it)
         const float *drow_g = dband + (b * NF + (live ? f : NF - 1)) * M;
         for (int m = lane; m < M; m += 64) S.drow[wave][m] = drow_g[m];
+        load_frame(xb, w, T, live ? f : NF - 1, hop, L.a[wave], lane);
         wave_lds_sync();
+        fft256<false>(L.a[wave], L.b[wave], L.tw, lane);
+        // X[k] from the packed transform and, in the same pass, G[k] = 2 X[k] * sum_j fbt_w[k, j] dband[fbt_start[k] + j],
+        // already scaled for the one-sided inverse: the spectrum itself is never stored
         const float *drow = S.drow[wave];
-        for (int k = lane; k < kBins; k += 64) {
+        auto grad_of_bin = [&](int k, float2 xk) {
             const int m0 = S.fbt_start[k];
             float dp = 0.0f;
             for (int j = 0; j < span_t; ++j) {
                 const int m = m0 + j;
                 if (m < M) dp = fmaf(S.fbt_w[k * span_t + j], drow[m], dp);
             }
-            const float2 z = L.xs[wave][k];
-            L.xs[wave][k] = make_float2(2.0f * z.x * dp, 2.0f * z.y * dp);
+            return one_sided_scale(make_float2(2.0f * xk.x * dp, 2.0f * xk.y * dp), k);
+        };
+        {
+            const float2 *Z = L.a[wave];
+            for (int k = lane; k < kN; k += 64) {
+                const float2 zk = Z[P(k)], zc = conjf2(Z[P((kN - k) & (kN - 1))]);
+                const float2 e = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y + zc.y));
+                const float2 d = make_float2(0.5f * (zk.x - zc.x), 0.5f * (zk.y - zc.y));
+                const float2 o = cmul(L.tw512[k], make_float2(d.y, -d.x));
+                L.xs_of(wave)[k] = grad_of_bin(k, cadd(e, o));
+            }
+            if (lane == 0) L.xs_of(wave)[kN] = grad_of_bin(kN, make_float2(Z[P(0)].x - Z[P(0)].y, 0.0f));
         }
         wave_lds_sync();
-        spectrum_grad_to_frame(L, wave, lane, w, S.dframe[fl], live);
+        spectrum_grad_to_frame<true>(L, wave, lane, w, S.dframe[fl], live);
     }
     __syncthreads();   // all frames' windowed gradients are in LDS
     overlap_add_block(S.dframe, dx + b * T, f_base, NF, hop, T);
@@ -373,7 +394,7 @@ __device__ __forceinline__ void mel_bands(const Lds &L, int wave, int lane, cons
             const int k = f0 + j;
             if (k < kBins) {
                 const float wj = fb_w[m * span + j];
-                const float2 z = L.xs[wave][k];
+                const float2 z = L.xs_of(wave)[k];
                 re = fmaf(wj, z.x, re);
                 im = fmaf(wj, z.y, im);
             }
@@ -424,7 +445,7 @@ struct LdsMelBwd {
     float stage[2][kMelMax][kFramesPerBlockBwd + 1];
 };
 
-// grid (ceil(NF / 8), B).  dout (B, 2, M, NF) -> dx (B, T), dx zeroed by the host entry point.
+// grid (ceil(NF / 4), B).  dout (B, 2, M, NF) -> dx (B, T), dx zeroed by the host entry point.
 __global__ __launch_bounds__(kThreads) void stft_mel_backward_kernel(const float *__restrict__ x, const float *__restrict__ w,
                                                                      const float *__restrict__ dout,
                                                                      const int32_t *__restrict__ fb_start,
@@ -478,10 +499,10 @@ __global__ __launch_bounds__(kThreads) void stft_mel_backward_kernel(const float
                     im = fmaf(wj, S.y[wave][m].y, im);
                 }
             }
-            L.xs[wave][k] = make_float2(re, im);
+            L.xs_of(wave)[k] = make_float2(re, im);
         }
         wave_lds_sync();
-        spectrum_grad_to_frame(L, wave, lane, w, S.dframe[fl], live);
+        spectrum_grad_to_frame<false>(L, wave, lane, w, S.dframe[fl], live);
     }
     __syncthreads();
     overlap_add_block(S.dframe, dx + b * T, f_base, NF, hop, T);
@@ -515,7 +536,8 @@ size_t advstep_stft_bands_block_count(int64_t B, int64_t NF) {
 }
 
 int advstep_stft_bands_supported(int64_t nfft, int64_t hop, int64_t T) {
-    return nfft == kNfft && hop >= 64 && hop <= kNfft && T > kN + 1;
+    // hop >= 128: the frames of one backward workgroup must advance past the overlap with its neighbour (see below)
+    return nfft == kNfft && hop >= 128 && hop <= kNfft && T > kN + 1;
 }
 
 int advstep_stft_bands_f32(const float *x, const float *window, const int32_t *fb_start, const float *fb_w, int64_t span,
@@ -546,11 +568,13 @@ int advstep_stft_bands_backward_f32(const float *x, const float *window, const f
     ensure_twiddles(st);
     if (hipMemsetAsync(dx, 0, (size_t)B * T * sizeof(float), st) != hipSuccess) return ADVSTEP_ELAUNCH;
     const dim3 grid((unsigned)ceil_div(NF, kFramesPerBlockBwd), (unsigned)B);
-    const size_t lds = sizeof(LdsBwd);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(stft_bands_backward_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(stft_bands_backward_kernel, grid, dim3(kThreads), lds, st, x, window, dband, fbt_start, fbt_w,
-                       (int)span_t, dx, (int)T, (int)NF, (int)hop, (int)M);
+    auto go = [&](auto kernel, size_t lds) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kernel, grid, dim3(kThreads), lds, st, x, window, dband, fbt_start, fbt_w, (int)span_t, dx, (int)T,
+                           (int)NF, (int)hop, (int)M);
+    };
+    if (span_t <= 2) go(stft_bands_backward_kernel<2>, sizeof(LdsBwd<2>));
+    else go(stft_bands_backward_kernel<kMaxSpanT>, sizeof(LdsBwd<kMaxSpanT>));
     return status_after_launch();
 }
 
