@@ -56,7 +56,7 @@ __device__ __forceinline__ float max_nan(float a, float b) {
 }
 
 // 256-point complex FFT of one wave's frame, radix 4, Stockham autosort: 4 stages ping-ponging between `a` and `b`
-// (float2[256] each, private to the wave).  tw[m] = exp(-2 pi i m / 256).  INV conjugates the twiddles and the
+// (float2[272] each, padded, private to the wave).  tw: the per-stage twiddle tables (see fill_twiddles).  INV conjugates the twiddles and the
 // butterfly (unnormalised inverse).  Result in `a` (4 stages = even number of swaps).  One wave-level sync per stage
 // orders this stage's writes before the next stage's reads (and, the buffers alternating, the next-but-one stage's
 // writes after this stage's reads).  `a` must be complete (and synced) on entry.
@@ -65,6 +65,7 @@ __device__ __forceinline__ float max_nan(float a, float b) {
 // all 16.  Every access to an FFT buffer goes through P().
 __device__ __forceinline__ int P(int i) { return i + (i >> 4); }
 constexpr int kNPad = kN + kN / 16;
+constexpr int kStageTw = 3 * (4 + 16 + 64);   // per-stage twiddle tables of the radix-4 stages 1..3
 
 template <bool INV>
 __device__ __forceinline__ void fft256(float2 *a, float2 *b, const float2 *__restrict__ tw, int lane) {
@@ -74,8 +75,10 @@ __device__ __forceinline__ void fft256(float2 *a, float2 *b, const float2 *__res
         const int k = lane & (Ns - 1);
         float2 v0 = a[P(lane)], v1 = a[P(lane + 64)], v2 = a[P(lane + 128)], v3 = a[P(lane + 192)];
         if (stage > 0) {
-            const int m = k * (64 >> (2 * stage));       // k * 64 / Ns
-            float2 w1 = tw[m], w2 = tw[2 * m], w3 = tw[3 * m];
+            // per-stage tables, [t - 1][k] contiguous in k: the lanes of a stage read consecutive entries (a shared
+            // 256-entry table would be read at strides of 4, 8, 12 entries in stage 2: 4- to 8-way bank conflicts)
+            const float2 *ts = tw + (stage == 1 ? 0 : (stage == 2 ? 12 : 60));
+            float2 w1 = ts[k], w2 = ts[Ns + k], w3 = ts[2 * Ns + k];
             if (INV) w1 = conjf2(w1), w2 = conjf2(w2), w3 = conjf2(w3);
             v1 = cmul(v1, w1), v2 = cmul(v2, w2), v3 = cmul(v3, w3);
         }
@@ -141,25 +144,32 @@ struct Lds {
     float2 b[kWavesPerBlock][kNPad];   // second FFT buffer; between transforms its first 257 entries hold the half spectrum
     __device__ __forceinline__ float2 *xs_of(int wave) { return b[wave]; }
     __device__ __forceinline__ const float2 *xs_of(int wave) const { return b[wave]; }
-    float2 tw[kN];       // exp(-2 pi i m / 256)
-    float2 tw512[kN];    // exp(-2 pi i k / 512)
+    float2 tw[kStageTw];  // stage s = 1, 2, 3 (Ns = 4^s): [t - 1][k] = exp(-2 pi i t k / (4 Ns)), t = 1..3, k < Ns
+    float2 tw512[kN];     // exp(-2 pi i k / 512)
     float red[kWavesPerBlock];
 };
 
-// twiddle table (device global, written once per process by the first launch): [0, 256) exp(-2 pi i m / 256),
-// [256, 512) exp(-2 pi i m / 512)
+// twiddle tables (device global, written once per process by the first launch): [0, 252) the per-stage tables,
+// [256, 512) exp(-2 pi i k / 512)
 __device__ float2 g_twiddles[2 * kN];
 
 __global__ void stft_twiddle_kernel() {
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= 2 * kN) return;
-    const double ang = m < kN ? -2.0 * M_PI * m / 256.0 : -2.0 * M_PI * (m - kN) / 512.0;
+    double ang = 0.0;
+    if (m >= kN) {
+        ang = -2.0 * M_PI * (m - kN) / 512.0;
+    } else if (m < kStageTw) {
+        const int stage = m < 12 ? 1 : (m < 60 ? 2 : 3), base = stage == 1 ? 0 : (stage == 2 ? 12 : 60), Ns = 1 << (2 * stage);
+        const int t = (m - base) / Ns + 1, k = (m - base) % Ns;
+        ang = -2.0 * M_PI * t * k / (4.0 * Ns);
+    }
     g_twiddles[m] = make_float2((float)cos(ang), (float)sin(ang));
 }
 
 __device__ __forceinline__ void fill_twiddles(Lds &L) {
     for (int m = threadIdx.x; m < kN; m += kThreads) {
-        L.tw[m] = g_twiddles[m];
+        if (m < kStageTw) L.tw[m] = g_twiddles[m];
         L.tw512[m] = g_twiddles[kN + m];
     }
 }
@@ -255,8 +265,8 @@ __device__ __forceinline__ void spectrum_grad_to_frame(Lds &L, int wave, int lan
     // z'[n] = dframe[2n] + i dframe[2n + 1]; window, park in LDS
     for (int n = lane; n < kN; n += 64) {
         const float2 z = L.a[wave][P(n)];
-        dst[2 * n] = live ? w[2 * n] * z.x : 0.0f;
-        dst[2 * n + 1] = live ? w[2 * n + 1] * z.y : 0.0f;
+        const float2 wv = reinterpret_cast<const float2 *>(w)[n];
+        reinterpret_cast<float2 *>(dst)[n] = live ? make_float2(wv.x * z.x, wv.y * z.y) : make_float2(0.0f, 0.0f);
     }
     wave_lds_sync();
 }
