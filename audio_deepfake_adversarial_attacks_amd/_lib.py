@@ -13,7 +13,7 @@ ABI_VERSION = 1
 _p, _i64, _f32, _f64, _u64, _sz = (ctypes.c_void_p, ctypes.c_int64, ctypes.c_float, ctypes.c_double,
                                    ctypes.c_uint64, ctypes.c_size_t)
 
-# name -> (restype, argtypes); one entry per symbol declared in include/advstep.h, advstep_lcnn.h, advstep_frontend.h and advstep_fab.h
+# name -> (restype, argtypes); one entry per symbol declared in include/advstep.h, advstep_lcnn.h, advstep_frontend.h, advstep_fab.h and advstep_dataset.h
 SIGNATURES = {
     "advstep_abi_version": (ctypes.c_int, []),
     "advstep_status_string": (ctypes.c_char_p, [ctypes.c_int]),
@@ -80,6 +80,10 @@ SIGNATURES = {
     "advstep_fab_projection_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, ctypes.c_int, _p]),
     "advstep_fab_combine_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _f32, _f32, _p]),
     "advstep_fab_backward_step_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _i64, _f32, ctypes.c_int, _p]),
+    # include/advstep_dataset.h
+    "advstep_wave_pad_tile_f32": (ctypes.c_int, [_p, ctypes.c_int, _p, _p, _p, _p, _i64, _i64, _p]),
+    "advstep_qual_select": (ctypes.c_int, [_p, _p, _p, _i64, _p, _p, _p]),
+    "advstep_wave_gather_rows_f32": (ctypes.c_int, [_p, _p, _p, _i64, _i64, _p]),
 }
 
 

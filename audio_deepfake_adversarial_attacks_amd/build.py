@@ -9,9 +9,10 @@ PKG = Path(__file__).resolve().parent
 ROOT = PKG.parent
 SOURCES = [PKG / "csrc" / "advstep.hip", PKG / "csrc" / "lcnn_mfm.hip", PKG / "csrc" / "lcnn_conv0.hip",
            PKG / "csrc" / "lcnn_conv1x1.hip", PKG / "csrc" / "lcnn_lstm.hip", PKG / "csrc" / "lcnn_wino.hip",
-           PKG / "csrc" / "lfcc.hip", PKG / "csrc" / "lfcc_stft.hip", PKG / "csrc" / "fab.hip"]
+           PKG / "csrc" / "lfcc.hip", PKG / "csrc" / "lfcc_stft.hip", PKG / "csrc" / "fab.hip",
+           PKG / "csrc" / "wave_prep.hip"]
 HEADERS = [ROOT / "include" / "advstep.h", ROOT / "include" / "advstep_lcnn.h", ROOT / "include" / "advstep_frontend.h",
-           ROOT / "include" / "advstep_fab.h"]
+           ROOT / "include" / "advstep_fab.h", ROOT / "include" / "advstep_dataset.h"]
 LIB = PKG / "libadvstep.so"
 
 # -ffp-contract=off: the kernels must round exactly like the reference's one-ATen-op-per-expression chains

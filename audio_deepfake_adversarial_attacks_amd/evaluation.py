@@ -25,7 +25,10 @@ from torch.utils.data import DataLoader, Dataset, Sampler
 
 from . import metrics
 from .aa import utils as aa_utils
+from .datasets.base_dataset import WAVE_FAKE_CUT, SimpleAudioFakeDataset, ragged_collate
+from .datasets.detection_dataset import DetectionDataset
 from .datasets.synthetic import SyntheticDetectionDataset
+from .datasets.wave_ops import RaggedWaveBatch
 from .utils import load_model
 
 LOGGER = logging.getLogger()
@@ -120,6 +123,16 @@ def format_report(report: Dict[str, float]) -> str:
 # the loop
 # ---------------------------------------------------------------------------------------------------------
 
+def get_dataset(datasets_paths: List[Union[str, os.PathLike, None]], amount_to_use: Optional[int],
+                raw_sample_from_dataset: bool = False, device_pad: bool = False,
+                wave_fake_trim: Optional[bool] = None) -> DetectionDataset:
+    """Reference :301-317 — the validation part of the three corpora, class-balanced, optionally reduced."""
+    return DetectionDataset(asvspoof_path=datasets_paths[0], wavefake_path=datasets_paths[1],
+                            fakeavceleb_path=datasets_paths[2], subset="val", reduced_number=amount_to_use,
+                            return_label=True, return_meta=True, return_raw=raw_sample_from_dataset,
+                            device_pad=device_pad, wave_fake_trim=wave_fake_trim)
+
+
 def generate_attacks(
     datasets_paths: List[Union[str, os.PathLike, None]],
     model_config: Dict,
@@ -135,11 +148,15 @@ def generate_attacks(
     share_weights: bool = False,
     shuffle: bool = True,
     num_workers: int = 0,
+    device_pad: bool = True,
+    wave_fake_trim: Optional[bool] = None,
 ) -> Dict[str, float]:
     """Reference signature (:146-157) plus additive keywords: `dataset` (a ready Dataset yielding the reference's
-    4-tuple; the real-corpus `DetectionDataset` is out of scope, so one must be supplied or `amount_to_use`
-    synthetic utterances are generated), `share_weights` (white-box runs without checkpoints: copy the target's
-    weights into the attack model), `shuffle`, `num_workers`.  `batch_size` is the GLOBAL batch."""
+    4-tuple; without it the `DetectionDataset` over `datasets_paths` is built as in the reference's `get_dataset`,
+    :301-317, or — with no corpus path — `amount_to_use` synthetic utterances are generated), `share_weights`
+    (white-box runs without checkpoints: copy the target's weights into the attack model), `shuffle`, `num_workers`,
+    `device_pad` (real corpora: ship undecoded payloads and pad on the device) and `wave_fake_trim` (None = the
+    reference's default, the SoX silence trim, which needs a registered backend).  `batch_size` is the GLOBAL batch."""
     rank, world = rank_and_world()
     LOGGER.info("Loading data...")
 
@@ -153,12 +170,14 @@ def generate_attacks(
     else:
         attack_model, atk = None, None
 
-    if raw_sample_from_dataset:
-        raise NotImplementedError("--raw_from_dataset needs the SoX-based WaveFake preprocessing of the real-corpus "
-                                  "dataset (src/datasets/base_dataset.py:122-148), which is outside the hot-path scope")
     if dataset is None:
-        dataset = SyntheticDetectionDataset(amount_to_use if amount_to_use else 4 * batch_size)
+        if any(p is not None for p in datasets_paths):
+            dataset = get_dataset(datasets_paths, amount_to_use, raw_sample_from_dataset, device_pad=device_pad,
+                                  wave_fake_trim=wave_fake_trim)
+        else:
+            dataset = SyntheticDetectionDataset(amount_to_use if amount_to_use else 4 * batch_size)
     data_val = dataset
+    collate_fn = ragged_collate if getattr(data_val, "device_pad", False) else None
 
     LOGGER.info(f"Testing '{model.__class__.__name__}' model, weights path: '{model.weights_path}', "
                 f"on {len(data_val)} audio files.")
@@ -170,7 +189,8 @@ def generate_attacks(
 
     seed = model_config.get("data", {}).get("seed", 42)
     sampler = ShardedBatchSampler(len(data_val), batch_size, rank, world, shuffle=shuffle, seed=seed)
-    test_loader = DataLoader(data_val, batch_sampler=sampler, num_workers=num_workers)
+    test_loader = DataLoader(data_val, batch_sampler=sampler, num_workers=num_workers, collate_fn=collate_fn,
+                             pin_memory=collate_fn is not None)
     if world > 1:
         # decorrelate the random starts of different ranks (all ranks were seeded alike to build equal replicas)
         torch.manual_seed(seed + rank)
@@ -181,7 +201,11 @@ def generate_attacks(
 
     for batch_x, batch_sr, batch_y, batch_metadata in test_loader:
         model.eval()
-        batch_x = batch_x.to(device, non_blocking=True)
+        if isinstance(batch_x, RaggedWaveBatch):
+            # device_pad datasets: the file payloads go up as they are; decode + first channel + pad/tile on the device
+            batch_x = batch_x.to_padded(device, WAVE_FAKE_CUT)
+        else:
+            batch_x = batch_x.to(device, non_blocking=True)
         batch_y = batch_y.to(device, non_blocking=True)
         num_total += batch_x.size(0)
 
@@ -189,12 +213,19 @@ def generate_attacks(
             batch_x_attacked = attack_batch(atk, batch_x, batch_y)
         else:
             batch_x_attacked = torch.clone(batch_x)
+        batch_x_noproc, batch_x_attacked_noproc = batch_x, batch_x_attacked  # :223-224 (nothing below writes in place)
 
+        if raw_sample_from_dataset:  # :229-234 — the dataset's default preprocessing, after the attack
+            batch_x_attacked, _ = SimpleAudioFakeDataset.wavefake_preprocessing_on_batch(
+                batch_x_attacked, batch_sr, wave_fake_trim=wave_fake_trim)
         batch_preds, batch_preds_label = score_batch(model, batch_x_attacked)
 
         if on_attack_end_callback is not None:  # :240-259
+            if raw_sample_from_dataset:
+                batch_x, _ = SimpleAudioFakeDataset.wavefake_preprocessing_on_batch(
+                    batch_x, batch_sr, wave_fake_trim=wave_fake_trim)
             batch_preds_noattack, batch_preds_noattack_label = score_batch(model, batch_x)
-            on_attack_end_callback(batch_x=batch_x, batch_x_attacked=batch_x_attacked, batch_y=batch_y,
+            on_attack_end_callback(batch_x=batch_x_noproc, batch_x_attacked=batch_x_attacked_noproc, batch_y=batch_y,
                                    batch_preds_label=batch_preds_label, batch_preds=batch_preds,
                                    batch_preds_noattack_label=batch_preds_noattack_label,
                                    batch_preds_noattack=batch_preds_noattack, batch_metadata=batch_metadata)

@@ -46,3 +46,10 @@ def load_model(model_config, device: str = "cuda"):
     model = model.to(device)
     model.weights_path = model_path
     return model
+
+
+def find_wav_files(path_to_dir):
+    """All *.wav files below a directory, sorted; None when there are none (src/utils.py:18-30)."""
+    from pathlib import Path
+    paths = sorted(Path(path_to_dir).glob("**/*.wav"))
+    return paths or None

@@ -3,8 +3,8 @@
 (evaluate_models_on_adversarial_attacks.py:38-143): same flags, same YAML schema, same final log line.
 
 Additive flags (defaults keep the reference behaviour): --batch_size (the reference hard-codes 64, :154),
---synthetic N (seeded synthetic utterances; the real-corpus datasets are outside the hot-path scope),
---share_weights (white-box runs with random-init models).  Multi-GPU: launch one process per GPU, e.g.
+--synthetic N (seeded synthetic utterances instead of the corpora), --no_trim (real corpora without the SoX silence
+trim, which needs a registered backend), --num_workers, --share_weights (white-box runs with random-init models).  Multi-GPU: launch one process per GPU, e.g.
 `python -m torch.distributed.run --nproc-per-node 8 evaluate_models_on_adversarial_attacks.py ...`;
 each rank attacks a contiguous slice of every global batch and only the final scores cross xGMI (RCCL).
 
@@ -21,6 +21,7 @@ import torch.distributed as dist
 import yaml
 
 from audio_deepfake_adversarial_attacks_amd.aa.aa_types import AttackEnum
+from audio_deepfake_adversarial_attacks_amd.aa.qualitative.attacks_analysis import AttackAnalyser
 from audio_deepfake_adversarial_attacks_amd.datasets.synthetic import SyntheticDetectionDataset
 from audio_deepfake_adversarial_attacks_amd.evaluation import generate_attacks
 from audio_deepfake_adversarial_attacks_amd.utils import set_seed
@@ -60,6 +61,10 @@ def parse_arguments(argv=None):
     parser.add_argument("--batch_size", type=int, default=64, help="GLOBAL batch size (reference: fixed 64)")
     parser.add_argument("--synthetic", type=int, default=None, metavar="N",
                         help="evaluate on N seeded synthetic 64 600-sample utterances")
+    parser.add_argument("--no_trim", default=False, action="store_true",
+                        help="real corpora: skip the SoX silence trim (SoX is not part of this build; without this "
+                             "flag a backend must be registered, datasets/base_dataset.py)")
+    parser.add_argument("--num_workers", type=int, default=3, help="DataLoader workers (reference :202: 3)")
     parser.add_argument("--share_weights", default=False, action="store_true",
                         help="copy the target model's weights into the attack model (white-box, no checkpoints)")
     return parser.parse_args(argv)
@@ -86,10 +91,16 @@ def main(args):
 
     set_seed(config["data"].get("seed", 42))
     attack_method, attack_params = AttackEnum[args.attack].value
-    if args.qual:
-        raise SystemExit("--qual (AttackAnalyser WAV dumps) is outside the hot-path scope of this build")
-    if args.synthetic is None:
-        raise SystemExit("real-corpus loading (DetectionDataset) is outside the hot-path scope: pass --synthetic N")
+    on_attack_end_callback = None
+    if args.qual:  # reference :126-129
+        if args.attack_model_config is None:
+            raise SystemExit("--qual names its folder after the attack model: pass --attack_model_config")
+        results_folder = f"attack_{args.attack}_{Path(args.attack_model_config).stem}_on_{Path(args.config).stem}"
+        attack_analyser = AttackAnalyser(Path("qualitative_results") / results_folder)
+        on_attack_end_callback = attack_analyser.analyse
+    corpora = [args.asv_path, args.wavefake_path, args.celeb_path]
+    if args.synthetic is None and all(p is None for p in corpora):
+        raise SystemExit("no data: pass --asv_path / --wavefake_path / --celeb_path, or --synthetic N")
 
     report = generate_attacks(
         datasets_paths=[args.asv_path, args.wavefake_path, args.celeb_path],
@@ -100,10 +111,12 @@ def main(args):
         amount_to_use=args.amount,
         batch_size=args.batch_size,
         device=device,
-        on_attack_end_callback=None,
+        on_attack_end_callback=on_attack_end_callback,
         raw_sample_from_dataset=args.raw_from_dataset,
-        dataset=SyntheticDetectionDataset(args.synthetic),
+        dataset=SyntheticDetectionDataset(args.synthetic) if args.synthetic is not None else None,
         share_weights=args.share_weights,
+        wave_fake_trim=False if args.no_trim else None,
+        num_workers=args.num_workers,
     )
     if world > 1:
         dist.destroy_process_group()

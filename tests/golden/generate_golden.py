@@ -490,6 +490,107 @@ def gen_model_bodies():
     np.savez_compressed(OUT / "specrnet_body.npz", **out)
 
 
+def gen_datasets():
+    """PadDataset.apply_pad, wavefake_preprocessing_on_batch (SoX steps off), the corpus
+    listings of DetectionDataset on the miniature corpora of tests/helpers.build_corpus_trees, and AttackAnalyser's
+    files.  `src.datasets.base_dataset` imports soundfile and torchaudio (absent): inert module objects stand in for
+    them — none of the recorded functions calls into either."""
+    import hashlib
+    import json
+    import tempfile
+
+    sys.path.insert(0, str(OUT.parent))
+    import helpers
+
+    ta = sys.modules.get("torchaudio") or _inert_torchaudio()
+    ta.functional = types.ModuleType("torchaudio.functional")
+    ta.functional.apply_codec = None
+    sys.modules["torchaudio"] = ta
+    sys.modules["torchaudio.functional"] = ta.functional
+    sys.modules.setdefault("soundfile", types.ModuleType("soundfile"))
+    if "asteroid_filterbanks" not in sys.modules:  # src.utils -> src.models.rawnet3 imports it; nothing recorded uses it
+        afb = types.ModuleType("asteroid_filterbanks")
+        afb.Encoder = afb.ParamSincFB = None
+        sys.modules["asteroid_filterbanks"] = afb
+    import typing
+    import torch.utils.data.dataset as tud
+    if not hasattr(tud, "T_co"):  # a type-annotation name torch 2.10 no longer exports (base_dataset.py:14,150)
+        tud.T_co = typing.TypeVar("T_co", covariant=True)
+    from src.datasets import base_dataset as ref_base
+    from src.datasets.detection_dataset import DetectionDataset as RefDetectionDataset
+    from src.aa.qualitative.attacks_analysis import AttackAnalyser as RefAnalyser
+
+    out = {}
+    # --- apply_pad: (length, cut) pairs incl. exact multiples, one sample, longer than the cut
+    g = torch.Generator().manual_seed(81)
+    cases = [(1, 10), (7, 64), (64, 64), (65, 64), (100, 4099), (4099, 4099), (32300, 64600), (64599, 64600),
+             (70000, 64600), (21533, 64600)]
+    out["pad_cases"] = np.array(cases, dtype=np.int64)
+    for k, (n, cut) in enumerate(cases):
+        w = (torch.arange(n).remainder(997).float() / 997.0 - 0.5).unsqueeze(0)  # a ramp: compresses well
+        out[f"pad_in_{k}"] = npy(w)
+        out[f"pad_out_{k}"] = npy(ref_base.PadDataset.apply_pad(w, cut))
+    # --- wavefake_preprocessing_on_batch with every SoX step off
+    batch = torch.randn(5, 1000, generator=g)
+    rates = torch.full((5,), 16_000, dtype=torch.int64)
+    for name, cut in (("short", 2600), ("long", 640)):
+        got, got_rates = ref_base.SimpleAudioFakeDataset.wavefake_preprocessing_on_batch(
+            batch, rates, wave_fake_trim=False, wave_fake_cut=cut)
+        out[f"onbatch_{name}_out"], out[f"onbatch_{name}_rates"] = npy(got), npy(got_rates)
+    out["onbatch_in"] = npy(batch)
+    # --- AttackAnalyser
+    B, T = 14, 800
+    x = torch.randn(B, T, generator=g) * 0.1
+    xa = x + torch.randn(B, T, generator=g) * 0.01
+    y = torch.tensor([0, 0, 1, 1, 0, 1, 0, 1, 1, 0, 0, 1, 0, 1])
+    clean = torch.tensor([0, 1, 1, 0, 0, 1, 0, 1, 1, 0, 1, 1, 0, 0], dtype=torch.int32)
+    attacked = torch.tensor([1, 1, 0, 0, 0, 0, 1, 1, 0, 0, 0, 1, 1, 1], dtype=torch.int32)
+    paths = [f"/data/WaveFake/generated_audio/ljspeech_melgan/LJ001-{i:04d}_gen.wav" if i % 3 == 0 else
+             f"/data/FakeAVCeleb_v1.2/FakeAVCeleb-audio/RealVideo-RealAudio/African/men/id{i:05d}/{i:05d}.mp3" if i % 3 == 1
+             else f"/data/ASVspoof2021/DF/ASVspoof2021_DF_eval_part00/ASVspoof2021_DF_eval/flac/DF_E_{2000000 + i}.flac"
+             for i in range(B)]
+    seconds = torch.tensor([1.0 + 0.377 * i for i in range(B)], dtype=torch.float64)
+    metadata = [["melgan"] * B, paths, ["val"] * B, seconds]  # what default_collate makes of B metadata tuples
+    with tempfile.TemporaryDirectory() as tmp, contextlib.redirect_stdout(None):
+        RefAnalyser(tmp).analyse(batch_x=x, batch_x_attacked=xa, batch_y=y, batch_preds_label=attacked,
+                                 batch_preds=torch.rand(B), batch_preds_noattack_label=clean,
+                                 batch_preds_noattack=torch.rand(B), batch_metadata=metadata)
+        files = {p.name: p.read_bytes() for p in sorted(Path(tmp).iterdir())}
+    out.update({"qual_x": npy(x), "qual_xa": npy(xa), "qual_y": npy(y), "qual_clean": npy(clean),
+                "qual_attacked": npy(attacked), "qual_seconds": npy(seconds)})
+    first = sorted(files)[0]
+    out["qual_first_file"] = np.frombuffer(files[first], dtype=np.uint8)
+    np.savez_compressed(OUT / "datasets.npz", **out)
+
+    # --- corpus listings
+    listing = {"qual_paths": paths, "qual_files": {n: hashlib.sha256(b).hexdigest() for n, b in files.items()},
+               "qual_first_file": first, "listings": {}}
+    # FakeAVCelebDataset.get_fake_samples hands split_samples a list of (index, Series) pairs, and base_dataset.py:66
+    # passes it to np.split, which numpy <= 1.23 (the reference's pin) turned into an (n, 2) object array cut along axis
+    # 0.  numpy >= 1.24 refuses to build that ragged array, so for such a list the cut is made on the list itself with
+    # the same indices — the rows numpy <= 1.23 returned.
+    real_split = np.split
+
+    def split_lists_too(ary, indices, axis=0):
+        if isinstance(ary, list) and ary and isinstance(ary[0], tuple):
+            bounds = [0, *indices, len(ary)]
+            return [ary[lo:hi] for lo, hi in zip(bounds[:-1], bounds[1:])]
+        return real_split(ary, indices, axis)
+
+    ref_base.np.split = split_lists_too
+    with tempfile.TemporaryDirectory() as tmp:
+        roots = helpers.build_corpus_trees(tmp)
+        for subset in ("train", "test", "val"):
+            for name, kw in (("plain", dict(oversample=False)), ("oversample", dict(oversample=True)),
+                             ("undersample", dict(oversample=False, undersample=True)),
+                             ("reduced", dict(oversample=True, reduced_number=17))):
+                np.random.seed(5)  # oversampling draws from numpy's global RNG
+                ds = RefDetectionDataset(subset=subset, **{k: str(v) for k, v in roots.items()}, **kw)
+                listing["listings"][f"{subset}/{name}"] = helpers.listing_of(ds.samples, tmp)
+    ref_base.np.split = real_split
+    (OUT / "datasets_listing.json").write_text(json.dumps(listing, indent=0))
+
+
 def main():
     _import_reference()
     torch.set_num_threads(1)  # fixed thread count: the reference is bit-reproducible at a fixed thread count
@@ -507,6 +608,7 @@ def main():
     gen_trainer()
     gen_metrics()
     gen_model_bodies()
+    gen_datasets()
     for p in sorted(OUT.glob("*.npz")):
         print(f"{p.name}: {p.stat().st_size / 1e6:.2f} MB")
 

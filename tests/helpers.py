@@ -66,3 +66,98 @@ class TinyDetectionSet(torch.utils.data.Dataset):
 
     def __getitem__(self, i):
         return self.x[i], 16_000, int(self.y[i])
+
+
+# ---------------------------------------------------------------------------------------------------------
+# a miniature copy of the three corpora's directory layouts
+# ---------------------------------------------------------------------------------------------------------
+
+def _write_wav(path, data, rate):
+    """Minimal PCM16 / float32 WAVE writer for the test corpora (independent of the product's reader/writer)."""
+    import struct
+    data = np.ascontiguousarray(data)
+    channels = 1 if data.ndim == 1 else data.shape[1]
+    code, width = (1, 2) if data.dtype == np.int16 else (3, 4)
+    fmt = struct.pack("<HHIIHH", code, channels, rate, rate * width * channels, width * channels, 8 * width)
+    body = b"WAVE" + b"fmt " + struct.pack("<I", len(fmt)) + fmt + b"data" + struct.pack("<I", data.nbytes) + data.tobytes()
+    path.write_bytes(b"RIFF" + struct.pack("<I", len(body)) + body)
+
+
+def corpus_waveform(index: int):
+    """Deterministic content of the index-th WaveFake wav file: (samples, rate); every third file is stereo, every
+    fourth float32, lengths 150..2600 frames."""
+    rng = np.random.default_rng(1000 + index)
+    frames = 150 + (index * 397) % 2451
+    shape = (frames, 2) if index % 3 == 2 else (frames,)
+    if index % 4 == 3:
+        return (rng.standard_normal(shape) * 0.1).astype(np.float32), 16_000
+    return rng.integers(-20000, 20000, shape).astype(np.int16), 16_000
+
+
+def build_corpus_trees(root):
+    """Create <root>/ASVspoof2021/DF, <root>/WaveFake, <root>/FakeAVCeleb_v1.2 with the layouts the dataset classes
+    parse.  FLAC / MP3 files are empty placeholders (listing needs existence only); WaveFake wav files are real."""
+    from pathlib import Path
+    root = Path(root)
+    asv = root / "ASVspoof2021" / "DF"
+    (asv / "keys" / "CM").mkdir(parents=True)
+    lines = []
+    for i in range(46):
+        name = f"DF_E_{2000011 + 37 * i}"
+        label = "bonafide" if i % 4 == 1 else "spoof"
+        part = f"part0{i % 4}"
+        folder = asv / f"ASVspoof2021_DF_eval_{part}" / "ASVspoof2021_DF_eval" / "flac"
+        folder.mkdir(parents=True, exist_ok=True)
+        (folder / f"{name}.flac").touch()
+        attack = "-" if label == "bonafide" else f"A{7 + i % 13:02d}"
+        lines.append(f"LA_{i:04d} {name} nocodec asvspoof {attack} {label} notrim eval")
+    (asv / "keys" / "CM" / "trial_metadata.txt").write_text("\n".join(lines) + "\n")
+
+    wf = root / "WaveFake"
+    index = 0
+    folders = ["ljspeech_melgan", "ljspeech_hifiGAN", "jsut_multi_band_melgan", "ljspeech_full_band_melgan",
+               "ljspeech_unknownvoc", "common_voices_prompts_from_conformer_fastspeech2_pwg_ljspeech"]
+    for folder in folders:
+        d = wf / "generated_audio" / folder
+        d.mkdir(parents=True)
+        for k in range(9):
+            stem = f"BASIC5000_{k + 1:04d}" if folder.startswith("jsut") else f"LJ{1 + k // 5:03d}-{1 + k % 5:04d}"
+            _write_wav(d / f"{stem}_gen.wav", *corpus_waveform(index))
+            index += 1
+    for folder, stems in (("real_audio/jsut_ver1.1/basic5000/wav", [f"BASIC5000_{k + 1:04d}" for k in range(11)]),
+                          ("real_audio/LJSpeech-1.1/wavs", [f"LJ{1 + k // 5:03d}-{1 + k % 5:04d}" for k in range(13)])):
+        d = wf / folder
+        d.mkdir(parents=True)
+        for stem in stems:
+            _write_wav(d / f"{stem}.wav", *corpus_waveform(index))
+            index += 1
+
+    celeb = root / "FakeAVCeleb_v1.2"
+    audio = celeb / "FakeAVCeleb-audio"
+    audio.mkdir(parents=True)
+    rows = ["source,target1,target2,method,category,type,race,gender,filename,path"]
+    methods = ["real", "rtvc", "wav2lip", "faceswap-wav2lip", "fsgan-wav2lip", "faceswap"]
+    for i in range(60):
+        method = methods[i % len(methods)]
+        kind = "RealVideo-RealAudio" if method == "real" else (
+            "RealVideo-FakeAudio" if method == "rtvc" else ("FakeVideo-FakeAudio" if i % 2 else "FakeVideo-RealAudio"))
+        source = f"id{100 + i // 3:05d}"
+        rel = f"FakeAVCeleb/{kind}/African/men/{source}"
+        filename = f"{i:05d}_{method}.mp4"
+        rows.append(f"{source},-,-,{method},A,{kind},African,men,{filename},{rel}")
+        d = audio / kind / "African" / "men" / source
+        d.mkdir(parents=True, exist_ok=True)
+        (d / filename).with_suffix(".mp3").touch()
+    (audio / "meta_data.csv").write_text("\n".join(rows) + "\n")
+    return {"asvspoof_path": asv, "wavefake_path": wf, "fakeavceleb_path": celeb}
+
+
+def listing_of(samples, root):
+    """A dataset's `samples` frame as JSON-able rows with paths relative to the corpus root."""
+    from pathlib import Path
+    rows = []
+    for _, r in samples.iterrows():
+        attack = r["attack_type"] if "attack_type" in r else None
+        rows.append([str(Path(r["path"]).relative_to(root)), r["label"],
+                     attack if isinstance(attack, str) else None, r["sample_name"]])
+    return rows
