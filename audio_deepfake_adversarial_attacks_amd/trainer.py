@@ -38,6 +38,8 @@ import torch.distributed as dist
 from torch.utils.data import DataLoader
 
 from .aa.aa_types import AttackEnum
+from .datasets.base_dataset import WAVE_FAKE_CUT, ragged_collate
+from .datasets.wave_ops import RaggedWaveBatch
 from .evaluation import ShardedBatchSampler, rank_and_world
 
 LOGGER = logging.getLogger(__name__)
@@ -63,6 +65,7 @@ class Trainer:
     """Lightweight wrapper storing the training set-up (src/trainer.py:36-67)."""
 
     loader_workers = 0      # the reference forks 6 DataLoader workers to decode audio; tensors already in memory need none
+    corpus_loader_workers = 6   # ... audio files on disk do (src/trainer.py:154,162)
     attack_ops = None       # test seam: op table handed to every attack (None = the HIP kernels)
 
     def __init__(self, epochs: int = 20, batch_size: int = 32, device: str = "cpu",
@@ -84,14 +87,26 @@ class Trainer:
         n_test = int(len(dataset) * test_len)
         return torch.utils.data.random_split(dataset, [len(dataset) - n_test, n_test])
 
+    def _upload(self, batch_x):
+        """Batch to the device; `device_pad` corpora (datasets/base_dataset.py) arrive as undecoded payloads and are
+        decoded + padded there."""
+        if isinstance(batch_x, RaggedWaveBatch):
+            return batch_x.to_padded(self.device, WAVE_FAKE_CUT)
+        return batch_x.to(self.device)
+
     def _loader(self, data, epoch_seed: int) -> DataLoader:
         """Single process: the reference's DataLoader(shuffle=True, drop_last=True).  Distributed: this rank's
         contiguous shard of every global batch of `batch_size`, permutation shared through the seed."""
         rank, world = rank_and_world()
+        base = data.dataset if isinstance(data, torch.utils.data.Subset) else data
+        extra, workers = {}, self.loader_workers
+        if getattr(base, "device_pad", False):  # audio files: decode in workers (reference: 6), pad on the device
+            extra = dict(collate_fn=ragged_collate, pin_memory=True)
+            workers = self.loader_workers or self.corpus_loader_workers
         if world == 1:
-            return DataLoader(data, batch_size=self.batch_size, shuffle=True, drop_last=True, num_workers=self.loader_workers)
+            return DataLoader(data, batch_size=self.batch_size, shuffle=True, drop_last=True, num_workers=workers, **extra)
         sampler = ShardedBatchSampler(len(data), self.batch_size, rank, world, shuffle=True, seed=epoch_seed)
-        return DataLoader(data, batch_sampler=sampler, num_workers=self.loader_workers)
+        return DataLoader(data, batch_sampler=sampler, num_workers=workers, **extra)
 
     @staticmethod
     def _sum_over_ranks(*values: float) -> List[float]:
@@ -195,7 +210,7 @@ class AdversarialGDTrainer(Trainer):
             for i, (batch_x, _, batch_y) in enumerate(train_loader):
                 batch_size = batch_x.size(0)
                 num_total += batch_size
-                batch_x = batch_x.to(self.device)
+                batch_x = self._upload(batch_x)
                 if adversarial:
                     batch_x = self.apply_adv_attack(batch_x, batch_y).detach()
                 batch_y = batch_y.unsqueeze(1).type(torch.float32).to(self.device)
@@ -269,7 +284,7 @@ class AdversarialGDTrainer(Trainer):
         for batch_x, _, batch_y in test_loader:
             batch_size = batch_x.size(0)
             num_total += batch_size
-            batch_x = batch_x.to(self.device)
+            batch_x = self._upload(batch_x)
             if attack:
                 batch_x = self._attack_batch(attack, batch_x, batch_y)
             batch_y = batch_y.unsqueeze(1).type(torch.float32).to(self.device)

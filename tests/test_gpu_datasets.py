@@ -194,3 +194,25 @@ def test_real_wav_corpus_end_to_end(cuda, tmp_path, capsys):
 def audio_io_load(path):
     from audio_deepfake_adversarial_attacks_amd.datasets import audio_io
     return audio_io.load(path)
+
+
+def test_training_cli_on_a_wav_corpus(cuda, tmp_path):
+    """The second caller of the attack API fed from audio files: train / test parts of a WaveFake-layout corpus, payloads
+    decoded in DataLoader workers, padded on the device."""
+    import yaml
+
+    import train_models_on_adversarial_attacks as cli
+    roots = helpers.build_corpus_trees(tmp_path / "data")
+    with open("configs/aa_training/finetune/lcnn_fgsm.yaml") as f:
+        cfg = yaml.safe_load(f)
+    cfg["data"]["adversarial_attacks"] = ["FGSM_eps001"]
+    cfg["checkpoint"]["path"] = ""
+    (tmp_path / "one.yaml").write_text(yaml.dump(cfg))
+    args = cli.parse_args(["--config", str(tmp_path / "one.yaml"), "--wavefake_path", str(roots["wavefake_path"]),
+                           "--no_trim", "--batch_size", "8", "--epochs", "1", "--ckpt", str(tmp_path / "ckpt"),
+                           "--config_save_path", str(tmp_path), "--adv_training_strategy", "EQUAL"])
+    model = cli.main(args)
+    saved = list((tmp_path / "ckpt").glob("aad__lcnn_*/ckpt*.pth"))
+    assert len(saved) == 2
+    state = torch.load(saved[0], map_location="cpu")
+    assert all(torch.isfinite(v).all() for v in state.values() if v.dtype.is_floating_point)

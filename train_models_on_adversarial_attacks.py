@@ -3,8 +3,8 @@
 (train_models_on_adversarial_attacks.py:50-294): same flags, same YAML schema (`data.adversarial_attacks`,
 `model.optimizer`, `checkpoint.path`), same strategy names, same checkpoint / test-config outputs.
 
-Additive: --synthetic N_TRAIN,N_TEST (seeded synthetic utterances; the real-corpus DetectionDataset is outside the
-hot-path scope of this build).  Multi-GPU: one process per GPU,
+Additive: --synthetic N_TRAIN,N_TEST (seeded synthetic utterances instead of the corpora), --no_trim (corpora without
+the SoX silence trim, which needs a registered backend).  Multi-GPU: one process per GPU,
 `python -m torch.distributed.run --nproc-per-node 8 train_models_on_adversarial_attacks.py ...` — the model is wrapped in
 DistributedDataParallel (bucketed gradient all-reduce over RCCL, overlapped with backward) instead of the reference's
 nn.DataParallel (:100, :110), --batch_size is the GLOBAL batch, every rank attacks and trains on its contiguous shard."""
@@ -21,6 +21,7 @@ import torch.distributed as dist
 import yaml
 
 from audio_deepfake_adversarial_attacks_amd.aa.aa_trainer_types import AdversarialGDTrainerEnum
+from audio_deepfake_adversarial_attacks_amd.datasets.detection_dataset import DetectionDataset
 from audio_deepfake_adversarial_attacks_amd.datasets.synthetic import SyntheticDetectionDataset
 from audio_deepfake_adversarial_attacks_amd.models import models
 from audio_deepfake_adversarial_attacks_amd.trainer import save_model
@@ -33,20 +34,29 @@ _handler.setFormatter(logging.Formatter("%(asctime)s - %(levelname)s - %(message
 LOGGER.addHandler(_handler)
 
 
-def get_datasets(amount_to_use: Tuple[int, int], synthetic: Optional[Tuple[int, int]]):
-    if synthetic is None:
-        raise SystemExit("real-corpus loading (DetectionDataset) is outside the hot-path scope: pass --synthetic N_TRAIN,N_TEST")
-    n_train = min(synthetic[0], amount_to_use[0]) if amount_to_use[0] else synthetic[0]
-    n_test = min(synthetic[1], amount_to_use[1]) if amount_to_use[1] else synthetic[1]
-    return (SyntheticDetectionDataset(n_train, seed=1234, return_meta=False),
-            SyntheticDetectionDataset(n_test, seed=4321, return_meta=False))
+def get_datasets(datasets_paths: List[Optional[str]], amount_to_use: Tuple[int, int],
+                 synthetic: Optional[Tuple[int, int]] = None, wave_fake_trim: Optional[bool] = None):
+    """train_models_on_adversarial_attacks.py:27-48 — the train / test parts of the three corpora, class-balanced;
+    `--synthetic` replaces them with seeded noise."""
+    if synthetic is not None:
+        n_train = min(synthetic[0], amount_to_use[0]) if amount_to_use[0] else synthetic[0]
+        n_test = min(synthetic[1], amount_to_use[1]) if amount_to_use[1] else synthetic[1]
+        return (SyntheticDetectionDataset(n_train, seed=1234, return_meta=False),
+                SyntheticDetectionDataset(n_test, seed=4321, return_meta=False))
+    if all(p is None for p in datasets_paths):
+        raise SystemExit("no data: pass --asv_path / --wavefake_path / --celeb_path, or --synthetic N_TRAIN,N_TEST")
+    common = dict(asvspoof_path=datasets_paths[0], wavefake_path=datasets_paths[1], fakeavceleb_path=datasets_paths[2],
+                  oversample=True, device_pad=True, wave_fake_trim=wave_fake_trim)
+    return (DetectionDataset(subset="train", reduced_number=amount_to_use[0], **common),
+            DetectionDataset(subset="test", reduced_number=amount_to_use[1], **common))
 
 
 def train_nn(batch_size: int, epochs: int, device: str, config: Dict, attack_config: Optional[Dict],
              adversarial_attacks: List[str], model_dir: Optional[Path] = None,
              amount_to_use: Tuple[int, int] = (None, None), config_save_path: str = "configs",
              adv_training_strategy: str = AdversarialGDTrainerEnum.RANDOM.name, is_finetune: bool = False,
-             synthetic: Optional[Tuple[int, int]] = None):
+             synthetic: Optional[Tuple[int, int]] = None, datasets_paths: List[Optional[str]] = (None, None, None),
+             wave_fake_trim: Optional[bool] = None):
     """train_models_on_adversarial_attacks.py:50-160."""
     model_config = config["model"]
     model_name = model_config["name"]
@@ -55,7 +65,7 @@ def train_nn(batch_size: int, epochs: int, device: str, config: Dict, attack_con
     LOGGER.info("Loading data...")
     timestamp = time.time()
     checkpoint_paths = []
-    data_train, data_test = get_datasets(amount_to_use, synthetic)
+    data_train, data_test = get_datasets(list(datasets_paths), amount_to_use, synthetic, wave_fake_trim)
 
     current_model = models.get_model(model_name=model_name, config=model_config["parameters"], device=device)
     if is_finetune:
@@ -129,14 +139,15 @@ def main(args):
              epochs=args.epochs, model_dir=model_dir, config=config, attack_config=attack_model_config,
              adversarial_attacks=config["data"].get("adversarial_attacks", []),
              adv_training_strategy=args.adv_training_strategy, is_finetune=args.finetune, synthetic=synthetic,
-             config_save_path=args.config_save_path)
+             config_save_path=args.config_save_path,
+             datasets_paths=[args.asv_path, args.wavefake_path, args.celeb_path],
+             wave_fake_trim=False if args.no_trim else None)
     if world > 1:
         dist.destroy_process_group()
 
 
 def parse_args(argv=None):
     parser = argparse.ArgumentParser()
-    # dataset roots: accepted for command-line compatibility; only --synthetic data is supported by this build
     parser.add_argument("--asv_path", type=str, default=None, help="Path to ASVspoof2021 dataset directory")
     parser.add_argument("--wavefake_path", type=str, default=None, help="Path to WaveFake dataset directory")
     parser.add_argument("--celeb_path", type=str, default=None, help="Path to FakeAVCeleb dataset directory")
@@ -155,6 +166,8 @@ def parse_args(argv=None):
     # additive
     parser.add_argument("--synthetic", type=str, default=None, metavar="N_TRAIN,N_TEST",
                         help="train / test on seeded synthetic 64 600-sample utterances")
+    parser.add_argument("--no_trim", default=False, action="store_true",
+                        help="real corpora: skip the SoX silence trim (needs a registered backend otherwise)")
     parser.add_argument("--config_save_path", type=str, default="configs", help="where the test config is written")
     return parser.parse_args(argv)
 
