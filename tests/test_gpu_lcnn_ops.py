@@ -155,8 +155,9 @@ def ref_block0(x, weight, bias):
     return ref_mfm_pool(torch.nn.functional.conv2d(x, weight, bias, stride=1, padding=2))
 
 
-@pytest.mark.parametrize("shape", [(2, 1, 12, 16), (3, 1, 9, 7), (1, 1, 2, 2), (2, 1, 101, 20), (4, 1, 404, 80), (2, 1, 5, 33)])
-@pytest.mark.parametrize("C,with_bias", [(32, True), (3, False), (8, True)])
+@pytest.mark.parametrize("shape", [(2, 1, 12, 16), (3, 1, 9, 7), (1, 1, 2, 2), (2, 1, 101, 20), (4, 1, 404, 80), (2, 1, 5, 33),
+                                   (3, 1, 14, 70), (2, 1, 9, 64), (5, 1, 11, 79), (1, 1, 2, 80), (37, 1, 6, 66)])
+@pytest.mark.parametrize("C,with_bias", [(32, True), (3, False), (8, True), (32, False)])
 def test_conv5_mfm_pool2_matches_float64_reference(L, cuda, shape, C, with_bias):
     g = torch.Generator().manual_seed(shape[2] * 131 + shape[3] + C)
     x = torch.randn(shape, generator=g).to(cuda)
