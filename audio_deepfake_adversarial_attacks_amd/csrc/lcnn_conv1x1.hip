@@ -40,7 +40,8 @@ __device__ __forceinline__ int mfma_row(int r, int lane) { return (r & 3) + 8 * 
 
 // grid (ceil(P / 128), N).  TILES = ceil(C / 32) channel tiles per half.
 // LDS: w_s[2 * TILES * 32][CIN + 1]; rows [0, 32 TILES) = first half (zero beyond C), rows [32 TILES, 64 TILES) = second.
-template <int CIN, int TILES>
+// FULL: C == 32 TILES (no accumulator row beyond C): the row-liveness branches of the epilogue compile away.
+template <int CIN, int TILES, bool FULL>
 __global__ __launch_bounds__(kBlock) void conv1x1_mfm_forward_kernel(const float *__restrict__ x,
                                                                      const float *__restrict__ weight,
                                                                      const float *__restrict__ bias,
@@ -73,13 +74,26 @@ __global__ __launch_bounds__(kBlock) void conv1x1_mfm_forward_kernel(const float
     if (wave_p0 >= P) return;  // wave-uniform: no pixel of this wave exists
     const int64_t p = wave_p0 + li;
     const bool valid = p < P;
-    const float *xbase = x + n * CIN * P;
+    // Addressing is 32-bit and mostly scalar: one buffer descriptor per tensor of this sample, a per-lane byte offset
+    // (row 4 lk or lk, pixel p — fixed for the whole kernel) and a wave-uniform row offset in an SGPR.  An out-of-range
+    // pixel gets an out-of-range lane offset (loads return 0, stores are dropped).  (64-bit pointer arithmetic per access cost ~300 of this kernel's ~570 VALU
+    // instructions, and VALU time adds to matrix time on this part: DESIGN.md section 4f.)
+    const uint32_t Pb = (uint32_t)P * 4u, PWb = (uint32_t)PW * 4u;
+    const __amdgpu_buffer_rsrc_t xr =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x + n * CIN * P), 0, (int)(CIN * Pb), 0x00020000);
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(y + n * (int64_t)C * P, 0, (int)(C * Pb), 0x00020000);
+    const __amdgpu_buffer_rsrc_t sr =
+        __builtin_amdgcn_make_buffer_rsrc(sel + n * (int64_t)C * PW, 0, (int)(C * PWb), 0x00020000);
+    constexpr uint32_t kOut = 0x80000000u;
+    const uint32_t pb = (uint32_t)p * 4u;
+    const uint32_t x_off = valid ? (uint32_t)lk * Pb + pb : kOut;                          // row lk, pixel p
+    const uint32_t y_off = valid ? 4u * (uint32_t)lk * Pb + pb : kOut;                     // row 4 lk, pixel p
+    const uint32_t s_off = li == 0 ? 4u * (uint32_t)lk * PWb + (uint32_t)(p >> 5) * 4u : kOut;  // one lane per half stores
     float xb[CIN / 2];
 #pragma unroll
-    for (int s = 0; s < CIN / 2; ++s) xb[s] = valid ? xbase[(int64_t)(2 * s + lk) * P + p] : 0.0f;
+    for (int s = 0; s < CIN / 2; ++s)
+        xb[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, x_off, (uint32_t)(2 * s) * Pb, 0));
 
-    float *yn = y + n * (int64_t)C * P + p;
-    uint32_t *sn = sel + n * (int64_t)C * PW + (p >> 5);
 #pragma unroll
     for (int t = 0; t < TILES; ++t) {
         f32x16 acc_a = {0}, acc_b = {0};
@@ -93,15 +107,24 @@ __global__ __launch_bounds__(kBlock) void conv1x1_mfm_forward_kernel(const float
         // branch-free epilogue: per-channel parameters come from LDS (identity values where absent)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int c = t * 32 + mfma_row(r, lane);
-            const bool live = c < C;
+            const int c_lo = t * 32 + (r & 3) + 8 * (r >> 2);        // lanes 0-31: channel c_lo, lanes 32-63: c_lo + 4
+            const int c = c_lo + 4 * lk;
             const float va = acc_a[r] + par_s[c], vb = acc_b[r] + par_s[CP + c];
             const bool tb = mfm_takes_b(va, vb);
-            // lanes 0-31 hold channel c_lo for 32 pixels, lanes 32-63 channel c_lo + 4: one ballot, two 32-bit words
-            const unsigned long long word = __ballot(valid && live && tb);
+            // one ballot, two 32-bit selection words
+            const unsigned long long word = __ballot(valid && tb);
             const float v = ((tb ? vb : va) - par_s[2 * CP + c]) * par_s[3 * CP + c];
-            if (live && valid) yn[(int64_t)c * P] = v;
-            if (live && li == 0) sn[(int64_t)c * PW] = lk ? (uint32_t)(word >> 32) : (uint32_t)word;
+            // the descriptor's range check covers the lane offset only, NOT the scalar row offset: rows >= C must not be
+            // stored.  Wave-uniform cases first (C a multiple of 8 never takes the per-lane one).
+            const uint32_t sw = lk ? (uint32_t)(word >> 32) : (uint32_t)word;
+            if (FULL || c_lo + 4 < C) {
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), yr, y_off, (uint32_t)c_lo * Pb, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(sw, sr, s_off, (uint32_t)c_lo * PWb, 0);
+            } else if (c_lo < C) {
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), yr, lk ? kOut : y_off,
+                                                      (uint32_t)c_lo * Pb, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(sw, sr, lk ? kOut : s_off, (uint32_t)c_lo * PWb, 0);
+            }
         }
     }
 }
@@ -132,8 +155,18 @@ __global__ __launch_bounds__(kBlock) void conv1x1_mfm_backward_kernel(const floa
     const bool valid = p < P;
     if ((int64_t)blockIdx.x * kPixPerBlock + wave * 32 >= P) return;
 
-    const float *gn = gy + n * (int64_t)C * P + (valid ? p : 0);
-    const uint32_t *sn = sel + n * (int64_t)C * PW + ((valid ? p : 0) >> 5);
+    // 32-bit, mostly scalar addressing as in the forward kernel
+    const uint32_t Pb = (uint32_t)P * 4u, PWb = (uint32_t)PW * 4u;
+    const __amdgpu_buffer_rsrc_t gr =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(gy + n * (int64_t)C * P), 0, (int)(C * Pb), 0x00020000);
+    const __amdgpu_buffer_rsrc_t sr =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(sel + n * (int64_t)C * PW), 0, (int)(C * PWb), 0x00020000);
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(gx + n * CIN * P, 0, (int)(CIN * Pb), 0x00020000);
+    constexpr uint32_t kOut = 0x80000000u;
+    const uint32_t pb = (uint32_t)p * 4u;
+    const uint32_t g_off = valid ? (uint32_t)lk * Pb + pb : kOut;                              // row lk, pixel p
+    const uint32_t s_off = valid ? (uint32_t)lk * PWb + (uint32_t)(p >> 5) * 4u : kOut;         // row lk, word of p
+    const uint32_t x_off = valid ? 4u * (uint32_t)lk * Pb + pb : kOut;                         // row 4 lk, pixel p
     f32x16 acc[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) acc[m] = (f32x16){0};
@@ -144,9 +177,8 @@ __global__ __launch_bounds__(kBlock) void conv1x1_mfm_backward_kernel(const floa
         uint32_t taken = 0;  // bit s: the second half won for channel 2 s + lk at this lane's pixel
 #pragma unroll
         for (int s = 0; s < STEPS; ++s) {
-            const int c = 2 * s + lk;
-            g[s] = valid ? gn[(int64_t)c * P] : 0.0f;
-            taken |= ((sn[(int64_t)c * PW] >> li) & 1u) << s;
+            g[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gr, g_off, (uint32_t)(2 * s) * Pb, 0));
+            taken |= ((__builtin_amdgcn_raw_buffer_load_b32(sr, s_off, (uint32_t)(2 * s) * PWb, 0) >> li) & 1u) << s;
         }
 #pragma unroll
         for (int s = 0; s < STEPS; ++s) {
@@ -167,8 +199,10 @@ __global__ __launch_bounds__(kBlock) void conv1x1_mfm_backward_kernel(const floa
     for (int s = 0; s < steps; ++s) {
         const int c = 2 * s + lk;
         const bool live = c < C;
-        const float g = (live && valid) ? gn[(int64_t)c * P] * gs_s[c] : 0.0f;
-        const bool tb = live && ((sn[(int64_t)(live ? c : 0) * PW] >> li) & 1u);
+        const float g = live ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gr, g_off, (uint32_t)(2 * s) * Pb, 0)) *
+                                   gs_s[c]
+                             : 0.0f;
+        const bool tb = live && ((__builtin_amdgcn_raw_buffer_load_b32(sr, s_off, (uint32_t)(2 * s) * PWb, 0) >> li) & 1u);
         const float ga = tb ? 0.0f : g, gb = tb ? g : 0.0f;
         const float *wa = w_s + (live ? c : 0) * PITCH + li;
         const float *wb = w_s + ((live ? c : 0) + C) * PITCH + li;
@@ -179,14 +213,17 @@ __global__ __launch_bounds__(kBlock) void conv1x1_mfm_backward_kernel(const floa
         }
     }
     }
-    if (!valid) return;
-    float *xn = gx + n * CIN * P + p;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int ci = m * 32 + mfma_row(r, lane);
-            if (ci < CIN) xn[(int64_t)ci * P] = acc[m][r];
+            // lanes 32-63 hold row ci_lo + 4.  Rows >= CIN must not be stored (the range check does not see the scalar
+            // row offset); CIN is a multiple of 8, so a row pair is live or dead as a whole — decided at compile time
+            const int ci_lo = m * 32 + (r & 3) + 8 * (r >> 2);
+            static_assert(CIN % 8 == 0, "row pairs (ci, ci + 4) must be live or dead together");
+            const float gv = acc[m][r];   // (bit-casting the vector element in place stores element 0 sixteen times: hipcc 7.2)
+            if (ci_lo < CIN)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(gv), xr, x_off, (uint32_t)ci_lo * Pb, 0);
         }
     }
 }
@@ -204,10 +241,16 @@ template <int CIN, int TILES>
 void launch_fwd(const float *x, const float *w, const float *b, const float *bn_mean, const float *bn_invstd, float *y,
                 uint32_t *sel, int64_t N, int64_t C, int64_t P, hipStream_t st) {
     const size_t lds = (size_t)(2 * TILES * 32 * (CIN + 1) + 4 * TILES * 32) * sizeof(float);
-    opt_in_lds(conv1x1_mfm_forward_kernel<CIN, TILES>, lds);
     const dim3 grid((unsigned)ceil_div(P, kPixPerBlock), (unsigned)N);
-    hipLaunchKernelGGL((conv1x1_mfm_forward_kernel<CIN, TILES>), grid, dim3(kBlock), lds, st, x, w, b, bn_mean, bn_invstd, y,
-                       sel, (int)C, P, ceil_div(P, 32));
+    if (C == TILES * 32) {
+        opt_in_lds(conv1x1_mfm_forward_kernel<CIN, TILES, true>, lds);
+        hipLaunchKernelGGL((conv1x1_mfm_forward_kernel<CIN, TILES, true>), grid, dim3(kBlock), lds, st, x, w, b, bn_mean,
+                           bn_invstd, y, sel, (int)C, P, ceil_div(P, 32));
+    } else {
+        opt_in_lds(conv1x1_mfm_forward_kernel<CIN, TILES, false>, lds);
+        hipLaunchKernelGGL((conv1x1_mfm_forward_kernel<CIN, TILES, false>), grid, dim3(kBlock), lds, st, x, w, b, bn_mean,
+                           bn_invstd, y, sel, (int)C, P, ceil_div(P, 32));
+    }
 }
 
 template <int CIN, int MT, int STEPS>

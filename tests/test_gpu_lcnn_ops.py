@@ -252,6 +252,45 @@ def test_conv1x1_mfm_matches_float64_reference(L, cuda, N, Cin, C, H, W, with_bi
     assert (gx.double() - gx_ref).abs().max().item() <= 2e-5 * max(gx_ref.abs().max().item(), 1.0)
 
 
+@pytest.mark.parametrize("Cin,C", [(48, 48), (32, 5), (48, 7), (64, 64), (64, 33)])
+def test_conv1x1_mfm_writes_nothing_outside_its_tensors(cuda, Cin, C):
+    """The kernels address channel rows through scalar offsets of a buffer descriptor, which the hardware does not
+    range-check: accumulator rows beyond C (forward) / Cin (backward) — present whenever these are not multiples of 32 —
+    must not be stored.  Outputs are carved out of sentinel-filled buffers and the sentinels checked afterwards."""
+    from audio_deepfake_adversarial_attacks_amd import _lib
+    lib = _lib.load()
+    N, P = 3, 77
+    g = torch.Generator().manual_seed(Cin + C)
+    x = torch.randn(N, Cin, P, generator=g).to(cuda)
+    w = (torch.randn(2 * C, Cin, generator=g) * 0.2).to(cuda)
+    PW = (P + 31) // 32
+    pad = 64 * P
+    ybuf = torch.full((pad + N * C * P + pad,), 7.5, device=cuda)
+    sbuf = torch.full((pad + N * C * PW + pad,), 0x5A5A5A5A, dtype=torch.int32, device=cuda)
+    y, sel = ybuf[pad:pad + N * C * P], sbuf[pad:pad + N * C * PW]
+    stream = torch.cuda.current_stream(cuda).cuda_stream
+    assert lib.advstep_conv1x1_mfm_forward_f32(x.data_ptr(), w.data_ptr(), None, None, None, y.data_ptr(), sel.data_ptr(),
+                                               N, Cin, C, P, stream) == 0
+    torch.cuda.synchronize()
+    assert (ybuf[:pad] == 7.5).all() and (ybuf[pad + N * C * P:] == 7.5).all()
+    assert (sbuf[:pad] == 0x5A5A5A5A).all() and (sbuf[pad + N * C * PW:] == 0x5A5A5A5A).all()
+    conv = torch.einsum("ok,nkp->nop", w.double(), x.double())
+    want = torch.maximum(conv[:, :C], conv[:, C:])
+    assert (y.view(N, C, P).double() - want).abs().max().item() <= 2e-5
+    gy = torch.randn(N, C, P, generator=g).to(cuda)
+    xpad = 64 * P
+    gbuf = torch.full((xpad + N * Cin * P + xpad,), -3.25, device=cuda)
+    gx = gbuf[xpad:xpad + N * Cin * P]
+    assert lib.advstep_conv1x1_mfm_backward_f32(gy.data_ptr(), sel.data_ptr(), w.data_ptr(), None, gx.data_ptr(), N, Cin,
+                                                C, P, stream) == 0
+    torch.cuda.synchronize()
+    assert (gbuf[:xpad] == -3.25).all() and (gbuf[xpad + N * Cin * P:] == -3.25).all()
+    took_b = conv[:, C:] > conv[:, :C]
+    gfull = torch.cat([torch.where(took_b, 0.0, gy.double()), torch.where(took_b, gy.double(), 0.0)], dim=1)
+    want_gx = torch.einsum("ok,nop->nkp", w.double(), gfull)
+    assert (gx.view(N, Cin, P).double() - want_gx).abs().max().item() <= 2e-5 * max(want_gx.abs().max().item(), 1.0)
+
+
 def test_conv1x1_mfm_rejects_unsupported_and_unfrozen(L, cuda):
     w = torch.randn(8, 16, 1, 1, device=cuda)
     with pytest.raises(ValueError, match="Cin"):
