@@ -9,8 +9,9 @@
 // the <= 9 pooled cells whose winner can reach it, straight from gy + the selection bytes.
 //   forward : thread = one pooled output position, 6x6 input window in registers, loop over the C channel
 //             pairs with the 2 x 25 taps + 2 biases as wave-uniform (scalar) operands: 100 v_pk_fma_f32 per pair.
-//   backward: thread = one 2x2 input patch; taps staged in LDS as zero-bordered tables (branch-free per-lane lookup);
-//             no atomics.
+//   backward: thread = one 2x2 input patch; taps staged in LDS as zero-bordered tables (branch-free per-lane lookup,
+//             start offset by selection code from an 8-entry LDS table); gradients / codes through buffer descriptors
+//             with scalar channel offsets; no atomics.
 // VALU-bound (13.2 GFLOP at B = 128), not HBM-bound; MFMA does not apply (K = 25, one input channel).
 // Accumulation order is fixed (taps row-major, then channels), fma contraction allowed: deterministic, and within
 // float rounding of any other convolution implementation (MIOpen's differs in the last bits as well).
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(kBlock) void conv5_mfm_pool2_backward_kernel(const 
                                                                           const uint8_t *__restrict__ idx,
                                                                           const float *__restrict__ weight,
                                                                           float *__restrict__ gx, int C, int H, int W) {
-    extern __shared__ __attribute__((aligned(16))) float wl[];  // [2][C][7][7] + 4 words between the halves
+    extern __shared__ __attribute__((aligned(16))) float wl[];  // [2][C][7][7] + 4 words between the halves, then lut[8]
     const int half_pitch = C * kTabWords + 4;
     for (int i = threadIdx.x; i < 2 * half_pitch; i += kBlock) wl[i] = 0.0f;
     __syncthreads();
@@ -134,6 +135,11 @@ __global__ __launch_bounds__(kBlock) void conv5_mfm_pool2_backward_kernel(const 
         const int ch = i / KK, tap = i - ch * KK, kh = tap / K, kw = tap - kh * K;
         const int half = ch >= C, c = ch - half * C;
         wl[half * half_pitch + c * kTabWords + (kh + 1) * kTab + (kw + 1)] = weight[i];
+    }
+    int *lut = reinterpret_cast<int *>(wl + 2 * half_pitch);   // byte offset of a winner's taps, by selection code
+    if (threadIdx.x < 8) {
+        const int code = threadIdx.x;
+        lut[code] = 4 * (((code & 4) ? half_pitch : 0) - kTab * ((code >> 1) & 1) - (code & 1));
     }
     __syncthreads();
 
@@ -143,44 +149,47 @@ __global__ __launch_bounds__(kBlock) void conv5_mfm_pool2_backward_kernel(const 
     const int p = blockIdx.x * kBlock + threadIdx.x;
     if (p >= Hp * Wp) return;
     const int hp = p / Wp, wp = p - hp * Wp;
-    const float *gn = gy + n * (int64_t)C * Ho * Wo;
-    const uint8_t *in = idx + n * (int64_t)C * Ho * Wo;
-
-    // the 9 neighbour cells: clamped 32-bit offsets + validity, hoisted out of the channel loop
-    uint32_t cell_off[9];
-    bool cell_ok[9];
+    // gy and the selection bytes of this sample through buffer descriptors: a 32-bit lane offset per neighbour cell
+    // (hoisted), the channel as a scalar offset — no per-access VALU address arithmetic (VALU time is what bounds this
+    // kernel).  A neighbour outside the pooled grid gets an out-of-range offset: its gradient and code read as 0.
+    const uint32_t plane = (uint32_t)(Ho * Wo);
+    const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(gy + n * (int64_t)C * plane), 0, (int)((uint32_t)C * plane * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ir = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t *>(idx + n * (int64_t)C * plane), 0, (int)((uint32_t)C * plane), 0x00020000);
+    uint32_t cell_b[9], cell_f[9];   // byte offsets into the selection bytes / the gradients; 0x80000000 = outside
 #pragma unroll
     for (int dh = -1; dh <= 1; ++dh) {
 #pragma unroll
         for (int dw = -1; dw <= 1; ++dw) {
             const int ho = hp + dh, wo = wp + dw;
             const bool ok = ho >= 0 && ho < Ho && wo >= 0 && wo < Wo;
-            cell_ok[(dh + 1) * 3 + dw + 1] = ok;
-            cell_off[(dh + 1) * 3 + dw + 1] = ok ? (uint32_t)(ho * Wo + wo) : 0u;
+            cell_b[(dh + 1) * 3 + dw + 1] = ok ? (uint32_t)(ho * Wo + wo) : 0x80000000u;
+            cell_f[(dh + 1) * 3 + dw + 1] = ok ? (uint32_t)(ho * Wo + wo) * 4u : 0x80000000u;
         }
     }
 
     // (x00, x01) and (x10, x11) accumulate as float2 pairs: the two taps a winner sends to one patch row are adjacent
-    // words of the bordered table (one ds_read2_b32 = an aligned register pair), the gradient is the broadcast operand
+    // words of the bordered table (one ds_read2_b32 = an aligned register pair), the gradient is the broadcast operand.
+    // Where the winner's taps start — which half's table, shifted by the winner's row / column inside its cell — is a
+    // function of the 3 code bits: an 8-entry byte-offset table in LDS (one ds_read instead of six VALU instructions).
     f32x2 acc0 = {0.0f, 0.0f}, acc1 = {0.0f, 0.0f};
-    const uint32_t plane = (uint32_t)(Ho * Wo);
+    const char *lut_b = reinterpret_cast<const char *>(lut);
     for (int c = 0; c < C; ++c) {
-        const float *gc = gn + (size_t)c * plane;      // wave-uniform bases: scalar registers + 32-bit lane offsets
-        const uint8_t *ic = in + (size_t)c * plane;
-        const float *wc = wl + c * kTabWords;
+        const uint32_t gsoff = (uint32_t)c * plane * 4u, isoff = (uint32_t)c * plane;   // wave-uniform
+        const char *wc = reinterpret_cast<const char *>(wl + c * kTabWords);
 #pragma unroll
         for (int dh = -1; dh <= 1; ++dh) {
 #pragma unroll
             for (int dw = -1; dw <= 1; ++dw) {
                 const int q = (dh + 1) * 3 + dw + 1;
-                const uint32_t code = ic[cell_off[q]];
-                const float gl = gc[cell_off[q]];              // unconditional (clamped address), then masked
-                const float g = cell_ok[q] ? gl : 0.0f;
+                const uint32_t code = __builtin_amdgcn_raw_buffer_load_b8(ir, cell_b[q], isoff, 0);
+                const float g = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gr, cell_f[q], gsoff, 0));
                 // winner's conv position relative to the patch origin: (2 dh + ph, 2 dw + pw); patch pixel (i, j) sees
                 // tap (i - rh + 2, j - rw + 2), stored at [i - rh + 3][j - rw + 3] of the bordered table: a constant
-                // per neighbour minus a term that depends on the 3 code bits only
-                const int by_code = ((code & 4u) ? half_pitch : 0) - kTab * (int)((code >> 1) & 1u) - (int)(code & 1u);
-                const float *t0 = wc + ((3 - 2 * dh) * kTab + (3 - 2 * dw)) + by_code;
+                // per neighbour plus lut[code]
+                const int by_code = *reinterpret_cast<const int *>(lut_b + code * 4u);   // codes are 0..7 (forward kernel)
+                const float *t0 = reinterpret_cast<const float *>(wc + ((3 - 2 * dh) * kTab + (3 - 2 * dw)) * 4 + by_code);
                 const f32x2 gg = {g, g};
                 acc0 = __builtin_elementwise_fma(gg, (f32x2){t0[0], t0[1]}, acc0);
                 acc1 = __builtin_elementwise_fma(gg, (f32x2){t0[kTab], t0[kTab + 1]}, acc1);
@@ -232,7 +241,7 @@ int advstep_conv5_mfm_pool2_backward_f32(const float *gy, const uint8_t *idx, co
     CONV0_REQUIRE(gy && idx && weight);
     const int64_t patches = ((H + 1) / 2) * ((W + 1) / 2);
     const dim3 grid((unsigned)ceil_div(patches, kBlock), (unsigned)N);
-    const size_t lds = (size_t)2 * (C * kTabWords + 4) * sizeof(float);
+    const size_t lds = (size_t)(2 * (C * kTabWords + 4) + 8) * sizeof(float);
     hipLaunchKernelGGL(conv5_mfm_pool2_backward_kernel, grid, dim3(kBlock), lds, st, gy, idx, weight, gx, (int)C, (int)H,
                        (int)W);
     return status_after_launch();
