@@ -224,27 +224,45 @@ __global__ __launch_bounds__(kBlock) void lfcc_project_mfma_kernel(const float *
     const float *src = band_db + (b * NF + t0) * kLfccM;
     int ties = 0;
     // stage the (frames x 128) band tile and the DCT with 16-byte global loads, several in flight per thread
+    // all 16 loads of a thread are issued before the first is used (a load -> wait -> LDS write loop is one HBM latency
+    // per iteration: 16 of them were the whole kernel time); rows beyond the tile read a clamped address and are zeroed
     const float4 *src4 = reinterpret_cast<const float4 *>(src);
-#pragma unroll 4
-    for (int i = threadIdx.x; i < kMfmaFrames * kLfccM / 4; i += kBlock) {
-        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (i < nfr * kLfccM / 4) {
-            v = src4[i];
+    constexpr int kStage = kMfmaFrames * kLfccM / 4 / kBlock;   // 16
+    const int lim = nfr * kLfccM / 4;
+    float4 st[kStage];
+#pragma unroll
+    for (int j = 0; j < kStage; ++j) {
+        const int i = threadIdx.x + j * kBlock;
+        st[j] = src4[i < lim ? i : lim - 1];
+    }
+#pragma unroll
+    for (int j = 0; j < kStage; ++j) {
+        const int i = threadIdx.x + j * kBlock;
+        float4 v = st[j];
+        if (i < lim) {
             ties += (v.x == gmax) + (v.y == gmax) + (v.z == gmax) + (v.w == gmax);
             float *pv = &v.x;
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 pv[e] = (pv[e] != pv[e]) ? pv[e] : ((floor_db != floor_db) ? floor_db : (pv[e] > floor_db ? pv[e] : floor_db));
+        } else {
+            v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
         float *row = &band_s[i >> 5][(i & 31) * 4];
         row[0] = v.x; row[1] = v.y; row[2] = v.z; row[3] = v.w;
     }
     const float4 *dct4 = reinterpret_cast<const float4 *>(dct);
-#pragma unroll 4
-    for (int i = threadIdx.x; i < kLfccM * kLfccKPad / 4; i += kBlock) {
-        const int m = i / (kLfccKPad / 4), k4 = i - m * (kLfccKPad / 4);
-        const float4 v = k4 < kLfccK / 4 ? dct4[m * (kLfccK / 4) + k4] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        *reinterpret_cast<float4 *>(&dct_s[m][k4 * 4]) = v;
+    constexpr int kDctStage = kLfccM * kLfccKPad / 4 / kBlock;   // 12
+    float4 dt[kDctStage];
+#pragma unroll
+    for (int j = 0; j < kDctStage; ++j) {
+        const int i = threadIdx.x + j * kBlock, m = i / (kLfccKPad / 4), k4 = i - m * (kLfccKPad / 4);
+        dt[j] = dct4[m * (kLfccK / 4) + (k4 < kLfccK / 4 ? k4 : 0)];
+    }
+#pragma unroll
+    for (int j = 0; j < kDctStage; ++j) {
+        const int i = threadIdx.x + j * kBlock, m = i / (kLfccKPad / 4), k4 = i - m * (kLfccKPad / 4);
+        *reinterpret_cast<float4 *>(&dct_s[m][k4 * 4]) = k4 < kLfccK / 4 ? dt[j] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
     if (ties) atomicAdd(&stats[1], (float)ties);
     __syncthreads();
@@ -291,28 +309,48 @@ __global__ __launch_bounds__(kBlock) void lfcc_project_backward_mfma_kernel(cons
     const int t0 = blockIdx.x * kMfmaFrames;
     const int nfr = NF - t0 < kMfmaFrames ? NF - t0 : kMfmaFrames;
     const float *src = dout + (b * NF + t0) * kLfccK;
+    // staging in batches: every load of a batch is issued before the first is used (see the forward kernel)
     const float4 *src4 = reinterpret_cast<const float4 *>(src);
-#pragma unroll 4
-    for (int i = threadIdx.x; i < kMfmaFrames * kLfccK / 4; i += kBlock) {
-        const int t = i / (kLfccK / 4), k4 = i - t * (kLfccK / 4);
-        const float4 v = i < nfr * kLfccK / 4 ? src4[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        float *row = &g_s[t][k4 * 4];
-        row[0] = v.x; row[1] = v.y; row[2] = v.z; row[3] = v.w;
-    }
     const float4 *dct4 = reinterpret_cast<const float4 *>(dct);
-#pragma unroll 4
-    for (int i = threadIdx.x; i < kLfccM * kLfccK / 4; i += kBlock) {
-        const int m = i / (kLfccK / 4), k4 = i - m * (kLfccK / 4);
-        const float4 v = dct4[i];
-        float *row = &dct_s[m][k4 * 4];
-        row[0] = v.x; row[1] = v.y; row[2] = v.z; row[3] = v.w;
-    }
     const float4 *band4 = reinterpret_cast<const float4 *>(band_db + (b * NF + t0) * kLfccM);
-#pragma unroll 4
-    for (int i = threadIdx.x; i < nfr * kLfccM / 4; i += kBlock) {
-        const float4 v = band4[i];
-        float *row = &band_s[i >> 5][(i & 31) * 4];
-        row[0] = v.x; row[1] = v.y; row[2] = v.z; row[3] = v.w;
+    constexpr int kGStage = kMfmaFrames * kLfccK / 4 / kBlock;   // 10 (dout tile and the DCT have the same size)
+    constexpr int kBStage = kMfmaFrames * kLfccM / 4 / kBlock;   // 16
+    static_assert(kMfmaFrames == kLfccM, "the dout tile and the DCT are staged with the same index map");
+    {
+        const int lim = nfr * kLfccK / 4;
+        float4 gq[kGStage], dq[kGStage];
+#pragma unroll
+        for (int j = 0; j < kGStage; ++j) {
+            const int i = threadIdx.x + j * kBlock;
+            gq[j] = src4[i < lim ? i : lim - 1];
+            dq[j] = dct4[i];
+        }
+#pragma unroll
+        for (int j = 0; j < kGStage; ++j) {
+            const int i = threadIdx.x + j * kBlock, t = i / (kLfccK / 4), k4 = i - t * (kLfccK / 4);
+            const float4 v = i < lim ? gq[j] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            float *row = &g_s[t][k4 * 4];
+            row[0] = v.x; row[1] = v.y; row[2] = v.z; row[3] = v.w;
+            float *drow = &dct_s[t][k4 * 4];
+            drow[0] = dq[j].x; drow[1] = dq[j].y; drow[2] = dq[j].z; drow[3] = dq[j].w;
+        }
+    }
+    {
+        const int lim = nfr * kLfccM / 4;
+        float4 bq[kBStage];
+#pragma unroll
+        for (int j = 0; j < kBStage; ++j) {
+            const int i = threadIdx.x + j * kBlock;
+            bq[j] = band4[i < lim ? i : lim - 1];
+        }
+#pragma unroll
+        for (int j = 0; j < kBStage; ++j) {
+            const int i = threadIdx.x + j * kBlock;
+            if (i < lim) {
+                float *row = &band_s[i >> 5][(i & 31) * 4];
+                row[0] = bq[j].x; row[1] = bq[j].y; row[2] = bq[j].z; row[3] = bq[j].w;
+            }
+        }
     }
     __syncthreads();
 
