@@ -52,10 +52,26 @@ __global__ __launch_bounds__(kBlock) void conv1x1_mfm_forward_kernel(const float
     extern __shared__ __attribute__((aligned(16))) float w_s[];
     constexpr int CP = TILES * 32, PITCH = CIN + 1;
     float *par_s = w_s + 2 * CP * PITCH;  // [4][CP]: bias of half a, bias of half b, BN mean, BN invstd
-    for (int i = threadIdx.x; i < 2 * CP * CIN; i += kBlock) {
-        const int row = i / CIN, ci = i - row * CIN;
-        const int half = row / CP, c = row - half * CP;
-        w_s[row * PITCH + ci] = c < C ? weight[(int64_t)(half * C + c) * CIN + ci] : 0.0f;
+    // weights -> LDS in batches of kWBatch loads per thread, all issued before the first is used (a load -> LDS write
+    // loop pays one L2 latency per iteration: 24-32 iterations cost more than the tile's matrix instructions)
+    constexpr int kWLoads = 2 * CP * CIN / kBlock;
+    constexpr int kWBatch = kWLoads % 8 == 0 ? 8 : 12;
+    static_assert((2 * CP * CIN) % kBlock == 0 && kWLoads % kWBatch == 0, "weight staging batches");
+#pragma unroll
+    for (int j0 = 0; j0 < kWLoads; j0 += kWBatch) {
+        float wv[kWBatch];
+#pragma unroll
+        for (int j = 0; j < kWBatch; ++j) {
+            const int i = threadIdx.x + (j0 + j) * kBlock, row = i / CIN, ci = i - row * CIN;
+            const int half = row / CP, c = row - half * CP;
+            wv[j] = weight[(half * C + (c < C ? c : 0)) * CIN + ci];
+        }
+#pragma unroll
+        for (int j = 0; j < kWBatch; ++j) {
+            const int i = threadIdx.x + (j0 + j) * kBlock, row = i / CIN, ci = i - row * CIN;
+            const int c = row % CP;
+            w_s[row * PITCH + ci] = c < C ? wv[j] : 0.0f;
+        }
     }
     for (int c = threadIdx.x; c < CP; c += kBlock) {
         const bool live = c < C;
@@ -142,9 +158,30 @@ __global__ __launch_bounds__(kBlock) void conv1x1_mfm_backward_kernel(const floa
     extern __shared__ __attribute__((aligned(16))) float w_s[];
     constexpr int CW = MT * 32, PITCH = CW + 1;
     float *gs_s = w_s + 2 * C * PITCH;  // [C]: the following BatchNorm's invstd (1 where absent)
-    for (int i = threadIdx.x; i < 2 * C * CW; i += kBlock) {
-        const int row = i / CW, ci = i - row * CW;
-        w_s[row * PITCH + ci] = ci < CIN ? weight[(int64_t)row * CIN + ci] : 0.0f;
+    // weights -> LDS, several loads per thread in flight (see the forward kernel); with C known at compile time
+    // (STEPS > 0: C = 2 STEPS) the index arithmetic folds away
+    if constexpr (STEPS > 0) {
+        constexpr int kRows = 4 * STEPS, kWLoads = kRows * CW / kBlock, kWBatch = kWLoads % 8 == 0 ? 8 : 12;
+        static_assert((kRows * CW) % kBlock == 0 && kWLoads % kWBatch == 0, "weight staging batches");
+#pragma unroll
+        for (int j0 = 0; j0 < kWLoads; j0 += kWBatch) {
+            float wv[kWBatch];
+#pragma unroll
+            for (int j = 0; j < kWBatch; ++j) {
+                const int i = threadIdx.x + (j0 + j) * kBlock, row = i / CW, ci = i - row * CW;
+                wv[j] = weight[row * CIN + (ci < CIN ? ci : 0)];
+            }
+#pragma unroll
+            for (int j = 0; j < kWBatch; ++j) {
+                const int i = threadIdx.x + (j0 + j) * kBlock, row = i / CW, ci = i - row * CW;
+                w_s[row * PITCH + ci] = ci < CIN ? wv[j] : 0.0f;
+            }
+        }
+    } else {
+        for (int i = threadIdx.x; i < 2 * C * CW; i += kBlock) {
+            const int row = i / CW, ci = i - row * CW;
+            w_s[row * PITCH + ci] = ci < CIN ? weight[(int64_t)row * CIN + ci] : 0.0f;
+        }
     }
     for (int c = threadIdx.x; c < C; c += kBlock) gs_s[c] = gscale ? gscale[c] : 1.0f;
     __syncthreads();
