@@ -337,9 +337,30 @@ __global__ __launch_bounds__(kThreads) void stft_bands_backward_kernel(const flo
     extern __shared__ __attribute__((aligned(16))) unsigned char raw[];
     LdsBwd<SPAN_CAP> &S = *reinterpret_cast<LdsBwd<SPAN_CAP> *>(raw);
     Lds &L = S.c;
-    fill_twiddles(L);
-    for (int i = threadIdx.x; i < kBins; i += kThreads) S.fbt_start[i] = fbt_start[i];
-    for (int i = threadIdx.x; i < kBins * span_t; i += kThreads) S.fbt_w[i] = fbt_w[i];
+    {
+        // the workgroup's tables -> LDS: every load issued before the first LDS write (seven dependent load -> store
+        // round trips were ~40 % of a workgroup's 4-frame lifetime)
+        static_assert(kN == kThreads, "one twiddle pair per thread");
+        constexpr int kWIt = (kBins * SPAN_CAP + kThreads - 1) / kThreads;
+        const int m = threadIdx.x, nw = kBins * span_t;
+        const float2 t0 = g_twiddles[m < kStageTw ? m : 0], t1 = g_twiddles[kN + m];
+        const int32_t s0 = fbt_start[m], s1 = fbt_start[kThreads + (m < kBins - kThreads ? m : 0)];
+        float wq[kWIt];
+#pragma unroll
+        for (int j = 0; j < kWIt; ++j) {
+            const int i = m + j * kThreads;
+            wq[j] = fbt_w[i < nw ? i : nw - 1];
+        }
+        if (m < kStageTw) L.tw[m] = t0;
+        L.tw512[m] = t1;
+        S.fbt_start[m] = s0;
+        if (m < kBins - kThreads) S.fbt_start[kThreads + m] = s1;
+#pragma unroll
+        for (int j = 0; j < kWIt; ++j) {
+            const int i = m + j * kThreads;
+            if (i < nw) S.fbt_w[i] = wq[j];
+        }
+    }
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t b = blockIdx.y;
