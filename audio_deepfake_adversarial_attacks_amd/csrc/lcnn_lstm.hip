@@ -6,7 +6,8 @@
 // pass (8 000+ launches of 3-5 us per 40-iteration PGD step, ~20 % of the step once the convolution side is fused).
 // The recurrence of one utterance is independent of every other utterance, so here ONE workgroup owns one
 // (utterance, direction) for all T steps: 4H = 320 threads, thread j keeps row j of W_hh (H = 80 floats) in
-// registers, h_{t-1} lives in LDS (broadcast reads), two barriers per step.  256 workgroups at B = 128: one per CU.
+// registers, h_{t-1} lives in LDS (broadcast reads), two LDS-only barriers per step, each thread applies its own gate's
+// nonlinearity; the backward reduces the saved activations to coefficients one step ahead of the recurrence.  256 workgroups at B = 128: one per CU.
 // The input projection W_ih x + b (all steps, both directions) stays ONE rocBLAS GEMM on the torch side, as does its
 // backward.  Gate order and formulas are torch.nn.LSTM's (i, f, g, o).
 // Latency-bound by design (25 dependent steps); neither HBM nor MFMA is the limiter at this size.
@@ -23,6 +24,11 @@ inline hipStream_t as_stream(advstep_stream_t s) { return reinterpret_cast<hipSt
 inline int status_after_launch() { return hipGetLastError() == hipSuccess ? ADVSTEP_OK : ADVSTEP_ELAUNCH; }
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding global access
+// (s_waitcnt vmcnt(0)): inside the step loops that put each step's stores — and the prefetch of the next step's inputs —
+// on the critical path of a 25-step recurrence.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // gx (T, B, D, 4H), w_hh (D, 4H, H), out (T, B, D*H), gates (T, B, D, 4H), cell (T, B, D, H)
 template <int H>
@@ -41,6 +47,7 @@ __global__ __launch_bounds__(4 * H) void lstm_forward_kernel(const float *__rest
     }
     if (j < H) h_s[j] = 0.0f;
     float c = 0.0f;
+    const bool is_g = j >= 2 * H && j < 3 * H;   // gate order i, f, g, o
     __syncthreads();
     float gx_next = T > 0 ? gx[(((int64_t)(d == 0 ? 0 : T - 1) * B + b) * D + d) * 4 * H + j] : 0.0f;
     for (int step = 0; step < T; ++step) {
@@ -51,21 +58,26 @@ __global__ __launch_bounds__(4 * H) void lstm_forward_kernel(const float *__rest
             const int tn = d == 0 ? step + 1 : T - 2 - step;
             gx_next = gx[(((int64_t)tn * B + b) * D + d) * 4 * H + j];
         }
+        // four partial sums: a single 80-long dependent fma chain is latency-, not throughput-bound
+        float a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
 #pragma unroll
         for (int k = 0; k < H; k += 4) {
             const float4 hv = *reinterpret_cast<const float4 *>(&h_s[k]);
             acc = fmaf(w[k], hv.x, acc);
-            acc = fmaf(w[k + 1], hv.y, acc);
-            acc = fmaf(w[k + 2], hv.z, acc);
-            acc = fmaf(w[k + 3], hv.w, acc);
+            a1 = fmaf(w[k + 1], hv.y, a1);
+            a2 = fmaf(w[k + 2], hv.z, a2);
+            a3 = fmaf(w[k + 3], hv.w, a3);
         }
-        pre[j] = acc;
-        __syncthreads();
+        // every thread applies its own gate's nonlinearity (the transcendental work of a step spread over all 320
+        // threads instead of 80): sigmoid for i, f, o; tanh(x) = 2 sigmoid(2x) - 1 for g
+        const float z = (acc + a1) + (a2 + a3);
+        const float sg = 1.0f / (1.0f + expf(is_g ? -2.0f * z : -z));
+        pre[j] = is_g ? 2.0f * sg - 1.0f : sg;
+        lds_barrier();
         if (j < H) {
-            const float ig = sigmoidf_(pre[j]), fg = sigmoidf_(pre[H + j]), gg = tanhf(pre[2 * H + j]),
-                        og = sigmoidf_(pre[3 * H + j]);
+            const float ig = pre[j], fg = pre[H + j], gg = pre[2 * H + j], og = pre[3 * H + j];
             c = fg * c + ig * gg;
-            const float h = og * tanhf(c);
+            const float h = og * (2.0f / (1.0f + expf(-2.0f * c)) - 1.0f);   // og * tanh(c)
             float *gr = gates + row * 4 * H;
             gr[j] = ig;
             gr[H + j] = fg;
@@ -75,7 +87,7 @@ __global__ __launch_bounds__(4 * H) void lstm_forward_kernel(const float *__rest
             out[((int64_t)t * B + b) * D * H + d * H + j] = h;
             h_s[j] = h;
         }
-        __syncthreads();
+        lds_barrier();
     }
 }
 
@@ -88,7 +100,6 @@ __global__ __launch_bounds__(4 * H) void lstm_backward_kernel(const float *__res
                                                               int T, int B, int D) {
     __shared__ __attribute__((aligned(16))) float dg_s[4 * H];
     __shared__ float part[4 * H];
-    __shared__ float dh_s[H];
     const int b = blockIdx.x, d = blockIdx.y, tid = threadIdx.x;
     const int k = tid % H, q = tid / H;
     // thread (k, q) holds W_hh[q*H + jj][k], jj < H: its share of the transposed product dh[k] = sum_j dg[j] W_hh[j][k]
@@ -98,30 +109,59 @@ __global__ __launch_bounds__(4 * H) void lstm_backward_kernel(const float *__res
 #pragma unroll
         for (int jj = 0; jj < H; ++jj) w[jj] = wc[(int64_t)jj * H];
     }
-    if (tid < H) dh_s[tid] = 0.0f;
     float dc_next = 0.0f;
+    // a step's saved activations and incoming gradient (threads < H): loaded one step ahead
+    // Per step, threads < H need the saved gates / cell states and dout.  None of that depends on the recurrence
+    // (dh, dc), so it is loaded AND reduced to five coefficients one step ahead; what stays on the critical path is
+    //     dh = dout + sum of the four partial products;  d_o = dh a_o;  dc = dh a_c + dc_next;  d_{i,f,g} = dc a_{i,f,g}.
+    struct Raw {
+        float ig, fg, gg, og, c, c_prev, dout;
+    };
+    struct Coef {
+        float a_o, a_c, a_i, a_f, a_g, fg, dout;
+    };
+    auto load = [&](int step) {                  // issue only: nothing here waits for the values
+        Raw v = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        if (tid < H && step >= 0) {
+            const int t = d == 0 ? step : T - 1 - step, j = tid;
+            const int64_t row = ((int64_t)t * B + b) * D + d;
+            const float *gr = gates + row * 4 * H;
+            v.ig = gr[j], v.fg = gr[H + j], v.gg = gr[2 * H + j], v.og = gr[3 * H + j];
+            v.c = cell[row * H + j];
+            if (step > 0) {
+                const int tp = d == 0 ? step - 1 : T - step;
+                v.c_prev = cell[(((int64_t)tp * B + b) * D + d) * H + j];
+            }
+            v.dout = dout[((int64_t)t * B + b) * D * H + d * H + j];
+        }
+        return v;
+    };
+    auto reduce = [&](const Raw &r) {
+        const float tc = 2.0f / (1.0f + expf(-2.0f * r.c)) - 1.0f;   // tanh(c)
+        Coef v;
+        v.a_o = tc * r.og * (1.0f - r.og);
+        v.a_c = r.og * (1.0f - tc * tc);
+        v.a_i = r.gg * r.ig * (1.0f - r.ig);
+        v.a_f = r.c_prev * r.fg * (1.0f - r.fg);
+        v.a_g = r.ig * (1.0f - r.gg * r.gg);
+        v.fg = r.fg;
+        v.dout = r.dout;
+        return v;
+    };
+    part[tid] = 0.0f;                            // dh of the step after the last one
+    Coef cur = reduce(load(T - 1));
+    Raw raw = load(T - 2);                       // three-stage pipeline: loading (n - 2) | reducing (n - 1) | recurrence (n)
     __syncthreads();
     for (int step = T - 1; step >= 0; --step) {
         const int t = d == 0 ? step : T - 1 - step;
         const int64_t row = ((int64_t)t * B + b) * D + d;
         if (tid < H) {
             const int j = tid;
-            const float *gr = gates + row * 4 * H;
-            const float ig = gr[j], fg = gr[H + j], gg = gr[2 * H + j], og = gr[3 * H + j];
-            const float c = cell[row * H + j];
-            float c_prev = 0.0f;
-            if (step > 0) {
-                const int tp = d == 0 ? step - 1 : T - step;
-                c_prev = cell[(((int64_t)tp * B + b) * D + d) * H + j];
-            }
-            const float dh = dout[((int64_t)t * B + b) * D * H + d * H + j] + dh_s[j];
-            const float tc = tanhf(c);
-            const float d_o = dh * tc * og * (1.0f - og);
-            const float dc = dh * og * (1.0f - tc * tc) + dc_next;
-            const float d_i = dc * gg * ig * (1.0f - ig);
-            const float d_f = dc * c_prev * fg * (1.0f - fg);
-            const float d_g = dc * ig * (1.0f - gg * gg);
-            dc_next = dc * fg;
+            const float dh = cur.dout + ((part[j] + part[H + j]) + (part[2 * H + j] + part[3 * H + j]));
+            const float d_o = dh * cur.a_o;
+            const float dc = dh * cur.a_c + dc_next;
+            const float d_i = dc * cur.a_i, d_f = dc * cur.a_f, d_g = dc * cur.a_g;
+            dc_next = dc * cur.fg;
             dg_s[j] = d_i;
             dg_s[H + j] = d_f;
             dg_s[2 * H + j] = d_g;
@@ -132,20 +172,22 @@ __global__ __launch_bounds__(4 * H) void lstm_backward_kernel(const float *__res
             dr[2 * H + j] = d_g;
             dr[3 * H + j] = d_o;
         }
-        __syncthreads();
-        float s = 0.0f;
+        lds_barrier();                           // dg_s complete; every read of part[] above is done
+        const Raw raw_next = load(step - 2);     // in flight for a whole step before anything reads it
+        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
 #pragma unroll
         for (int jj = 0; jj < H; jj += 4) {
             const float4 gv = *reinterpret_cast<const float4 *>(&dg_s[q * H + jj]);
-            s = fmaf(gv.x, w[jj], s);
-            s = fmaf(gv.y, w[jj + 1], s);
-            s = fmaf(gv.z, w[jj + 2], s);
-            s = fmaf(gv.w, w[jj + 3], s);
+            s0 = fmaf(gv.x, w[jj], s0);
+            s1 = fmaf(gv.y, w[jj + 1], s1);
+            s2 = fmaf(gv.z, w[jj + 2], s2);
+            s3 = fmaf(gv.w, w[jj + 3], s3);
         }
-        part[tid] = s;
-        __syncthreads();
-        if (tid < H) dh_s[tid] = (part[tid] + part[H + tid]) + (part[2 * H + tid] + part[3 * H + tid]);
-        __syncthreads();
+        part[tid] = (s0 + s1) + (s2 + s3);
+        const Coef nxt = reduce(raw);            // values loaded during the previous step
+        lds_barrier();                           // part[] complete; dg_s free for the next step
+        cur = nxt;
+        raw = raw_next;
     }
 }
 
