@@ -183,6 +183,48 @@ def test_conv5_mfm_pool2_matches_float64_reference(L, cuda, shape, C, with_bias)
     assert close.float().mean().item() >= 0.999       # MIOpen's own rounding may flip a near-tie winner
 
 
+@pytest.mark.parametrize("kind", ["conv5", "conv3x3"])
+def test_fused_conv_pool_selection_with_nans_ties_and_infinities(L, cuda, kind):
+    """The pooling epilogues of the convolution kernels take a short path when no candidate in a wave is NaN and the
+    exact ATen rule otherwise: NaNs must propagate exactly as max-feature-map + MaxPool2d do, ties (integer-valued data:
+    the convolution is exact) and infinities must select like ATen, and the selection bytes must route the gradient the
+    same way."""
+    g = torch.Generator().manual_seed(11)
+    if kind == "conv5":
+        N, Cin, C, H, W, k = 3, 1, 32, 12, 70, 5
+    else:
+        N, Cin, C, H, W, k = 2, 32, 48, 10, 12, 3
+    # small integers: every product and partial sum is exact in float32, so equal candidates are exactly equal
+    x = torch.randint(-2, 3, (N, Cin, H, W), generator=g).float()
+    weight = torch.randint(-1, 2, (2 * C, Cin, k, k), generator=g).float()
+    bias = torch.randint(-1, 2, (2 * C,), generator=g).float()
+    if kind == "conv5":       # (a Winograd convolution — MIOpen's and this library's 3x3 — smears non-finite inputs over
+        x[0, 0, 3, 5] = float("nan")              # neighbouring tiles through inf - inf in its transforms: no common reference)
+        x[1, 0, 7, 30] = float("inf")
+        x[1, 0, 2, 3] = float("-inf")
+    x, weight, bias = x.to(cuda), weight.to(cuda), bias.to(cuda)
+    # reference convolution on the CPU in float64: a direct convolution, so a NaN / inf reaches exactly its receptive
+    # field (MIOpen's Winograd / FFT algorithms smear them over neighbouring outputs)
+    y_ref = ref_mfm_pool(torch.nn.functional.conv2d(x.cpu().double(), weight.cpu().double(), bias.cpu().double(),
+                                                    padding=k // 2)).float().to(cuda)
+    xa = x.clone().requires_grad_(True)
+    y = L.conv5_mfm_pool2(xa, weight, bias) if kind == "conv5" else L.conv3x3_mfm_pool2(xa, weight, bias)
+    assert torch.equal(torch.isnan(y), torch.isnan(y_ref)) and (kind != "conv5" or torch.isnan(y).any())
+    finite = torch.isfinite(y_ref)
+    assert torch.equal(torch.nan_to_num(y, nan=0.0, posinf=1e30, neginf=-1e30),
+                       torch.nan_to_num(y_ref, nan=0.0, posinf=1e30, neginf=-1e30))
+    # gradient routing on the samples without NaN / inf (a NaN anywhere poisons ATen's whole convolution backward)
+    clean = torch.randint(-2, 3, (N, Cin, H, W), generator=g).float().to(cuda)
+    ca, cr = clean.clone().requires_grad_(True), clean.clone().requires_grad_(True)
+    yc = L.conv5_mfm_pool2(ca, weight, bias) if kind == "conv5" else L.conv3x3_mfm_pool2(ca, weight, bias)
+    yr = ref_mfm_pool(torch.nn.functional.conv2d(cr, weight, bias, padding=k // 2))
+    assert torch.equal(yc, yr)
+    gy = torch.randint(-2, 3, yr.shape, generator=g).float().to(cuda)
+    (ga,) = torch.autograd.grad(yc, ca, gy)
+    (gr,) = torch.autograd.grad(yr, cr, gy)
+    assert torch.equal(ga, gr) and finite.any()
+
+
 def test_conv5_mfm_pool2_requires_frozen_weights(L, cuda):
     x = torch.randn(1, 1, 8, 8, device=cuda, requires_grad=True)
     w = torch.randn(4, 1, 5, 5, device=cuda, requires_grad=True)
