@@ -49,6 +49,9 @@ SIGNATURES = {
     "advstep_lstm_supported": (ctypes.c_int, [_i64]),
     "advstep_lstm_forward_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p]),
     "advstep_lstm_backward_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p]),
+    "advstep_gru_supported": (ctypes.c_int, [_i64]),
+    "advstep_gru_forward_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p]),
+    "advstep_gru_backward_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p]),
     "advstep_conv3x3_supported": (ctypes.c_int, [_i64, _i64]),
     "advstep_conv3x3_prepared_floats": (_sz, [_i64, _i64, ctypes.c_int]),
     "advstep_conv3x3_prepare_f32": (ctypes.c_int, [_p, _p, _p, _i64, _i64, ctypes.c_int, _p]),

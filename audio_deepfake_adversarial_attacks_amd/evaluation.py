@@ -189,8 +189,10 @@ def generate_attacks(
 
     seed = model_config.get("data", {}).get("seed", 42)
     sampler = ShardedBatchSampler(len(data_val), batch_size, rank, world, shuffle=shuffle, seed=seed)
+    # pinned batches: the H2D copy is then asynchronous and the host thread goes straight back to launching kernels (an
+    # attack iteration is ~48 launches; the loop is launch-bound on the host side)
     test_loader = DataLoader(data_val, batch_sampler=sampler, num_workers=num_workers, collate_fn=collate_fn,
-                             pin_memory=collate_fn is not None)
+                             pin_memory=str(device).startswith("cuda"), persistent_workers=False)
     if world > 1:
         # decorrelate the random starts of different ranks (all ranks were seeded alike to build equal replicas)
         torch.manual_seed(seed + rank)

@@ -399,6 +399,55 @@ def lstm_layer(x: torch.Tensor, w_ih: torch.Tensor, w_hh: torch.Tensor, bias: to
     return _LstmLayer.apply(x.contiguous(), w_ih, w_hh, bias)
 
 
+class _GruLayer(torch.autograd.Function):
+    """One (bi)directional GRU layer, sequence-first, zero initial state; input gradient only (csrc/specrnet_gru.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh):
+        # x (T, B, I); w_ih (D*3H, I); w_hh (D, 3H, H); b_ih (D*3H); b_hh (D, 3H)
+        for name, t in (("x", x), ("w_ih", w_ih), ("w_hh", w_hh), ("b_ih", b_ih), ("b_hh", b_hh)):
+            _require(t, name)
+        T, B, I = x.shape
+        D, H3, H = w_hh.shape
+        if H3 != 3 * H or tuple(w_ih.shape) != (D * H3, I) or b_ih.numel() != D * H3 or b_hh.numel() != D * H3:
+            raise ValueError("inconsistent GRU parameter shapes")
+        gx = torch.addmm(b_ih, x.reshape(T * B, I), w_ih.t())            # one GEMM for all steps and directions
+        out = torch.empty((T, B, D * H), dtype=x.dtype, device=x.device)
+        saved = torch.empty((T, B, D, 4 * H), dtype=x.dtype, device=x.device)
+        with _Launch("gru_forward", x.device):
+            st = _lib.load().advstep_gru_forward_f32(gx.data_ptr(), w_hh.data_ptr(), b_hh.data_ptr(), out.data_ptr(),
+                                                     saved.data_ptr(), T, B, D, H, _stream(x.device))
+        _lib.check(st, "advstep_gru_forward_f32")
+        ctx.save_for_backward(saved, out, w_hh, w_ih)
+        ctx.dims = (T, B, I, D, H)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        if any(ctx.needs_input_grad[1:]):
+            raise RuntimeError("gru_layer provides the input gradient only; call it with frozen weights "
+                               "(the model falls back to torch.nn.GRU otherwise)")
+        saved, out, w_hh, w_ih = ctx.saved_tensors
+        T, B, I, D, H = ctx.dims
+        dout = dout.contiguous()
+        dgx = torch.empty((T, B, D, 3 * H), dtype=dout.dtype, device=dout.device)
+        with _Launch("gru_backward", dout.device):
+            st = _lib.load().advstep_gru_backward_f32(dout.data_ptr(), w_hh.data_ptr(), saved.data_ptr(), out.data_ptr(),
+                                                      dgx.data_ptr(), T, B, D, H, _stream(dout.device))
+        _lib.check(st, "advstep_gru_backward_f32")
+        dx = torch.mm(dgx.view(T * B, D * 3 * H), w_ih).view(T, B, I)
+        return dx, None, None, None, None
+
+
+def gru_supported(hidden_size: int) -> bool:
+    return bool(_lib.load().advstep_gru_supported(hidden_size))
+
+
+def gru_layer(x: torch.Tensor, w_ih: torch.Tensor, w_hh: torch.Tensor, b_ih: torch.Tensor, b_hh: torch.Tensor) -> torch.Tensor:
+    """x (T, B, I) -> (T, B, D*H) for one GRU layer with D directions (parameters packed per direction)."""
+    return _GruLayer.apply(x.contiguous(), w_ih, w_hh, b_ih, b_hh)
+
+
 def mfm(x: torch.Tensor, bias: Optional[torch.Tensor] = None, bn=None) -> torch.Tensor:
     """(N, 2C, H, W) -> (N, C, H, W): max(x[:, :C] + bias[:C], x[:, C:] + bias[C:]) [then (. - mean) * invstd]."""
     return _Mfm.apply(x.contiguous(), bias, bn)

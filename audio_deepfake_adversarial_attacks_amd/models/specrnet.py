@@ -6,6 +6,7 @@ feeds `conv1` with the block INPUT (the bn1/leaky-relu result is discarded, spec
 logits in tests/test_models.py (tests/golden/specrnet_body.npz)."""
 from typing import Dict
 
+import torch
 import torch.nn as nn
 
 from .. import frontends
@@ -42,6 +43,11 @@ class Residual_block2D(nn.Module):
         out = self.conv2(self.lrelu(self.bn2(self.conv1(x))))
         identity = self.conv_downsample(x) if self.downsample else x
         return self.mp(out + identity)
+
+
+def _fused_gru_enabled() -> bool:
+    import os
+    return os.environ.get("ADVSTEP_SPECRNET_GRU", "1") != "0"
 
 
 class BaseSpecRNet(nn.Module):
@@ -85,9 +91,43 @@ class BaseSpecRNet(nn.Module):
         x = self.pool(self._attend(self.block4(x), self.fc_attention4))
         x = self.selu(self.bn_before_gru(x))
         x = x.squeeze(-2).permute(0, 2, 1)
-        self.gru.flatten_parameters()
-        x, _ = self.gru(x)
+        x = self._run_gru(x)
         return self.fc2_gru(self.fc1_gru(x[:, -1, :]))
+
+    def _packed_gru(self):
+        """Per-layer, per-direction GRU parameters packed for lcnn_ops.gru_layer, cached until a parameter changes."""
+        gru = self.gru
+        params = list(gru.parameters())
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        if getattr(self, "_gru_key", None) != key:
+            with torch.no_grad():
+                packed = []
+                for layer in range(gru.num_layers):
+                    sfx = [f"_l{layer}", f"_l{layer}_reverse"]
+                    w_ih = torch.cat([getattr(gru, "weight_ih" + s) for s in sfx], dim=0).contiguous()
+                    w_hh = torch.stack([getattr(gru, "weight_hh" + s) for s in sfx], dim=0).contiguous()
+                    b_ih = torch.cat([getattr(gru, "bias_ih" + s) for s in sfx], dim=0).contiguous()
+                    b_hh = torch.stack([getattr(gru, "bias_hh" + s) for s in sfx], dim=0).contiguous()
+                    packed.append((w_ih, w_hh, b_ih, b_hh))
+            self._gru_key, self._gru_packed = key, packed
+        return self._gru_packed
+
+    def _run_gru(self, x):
+        """(B, T, C) -> (B, T, 2H).  With frozen parameters on a HIP device (an attack is running: only the input gradient
+        is needed) each layer's recurrence is one kernel per direction pair (csrc/specrnet_gru.hip) instead of MIOpen's
+        per-time-step kernel chain; otherwise torch.nn.GRU."""
+        gru = self.gru
+        frozen = not (torch.is_grad_enabled() and any(p.requires_grad for p in gru.parameters()))
+        if x.is_cuda and frozen and _fused_gru_enabled() and gru.bidirectional and gru.bias and gru.dropout == 0.0:
+            from .. import lcnn_ops
+            if lcnn_ops.gru_supported(gru.hidden_size):
+                seq = x.permute(1, 0, 2)
+                for w_ih, w_hh, b_ih, b_hh in self._packed_gru():
+                    seq = lcnn_ops.gru_layer(seq, w_ih, w_hh, b_ih, b_hh)
+                return seq.permute(1, 0, 2)
+        gru.flatten_parameters()
+        out, _ = gru(x)
+        return out
 
     def forward(self, x):
         return self._compute_embedding(x)

@@ -150,6 +150,20 @@ int advstep_lstm_forward_f32(const float *gx, const float *w_hh, float *out, flo
 int advstep_lstm_backward_f32(const float *dout, const float *w_hh, const float *gates, const float *cell, float *dgx,
                               int64_t T, int64_t B, int64_t D, int64_t H, advstep_stream_t stream);
 
+/* ---- recurrent part of a (bi)directional GRU layer  (src/models/specrnet.py:121-127,176-177: nn.GRU(64, 64, 2 layers,
+ * bidirectional); MIOpen runs it as ~400 kernels of ~4 us per forward + backward) --------------------------------------
+ *   gx (T, B, D, 3H) = W_ih x_t + b_ih per direction d (gate order r, z, n; d = 1 runs over time in reverse), computed
+ *   by the caller with one GEMM; w_hh (D, 3H, H), b_hh (D, 3H) as torch stores weight_hh_l* / bias_hh_l*.
+ * out (T, B, D*H) receives h_t; saved (T, B, D, 4H) = r, z, n and a_n = W_hn h + b_hn, kept for the backward pass.
+ * One workgroup per (utterance, direction).  H must satisfy advstep_gru_supported() (64: SpecRNet's). */
+int advstep_gru_supported(int64_t H);
+int advstep_gru_forward_f32(const float *gx, const float *w_hh, const float *b_hh, float *out, float *saved, int64_t T,
+                            int64_t B, int64_t D, int64_t H, advstep_stream_t stream);
+/* dgx (T, B, D, 3H): gradient w.r.t. gx, from dout (T, B, D*H), the saved gates and the forward's own output (h_{t-1});
+ * the caller maps it back to the layer input with one GEMM (dgx . W_ih). */
+int advstep_gru_backward_f32(const float *dout, const float *w_hh, const float *saved, const float *out, float *dgx,
+                             int64_t T, int64_t B, int64_t D, int64_t H, advstep_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -541,3 +541,59 @@ def test_conv3x3_batch_is_split_for_the_32bit_buffer_descriptor(L, cuda, monkeyp
     monkeypatch.setattr(L, "_batch_chunks", lambda N, per: [(0, 2), (2, 5)])
     y1, g1 = run()
     assert torch.equal(y0, y1) and torch.equal(g0, g1)
+
+
+# ---- GRU layer (SpecRNet) --------------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("T,B,I,layers", [(50, 6, 64, 2), (1, 2, 64, 1), (7, 128, 64, 2), (3, 1, 128, 1)])
+def test_gru_layer_matches_torch_gru(L, cuda, T, B, I, layers):
+    torch.manual_seed(T * 100 + B)
+    H = 64
+    ref = torch.nn.GRU(I, H, num_layers=layers, bidirectional=True).double()
+    x = torch.randn(T, B, I, dtype=torch.float64, requires_grad=True)
+    out_ref, _ = ref(x)
+    dout = torch.randn_like(out_ref)
+    (dx_ref,) = torch.autograd.grad(out_ref, x, dout)
+
+    xg = x.detach().float().to(cuda).requires_grad_(True)
+    seq = xg
+    for layer in range(layers):
+        sfx = [f"_l{layer}", f"_l{layer}_reverse"]
+        w_ih = torch.cat([getattr(ref, "weight_ih" + s) for s in sfx]).float().to(cuda).contiguous()
+        w_hh = torch.stack([getattr(ref, "weight_hh" + s) for s in sfx]).float().to(cuda).contiguous()
+        b_ih = torch.cat([getattr(ref, "bias_ih" + s) for s in sfx]).float().to(cuda).contiguous()
+        b_hh = torch.stack([getattr(ref, "bias_hh" + s) for s in sfx]).float().to(cuda).contiguous()
+        seq = L.gru_layer(seq, w_ih.detach(), w_hh.detach(), b_ih.detach(), b_hh.detach())
+    (dx,) = torch.autograd.grad(seq, xg, dout.float().to(cuda))
+    assert seq.shape == (T, B, 2 * H)
+    assert (seq.double().cpu() - out_ref).abs().max().item() <= 3e-6
+    assert (dx.double().cpu() - dx_ref).abs().max().item() <= 3e-5 * max(dx_ref.abs().max().item(), 1.0)
+
+
+def test_specrnet_uses_gru_kernel_when_frozen_and_matches_miopen(cuda, monkeypatch):
+    from audio_deepfake_adversarial_attacks_amd.models.models import get_model
+    torch.manual_seed(5)
+    model = get_model("specrnet", {"frontend_algorithm": ["mel_spec"], "input_channels": 2}, str(cuda)).to(cuda)
+    model.train()                      # attack mode (attack.py:311-319): train, BatchNorm / Dropout in eval
+    for m in model.modules():
+        if "BatchNorm" in m.__class__.__name__ or "Dropout" in m.__class__.__name__:
+            m.eval()
+    spec = torch.randn(6, 2, 80, 404, device=cuda)
+
+    def run(kernel, frozen):
+        monkeypatch.setenv("ADVSTEP_SPECRNET_GRU", "1" if kernel else "0")
+        for p in model.parameters():
+            p.requires_grad_(not frozen)
+        a = spec.clone().requires_grad_(True)
+        z = model._compute_embedding(a)
+        (g,) = torch.autograd.grad(z.sum(), a)
+        return z.detach(), g
+
+    z0, g0 = run(False, True)           # MIOpen
+    z1, g1 = run(True, True)            # HIP kernels
+    z2, g2 = run(True, False)           # parameters need grad -> torch.nn.GRU, identical to z0
+    assert torch.equal(z2, z0)
+    assert (z1 - z0).abs().max().item() <= 2e-5 * max(z0.abs().max().item(), 1.0)
+    assert (g1 - g0).abs().max().item() <= 1e-4 * max(g0.abs().max().item(), 1e-6)
+    for p in model.parameters():
+        p.requires_grad_(True)

@@ -1,0 +1,65 @@
+#!/usr/bin/env python
+"""Throughput of the OTHER BASELINE.json configurations through the shipped evaluation loop (`generate_attacks`), one
+GPU, synthetic data — informational companions of the bench line (which is configs[1]):
+
+  configs[2]  SpecRNet + mel-spec frontend, PGDL2-40 (eps 0.1), B = 128
+  configs[3]  RawNet3 attack model -> LCNN + LFCC target (transferability), FGSM and CW-100, B = 64
+  (plus configs[1] through the same loop, for a like-for-like number, and FAB on LCNN)
+
+Prints utterances/s over `--batches` global batches after one warm-up batch."""
+import argparse
+import sys
+import time
+from pathlib import Path
+
+import torch
+import yaml
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+from audio_deepfake_adversarial_attacks_amd.aa.aa_types import AttackEnum  # noqa: E402
+from audio_deepfake_adversarial_attacks_amd.datasets.synthetic import SyntheticDetectionDataset  # noqa: E402
+from audio_deepfake_adversarial_attacks_amd.evaluation import generate_attacks  # noqa: E402
+from audio_deepfake_adversarial_attacks_amd.utils import set_seed  # noqa: E402
+
+
+def cfg(name):
+    return yaml.safe_load((ROOT / "configs" / "aa_evaluation" / f"{name}.yaml").read_text())
+
+
+def run(label, target, attack_model, attack, batch, batches, workers=0):
+    cls, params = AttackEnum[attack].value
+    timings = []
+    sets = {n: SyntheticDetectionDataset(batch * n) for n in (2, batches)}   # generated outside the timed calls
+    for n in (2, 2, batches):                   # first call = warm-up (code objects, plans, weight transforms)
+        set_seed(42)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        rep = generate_attacks([None, None, None], cfg(target), "cuda:0", attack_model_config=cfg(attack_model),
+                               attack_method=cls, attack_params=params, batch_size=batch,
+                               dataset=sets[n], share_weights=target == attack_model, shuffle=False,
+                               num_workers=workers)
+        torch.cuda.synchronize()
+        timings.append(time.perf_counter() - t0)
+    # model construction, worker start-up, the first batch's load and the final report are inside both calls:
+    # difference = (batches - 2) batches of steady-state loop
+    per_batch = (timings[2] - timings[1]) / (batches - 2)
+    print(f"{label:58s} B={batch:4d}  {batch / per_batch:9.1f} utt/s  {per_batch * 1e3:9.1f} ms/batch  "
+          f"(acc {rep['adv_eval/accuracy']:.1f} %)", flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batches", type=int, default=6)
+    args = ap.parse_args()
+    run("configs[1] LCNN+LFCC, PGD-40 eps 0.003 (white box)", "lcnn", "lcnn", "PGD40_eps003", 128, args.batches)
+    run("configs[1] ... with 3 DataLoader workers (CLI default)", "lcnn", "lcnn", "PGD40_eps003", 128, args.batches, 3)
+    run("configs[2] SpecRNet+mel, PGDL2-40 eps 0.1 (white box)", "specrnet", "specrnet", "PGDL2_40", 128, args.batches)
+    run("configs[3] RawNet3 -> LCNN+LFCC, FGSM eps 0.0005", "lcnn", "rawnet3", "FGSM", 64, args.batches)
+    run("configs[3] RawNet3 -> LCNN+LFCC, CW-100 c = 1", "lcnn", "rawnet3", "CW", 64, 4)
+    run("           LCNN+LFCC, FAB (eta 10, 10 steps)", "lcnn", "lcnn", "FAB", 128, args.batches)
+
+
+if __name__ == "__main__":
+    main()
