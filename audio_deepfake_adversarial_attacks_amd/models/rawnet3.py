@@ -41,6 +41,33 @@ class AFMS(nn.Module):
         return (x + self.alpha) * y
 
 
+def _gemm_conv1d_enabled() -> bool:
+    import os
+    return os.environ.get("ADVSTEP_RAWNET3_GEMM_CONV", "1") != "0"
+
+
+def _same_conv1d(x: torch.Tensor, conv: nn.Conv1d) -> torch.Tensor:
+    """`conv(x)` for the dilated "same" Conv1d(width, width, 3, dilation=d, padding=d) of the Res2Net branches.
+
+    On a HIP device MIOpen (no tuned solver for these 128-channel dilated 1-D convolutions) runs them with its NAIVE
+    reference kernel — 5.9 ms each, 22 per forward: 130 ms of a 190 ms RawNet3 iteration at B = 64.  The same arithmetic
+    as k GEMMs over shifted views of the padded input, W[:, :, j] (Cout x Cin) . x[:, :, t + j d], goes to rocBLAS /
+    hipBLASLt instead (autograd included).  CPU tensors and any other geometry take the module itself."""
+    k, d = conv.kernel_size[0], conv.dilation[0]
+    if not (x.is_cuda and _gemm_conv1d_enabled() and conv.stride == (1,) and conv.groups == 1 and k % 2 == 1
+            and conv.padding == ((k // 2) * d,) and conv.padding_mode == "zeros"):
+        return conv(x)
+    T = x.shape[-1]
+    xp = torch.nn.functional.pad(x, ((k // 2) * d, (k // 2) * d))
+    out = None
+    for j in range(k):
+        term = torch.matmul(conv.weight[:, :, j], xp[:, :, j * d:j * d + T])
+        out = term if out is None else out + term
+    if conv.bias is not None:
+        out = out + conv.bias.view(1, -1, 1)
+    return out
+
+
 class Bottle2neck(nn.Module):
     """Res2Net bottleneck over time with hierarchical dilated convs (rawnet3.py:185-274)."""
 
@@ -73,7 +100,7 @@ class Bottle2neck(nn.Module):
         pieces, carry = [], None
         for i in range(self.nums):
             carry = groups[i] if i == 0 else carry + groups[i]
-            carry = self.bns[i](self.relu(self.convs[i](carry)))
+            carry = self.bns[i](self.relu(_same_conv1d(carry, self.convs[i])))
             pieces.append(carry)
         pieces.append(groups[self.nums])
         out = torch.cat(pieces, 1)
