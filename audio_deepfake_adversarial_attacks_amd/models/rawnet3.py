@@ -59,12 +59,13 @@ def _same_conv1d(x: torch.Tensor, conv: nn.Conv1d) -> torch.Tensor:
         return conv(x)
     T = x.shape[-1]
     xp = torch.nn.functional.pad(x, ((k // 2) * d, (k // 2) * d))
-    out = None
+    B = x.shape[0]
+    # bias and the running sum ride in the GEMM epilogue (C operand of baddbmm): no separate add kernels
+    out = conv.bias.view(1, -1, 1).expand(B, -1, T) if conv.bias is not None else None
     for j in range(k):
-        term = torch.matmul(conv.weight[:, :, j], xp[:, :, j * d:j * d + T])
-        out = term if out is None else out + term
-    if conv.bias is not None:
-        out = out + conv.bias.view(1, -1, 1)
+        wj = conv.weight[:, :, j].unsqueeze(0).expand(B, -1, -1)
+        xj = xp[:, :, j * d:j * d + T]
+        out = torch.bmm(wj, xj) if out is None else torch.baddbmm(out, wj, xj)
     return out
 
 
