@@ -210,6 +210,7 @@ def generate_attacks(
     num_workers: int = 3,
     device_pad: bool = True,
     wave_fake_trim: Optional[bool] = None,
+    return_scores: bool = False,
 ) -> Dict[str, float]:
     """Reference signature (:146-157) plus additive keywords: `dataset` (a ready Dataset yielding the reference's
     4-tuple; without it the `DetectionDataset` over `datasets_paths` is built as in the reference's `get_dataset`,
@@ -217,7 +218,9 @@ def generate_attacks(
     (white-box runs without checkpoints: copy the target's weights into the attack model), `shuffle`, `num_workers` (3 like the reference, :202 — the loop is launch-bound on the host,
     so collation belongs in worker processes),
     `device_pad` (real corpora: ship undecoded payloads and pad on the device) and `wave_fake_trim` (None = the
-    reference's default, the SoX silence trim, which needs a registered backend).  `batch_size` is the GLOBAL batch."""
+    reference's default, the SoX silence trim, which needs a registered backend) and `return_scores` (adds the whole job's
+    per-utterance `y_pred`, `y_pred_label`, `y` arrays, in rank order, to the returned report under "scores").
+    `batch_size` is the GLOBAL batch."""
     rank, world = rank_and_world()
     LOGGER.info("Loading data...")
 
@@ -300,6 +303,8 @@ def generate_attacks(
     report = metrics.adversarial_report(all_y, all_pred, all_label)
     report["adv_eval/accuracy"] = (n_correct / n_total) * 100  # :267 (from the all-reduced counters)
     report["num_total"] = n_total
+    if return_scores:
+        report["scores"] = {"y_pred": all_pred, "y_pred_label": all_label, "y": all_y}
     if rank == 0:
         LOGGER.info(format_report(report))
     return report

@@ -1,116 +1,188 @@
 #!/usr/bin/env python
-"""Headline benchmark: adversarial utterances / second, PGD-40 (L-inf, eps = 0.003, alpha = 2/255) on
-LCNN + LFCC over synthetic 4 s @ 16 kHz utterances (T = 64 600), 128 utterances per GPU (BASELINE.json configs[1];
-configs[4] is the same workload on 8 GPUs).
+"""Benchmark of the adversarial-evaluation hot loop on MI355X.  Default = the headline: adversarial utterances / second,
+PGD-40 (L-inf, eps = 0.003, alpha = 2/255) on LCNN + LFCC over synthetic 4 s @ 16 kHz utterances (T = 64 600), 128
+utterances per GPU (BASELINE.json configs[1]; configs[4] is the same workload on 8 GPUs).
 
 A "step" is one pass of the hot-loop body of evaluate_models_on_adversarial_attacks.py:211-265 over one batch that
-is already resident in HBM:  to_minmax -> PGD-40 (40 x [LCNN fwd + input-bwd under PyTorch-ROCm, fused HIP
-sign/project/clamp step]) -> revert_minmax -> target-model forward -> sigmoid / threshold.  After the K timed steps
-the per-utterance scores are aggregated once (RCCL all-reduce + all-gather when N > 1) inside the timed region.
+is already resident in HBM:  to_minmax -> attack (N x [model fwd + input-bwd, fused HIP update step]) ->
+revert_minmax -> target-model forward -> sigmoid / threshold.  After the K timed steps the per-utterance scores are
+aggregated once (RCCL all-reduce + all-gather when N > 1) inside the timed region.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config {1,2,3}]
 
-Rank 0 prints ONE JSON line.  `roofline` prices the dominant hand-written kernel (advstep_pgd_linf_step_f32,
-16 algorithmic bytes per waveform sample) with HIP events recorded on its launch stream inside the timed region;
-`cpu_baseline` times the CPU oracle ("port": oracle/attacks.py, torch CPU ops in the reference's order) on a bounded
-sample of the same workload on this box's host cores (rank 0, N = 1 only)."""
+With N > 1 and no launcher in the environment (WORLD_SIZE unset) the script starts its own N ranks — it re-executes
+itself under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` — so both
+`python bench.py --gpus 8` and the explicit launcher line work; rank 0 prints ONE JSON line either way.
+
+--config selects the BASELINE.json workload (the line's `metric` / `config.workload` name it):
+    1  configs[1]  LCNN + LFCC, PGD-40 L-inf eps 0.003, B = 128        roofline: advstep_pgd_linf_step_f32, 16 B/sample
+    2  configs[2]  SpecRNet + mel-spec, PGDL2-40 eps 0.1, B = 128      roofline: advstep_pgd_l2_step_f32,   16 B/sample
+    3  configs[3]  RawNet3 -> LCNN + LFCC transfer, FGSM + CW-100, B = 64 (a step attacks the batch with both)
+                                                                       roofline: advstep_cw_adam_step_f32,  32 B/sample
+
+`roofline` prices the dominant hand-written kernel of the workload with HIP events recorded on its launch stream
+inside the timed region; `cpu_baseline` times the CPU oracle ("port": oracle/attacks.py, torch CPU ops in the
+reference's order) on a bounded sample of the same workload on this box's host cores (rank 0, N = 1 only)."""
 import argparse
 import json
 import os
+import socket
 import sys
 import time
 from pathlib import Path
-
-import torch
-import torch.distributed as dist
 
 ROOT = Path(__file__).resolve().parent
 if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
 T = 64_600
-PER_GPU_BATCH = 128
-EPS, ALPHA, PGD_STEPS = 0.003, 2 / 255, 40
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-STEP_BYTES_PER_SAMPLE = 16     # adv + grad + orig read, adv written, f32
-LCNN_CONFIG = {"frontend_algorithm": ["lfcc"], "input_channels": 1}
+LCNN = ("lcnn", {"frontend_algorithm": ["lfcc"], "input_channels": 1})
+SPECRNET = ("specrnet", {"frontend_algorithm": ["mel_spec"], "input_channels": 2})
+RAWNET3 = ("rawnet3", {})
+
+# attacks are named by their AttackEnum member (aa/aa_types.py) so bench, CLI and tests run the same hyper-parameters;
+# `kernel` = (hip_ops entry point, algorithmic bytes per waveform sample per launch — SURVEY.md section 8(d))
+WORKLOADS = {
+    1: dict(tag="configs[1]", target=LCNN, attacked=LCNN, white_box=True, attacks=("PGD40_eps003",), batch=128,
+            metric="adversarial utterances/sec, PGD-40 LCNN+LFCC 4s@16kHz",
+            what="LCNN+LFCC, PGD-40 Linf eps=0.003 alpha=2/255 random start",
+            kernel=("pgd_linf_step", 16, "advstep_pgd_linf_step_f32 (flat_vec_kernel<3, PgdLinfOp>)")),
+    2: dict(tag="configs[2]", target=SPECRNET, attacked=SPECRNET, white_box=True, attacks=("PGDL2_40",), batch=128,
+            metric="adversarial utterances/sec, PGDL2-40 SpecRNet+mel-spec 4s@16kHz",
+            what="SpecRNet+mel-spec (2 channels), PGDL2-40 eps=0.1 alpha=0.2 random start",
+            kernel=("pgd_l2_step", 16, "advstep_pgd_l2_step_f32 (all kernels of one call)")),
+    3: dict(tag="configs[3]", target=LCNN, attacked=RAWNET3, white_box=False, attacks=("FGSM", "CW"), batch=64,
+            metric="adversarial utterances/sec, FGSM + CW-100 transfer pair RawNet3->LCNN+LFCC 4s@16kHz",
+            what="attack model RawNet3 (raw waveform), target LCNN+LFCC; every batch is attacked with FGSM eps=0.0005 "
+                 "and with CW c=1 kappa=0 steps=100 lr=0.01, each adversarial batch scored by the target",
+            kernel=("cw_adam_step", 32, "advstep_cw_adam_step_f32 (cw_adam_vec_kernel)")),
+}
+PROFILED = ("pgd_linf_step", "pgd_linf_init", "pgd_l2_step", "pgd_l2_init", "fgsm_step", "cw_adam_step",
+            "cw_tanh_sqdist", "cw_best_update", "minmax_normalize", "minmax_revert", "ce2_loss_grad")
 
 
-def parse():
+def parse(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=4)
-    p.add_argument("--warmup", type=int, default=2)
-    p.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="utterances per GPU per step")
+    p.add_argument("--steps", type=int, default=None, help="timed steps (default 4; 2 for --config 3)")
+    p.add_argument("--warmup", type=int, default=None, help="untimed steps (default 2; 1 for --config 3)")
+    p.add_argument("--config", type=int, default=1, choices=sorted(WORKLOADS), help="BASELINE.json configs[N]")
+    p.add_argument("--batch", type=int, default=None, help="utterances per GPU per step (default: the config's)")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-sample", type=int, default=8, help="utterances in the CPU-baseline sample (one batch)")
-    p.add_argument("--cpu-threads", type=int, default=0, help="host threads for the CPU baseline (0 = min(cores, 64))")
-    return p.parse_args()
+    p.add_argument("--cpu-threads", type=int, default=0, help="host threads for the CPU baseline (0 = swept default)")
+    p.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
+                   help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only for single-GPU rehearsals)")
+    p.add_argument("--share-device", action="store_true",
+                   help="rehearsal on a box with fewer GPUs than ranks: every rank uses cuda:0 (needs --backend gloo)")
+    a = p.parse_args(argv)
+    if a.steps is None:
+        a.steps = 2 if a.config == 3 else 4
+    if a.warmup is None:
+        a.warmup = 1 if a.config == 3 else 2
+    return a
 
 
-def build_models(device):
+def launcher_command(argv, gpus, port=None):
+    """The command `python bench.py --gpus N ...` replaces itself with when no launcher set WORLD_SIZE."""
+    if port is None:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()), *argv]
+
+
+def build_models(spec, device):
     from audio_deepfake_adversarial_attacks_amd.models.models import get_model
     from audio_deepfake_adversarial_attacks_amd.utils import set_seed
     set_seed(42)
-    target = get_model("lcnn", dict(LCNN_CONFIG), device).to(device)
-    attacked = get_model("lcnn", dict(LCNN_CONFIG), device).to(device)
-    attacked.load_state_dict(target.state_dict())  # white-box: same weights
+    target = get_model(spec["target"][0], dict(spec["target"][1]), device).to(device)
+    attacked = get_model(spec["attacked"][0], dict(spec["attacked"][1]), device).to(device)
+    if spec["white_box"]:
+        attacked.load_state_dict(target.state_dict())  # same weights
     return target.eval(), attacked.eval()
 
 
-def cpu_baseline(n_utt: int, threads: int):
+def cpu_baseline(config: int, threads: int, iterations: float = 0.0):
     """Oracle ("port") on the host cores: the same per-batch body on a bounded sample of the same workload, run in
     a separate process (oracle/cpu_baseline.py) after the GPU measurement."""
     import subprocess
-    cmd = [sys.executable, "-m", "oracle.cpu_baseline", "--utterances", str(n_utt), "--threads", str(threads)]
+    cmd = [sys.executable, "-m", "oracle.cpu_baseline", "--config", str(config), "--threads", str(threads),
+           "--iterations", str(iterations)]
+    fail = {"value": None, "unit": "utterances/s", "cores": threads, "kind": "port"}
     try:
-        proc = subprocess.run(cmd, cwd=str(ROOT), capture_output=True, text=True, timeout=600)
+        proc = subprocess.run(cmd, cwd=str(ROOT), capture_output=True, text=True, timeout=900)
         lines = [l for l in proc.stdout.splitlines() if l.startswith("{")]
         if proc.returncode == 0 and lines:
             return json.loads(lines[-1])
-        return {"value": None, "unit": "utterances/s", "cores": threads, "kind": "port",
-                "sample": f"failed rc={proc.returncode}: {proc.stderr[-300:]}"}
+        return dict(fail, sample=f"failed rc={proc.returncode}: {proc.stderr[-300:]}")
     except subprocess.TimeoutExpired:
-        return {"value": None, "unit": "utterances/s", "cores": threads, "kind": "port", "sample": "timed out (600 s)"}
+        return dict(fail, sample="timed out (900 s)")
+
+
+def measured_traffic(entry_point: str, B: int):
+    """HBM bytes per launch of the priced kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE in
+    separate runs, gfx950 corrections applied; tools/hbm_traffic.py writes the file).  Counters cannot be read inside
+    an un-profiled run, so the line says where the figure comes from; null when no pass exists for this batch size."""
+    path = ROOT / "profiles" / "hbm_traffic.json"
+    if not path.exists():
+        return None, "no PMC pass committed"
+    table = json.loads(path.read_text())
+    row = table.get("entry_points", {}).get(entry_point)
+    if not row or row.get("batch") != B:
+        return None, f"no PMC pass for {entry_point} at B={B}"
+    return row["hbm_bytes_per_launch"], f"profiles/hbm_traffic.json: {table['source']}"
 
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        os.execv(sys.executable, launcher_command(sys.argv[1:], args.gpus))      # never returns
+
+    import torch
+    import torch.distributed as dist
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
-                         f"--nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher set WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the attack kernels have no CPU fallback)")
+    if args.share_device:
+        if args.backend != "gloo":
+            raise SystemExit("--share-device needs --backend gloo (RCCL refuses two ranks on one device)")
+        local_rank = 0
+    elif torch.cuda.device_count() < world:
+        raise SystemExit(f"--gpus {world} but this node exposes {torch.cuda.device_count()} HIP device(s)")
     torch.cuda.set_device(local_rank)
     device = torch.device(f"cuda:{local_rank}")
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=device)  # RCCL over xGMI
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)  # RCCL over xGMI
+        else:
+            dist.init_process_group(backend="gloo")
 
-    from audio_deepfake_adversarial_attacks_amd import hip_ops, torchattacks
+    from audio_deepfake_adversarial_attacks_amd import hip_ops, metrics
+    from audio_deepfake_adversarial_attacks_amd.aa.aa_types import AttackEnum
     from audio_deepfake_adversarial_attacks_amd.datasets.synthetic import synthetic_waveforms
     from audio_deepfake_adversarial_attacks_amd.evaluation import (aggregate_across_ranks, attack_batch, score_batch)
-    from audio_deepfake_adversarial_attacks_amd import metrics
 
-    target, attacked = build_models(device)
-    atk = torchattacks.PGD(attacked, eps=EPS, alpha=ALPHA, steps=PGD_STEPS, random_start=True)
-    atk.set_training_mode(model_training=True, batchnorm_training=False)
+    spec = WORKLOADS[args.config]
+    target, attacked = build_models(spec, device)
+    attacks = []
+    for member in spec["attacks"]:
+        cls, params = AttackEnum[member].value
+        atk = cls(attacked, **params)
+        atk.set_training_mode(model_training=True, batchnorm_training=False)   # evaluate_...:170
+        attacks.append((member, atk))
     torch.manual_seed(42 + rank)  # per-rank random starts
 
-    B = args.batch
+    B = args.batch or spec["batch"]
     n_batches = args.warmup + args.steps
     x_all, y_all = synthetic_waveforms(B * n_batches, T, seed=1234 + rank)
     x_all, y_all = x_all.to(device), y_all.to(device)   # inputs resident in HBM before the clock starts
-
-    def one_step(i):
-        bx, by = x_all[i * B:(i + 1) * B], y_all[i * B:(i + 1) * B]
-        adv = attack_batch(atk, bx, by)
-        preds, labels = score_batch(target, adv)
-        return preds, labels, by
 
     def sync_all():
         torch.cuda.synchronize()
@@ -118,43 +190,46 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Warm-up = the timed loop's body, bookkeeping kernels and launch profiling included: the first launch of any kernel
-    # loads its code object (tens of milliseconds in the first process on a fresh box), which must not land in a timed step.
-    profiled = ("pgd_linf_step", "pgd_linf_init", "minmax_normalize", "minmax_revert", "ce2_loss_grad")
-
     def timed_loop(first, last):
-        preds, labels, ys = [], [], []
-        correct = torch.zeros((), dtype=torch.int64, device=device)
+        """The loop body for batches [first, last): per attack the scores, labels and a per-step event mark."""
+        out = {m: ([], [], []) for m, _ in attacks}
+        correct = {m: torch.zeros((), dtype=torch.int64, device=device) for m, _ in attacks}
         marks = [torch.cuda.Event(enable_timing=True)]
         marks[0].record()
         for i in range(first, last):
-            p, l, by = one_step(i)
-            preds.append(p), labels.append(l), ys.append(by)
-            correct += (l == by.int()).sum()
-            marks.append(torch.cuda.Event(enable_timing=True))
-            marks[-1].record()
-        return preds, labels, ys, correct, marks
+            bx, by = x_all[i * B:(i + 1) * B], y_all[i * B:(i + 1) * B]
+            for m, atk in attacks:
+                adv = attack_batch(atk, bx, by)
+                p, l = score_batch(target, adv)
+                out[m][0].append(p), out[m][1].append(l), out[m][2].append(by)
+                correct[m] += (l == by.int()).sum()
+                marks.append(torch.cuda.Event(enable_timing=True))
+                marks[-1].record()
+        return out, correct, marks
 
+    def aggregate(out, correct, n_steps):
+        total = torch.tensor(B * n_steps, dtype=torch.int64, device=device)
+        return {m: aggregate_across_ranks(torch.cat(out[m][0]), torch.cat(out[m][1]), torch.cat(out[m][2]),
+                                          correct[m], total) for m, _ in attacks}
+
+    # Warm-up = the timed loop's body, bookkeeping kernels and launch profiling included: the first launch of any kernel
+    # loads its code object (tens of milliseconds in the first process on a fresh box), which must not land in a timed
+    # step ... and the end-of-run aggregate (RCCL communicator set-up for world > 1, the D2H copy kernels otherwise).
     if args.warmup > 0:
-        hip_ops.start_profile(*profiled)
-        w = timed_loop(0, args.warmup)
-        # ... and the end-of-run aggregate (RCCL communicator set-up for world > 1, the D2H copy kernels otherwise)
-        aggregate_across_ranks(torch.cat(w[0]), torch.cat(w[1]), torch.cat(w[2]), w[3],
-                               torch.tensor(B * args.warmup, dtype=torch.int64, device=device))
+        hip_ops.start_profile(*PROFILED)
+        w_out, w_correct, _ = timed_loop(0, args.warmup)
+        aggregate(w_out, w_correct, args.warmup)
         hip_ops.stop_profile()
-        del w
-    elif world > 1:  # RCCL communicator warm-up outside the timed region
-        aggregate_across_ranks(torch.zeros(B, device=device), torch.zeros(B, device=device),
-                               torch.zeros(B, device=device), torch.zeros((), device=device),
-                               torch.zeros((), device=device))
+        del w_out, w_correct
+    elif world > 1:  # communicator warm-up outside the timed region
+        z = torch.zeros(B, device=device)
+        aggregate_across_ranks(z, z, z, torch.zeros((), device=device), torch.zeros((), device=device))
     sync_all()
 
-    hip_ops.start_profile(*profiled)
+    hip_ops.start_profile(*PROFILED)
     t0 = time.perf_counter()
-    preds, labels, ys, correct, marks = timed_loop(args.warmup, n_batches)
-    total = torch.tensor(B * args.steps, dtype=torch.int64, device=device)
-    all_pred, all_label, all_y, n_correct, n_total = aggregate_across_ranks(
-        torch.cat(preds), torch.cat(labels), torch.cat(ys), correct, total)
+    out, correct, marks = timed_loop(args.warmup, n_batches)
+    gathered = aggregate(out, correct, args.steps)
     sync_all()
     elapsed = time.perf_counter() - t0
     kernel_ms = hip_ops.stop_profile()
@@ -165,18 +240,17 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
-        report = metrics.adversarial_report(all_y, all_pred, all_label)
         utterances = B * args.steps * world
-        step_ms = kernel_ms["pgd_linf_step"]
+        entry, bytes_per_sample, kernel_name = spec["kernel"]
+        step_ms = kernel_ms[entry]
         avg_ms = sum(step_ms) / len(step_ms)
-        launch_bytes = STEP_BYTES_PER_SAMPLE * B * T
+        launch_bytes = bytes_per_sample * B * T
         achieved = launch_bytes / (avg_ms * 1e-3) / 1e9
-        traffic = None
-        pmc = ROOT / "profiles" / "pgd_linf_step_pmc.json"  # per-launch HBM bytes from the rocprofv3 --pmc passes
-        if pmc.exists() and B == PER_GPU_BATCH:
-            traffic = json.loads(pmc.read_text()).get("hbm_bytes_per_launch")
+        traffic, provenance = measured_traffic(entry, B)
+        each = [a.elapsed_time(b) for a, b in zip(marks[:-1], marks[1:])]
+        k = len(attacks)
         line = {
-            "metric": "adversarial utterances/sec, PGD-40 LCNN+LFCC 4s@16kHz",
+            "metric": spec["metric"],
             "value": utterances / elapsed,
             "unit": "utterances/s",
             "n_gpus": world,
@@ -189,32 +263,48 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"LCNN+LFCC, PGD-40 Linf eps=0.003 alpha=2/255 random start, batch={B}/GPU, T={T} "
-                            f"(BASELINE.json configs[1]); step = minmax -> attack -> revert -> target fwd -> score",
+                "workload": f"{spec['what']}, batch={B}/GPU, T={T} (BASELINE.json {spec['tag']}); "
+                            f"step = minmax -> attack -> revert -> target fwd -> score",
                 "global_batch": B * world,
-                "sharding": f"{world} independent contiguous shards, no per-step collective; one RCCL "
-                            f"all-reduce + all-gather of the scores after the last step",
-                "weights": "seeded random init (set_seed(42)), target == attacked (white-box)",
+                "sharding": f"{world} independent contiguous shards, no per-step collective; one "
+                            f"{'RCCL' if args.backend == 'nccl' else args.backend} all-reduce + all-gather of the "
+                            f"scores after the last step",
+                "weights": "seeded random init (set_seed(42))" + (", target == attacked (white-box)"
+                                                                    if spec["white_box"] else ", transfer (two models)"),
             },
             "roofline": {
-                "kernel": "advstep_pgd_linf_step_f32 (flat_vec_kernel<3, PgdLinfOp>)",
+                "kernel": kernel_name,
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
+                "traffic_provenance": provenance,
                 "algorithmic_bytes_per_launch": launch_bytes,
                 "avg_launch_ms": avg_ms,
                 "launches_timed": len(step_ms),
             },
-            "attack_kernel_ms_per_step": {k: (sum(v) / args.steps if v else 0.0) for k, v in kernel_ms.items()},
-            "ms_each_step": [round(a.elapsed_time(b), 2) for a, b in zip(marks[:-1], marks[1:])],
-            "adv_eval": {k.split("/")[1]: round(v, 4) for k, v in report.items()},
+            "attack_kernel_ms_per_step": {n: sum(v) / args.steps for n, v in kernel_ms.items() if v},
+            "ms_each_step": [round(sum(each[i * k:(i + 1) * k]), 2) for i in range(args.steps)],
+            "adv_eval": {},
         }
+        for j, (m, _) in enumerate(attacks):
+            all_pred, all_label, all_y, _, _ = gathered[m]
+            rep = metrics.adversarial_report(all_y, all_pred, all_label)
+            line["adv_eval"][m] = {key.split("/")[1]: round(v, 4) for key, v in rep.items()}
+            if k > 1:   # the pair of configs[3], separately (HIP-event time of each attack's share of the steps)
+                ms = sum(each[j::k]) / args.steps
+                line.setdefault("per_attack", {})[m] = {"ms_per_batch": round(ms, 2),
+                                                        "utterances_per_s": round(B / (ms * 1e-3), 1)}
+        if k == 1:
+            line["adv_eval"] = line["adv_eval"][attacks[0][0]]
         if world == 1 and not args.no_cpu_baseline:
-            threads = args.cpu_threads or min(os.cpu_count() or 1, 16)  # fastest of 8..128 on the 256-thread EPYC box (profiles/)
-            line["cpu_baseline"] = cpu_baseline(args.cpu_sample, threads)
+            # CW stops early on its own cost (cw.py:107-110): price the CPU leg at the iterations the GPU run executed
+            cw_iters = len(kernel_ms.get("cw_adam_step", ())) / args.steps if args.config == 3 else 0.0
+            if cw_iters:
+                line["per_attack"]["CW"]["iterations_per_batch"] = cw_iters
+            line["cpu_baseline"] = cpu_baseline(args.config, args.cpu_threads, cw_iters)
         print(json.dumps(line), flush=True)
 
     if world > 1:

@@ -1,0 +1,118 @@
+"""BASELINE.json configs[4] rehearsed on ONE device: two ranks (one process each, gloo — RCCL refuses two ranks on the
+same GPU) run the shipped sharded loop, and `bench.py --gpus 2` launches its own ranks.  What runs here is everything
+of the 8-GPU path except the RCCL transport itself: rank discovery, contiguous shards of every global batch, per-rank
+models / streams / workspaces, the end-of-run all-reduce + all-gather, rank 0's report (SURVEY.md section 8-e;
+replaces nn.DataParallel, reference evaluate_models_on_adversarial_attacks.py:163,167)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = Path(__file__).resolve().parent.parent
+GLOBAL_BATCH, N_ITEMS, SEED = 16, 40, 42            # 2 complete global batches; 8 utterances are dropped (drop_last)
+ATTACK = {"eps": 0.003, "steps": 3, "random_start": False}   # deterministic: the shard replay needs no RNG agreement
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _config():
+    import yaml
+    return yaml.safe_load((ROOT / "configs" / "aa_evaluation" / "lcnn.yaml").read_text())
+
+
+def _evaluate(dataset, batch_size, shuffle):
+    from audio_deepfake_adversarial_attacks_amd import torchattacks
+    from audio_deepfake_adversarial_attacks_amd.evaluation import generate_attacks
+    from audio_deepfake_adversarial_attacks_amd.utils import set_seed
+    cfg = _config()
+    set_seed(SEED)                                     # equal replicas on every rank and in the replay
+    return generate_attacks([None, None, None], cfg, "cuda:0", attack_model_config=cfg, attack_method=torchattacks.PGD,
+                            attack_params=dict(ATTACK), batch_size=batch_size, dataset=dataset, share_weights=True,
+                            shuffle=shuffle, num_workers=0, return_scores=True)
+
+
+def _worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    from torch.utils.data import Subset
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, str(ROOT))
+    from audio_deepfake_adversarial_attacks_amd.datasets.synthetic import SyntheticDetectionDataset
+    from audio_deepfake_adversarial_attacks_amd.evaluation import ShardedBatchSampler
+    torch.cuda.set_device(0)
+    data = SyntheticDetectionDataset(N_ITEMS)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sharded = _evaluate(data, GLOBAL_BATCH, shuffle=True)
+    finally:
+        dist.destroy_process_group()
+    # the same rows through the single-process loop: this rank's contiguous slices, batch = the shard size, so the
+    # LFCC batch-wide dB floor sees the same rows as in the sharded run
+    mine = sum(ShardedBatchSampler(N_ITEMS, GLOBAL_BATCH, rank, world, shuffle=True, seed=SEED), [])
+    alone = _evaluate(Subset(data, mine), GLOBAL_BATCH // world, shuffle=False)
+    np.savez(Path(out_dir) / f"rank{rank}.npz", mine=np.array(mine),
+             sharded_pred=sharded["scores"]["y_pred"], sharded_label=sharded["scores"]["y_pred_label"],
+             sharded_y=sharded["scores"]["y"], alone_pred=alone["scores"]["y_pred"],
+             alone_label=alone["scores"]["y_pred_label"], alone_y=alone["scores"]["y"],
+             report=json.dumps({k: v for k, v in sharded.items() if k != "scores"}))
+
+
+@pytest.mark.timeout(900)
+def test_two_ranks_on_one_gpu_equal_single_process_shards(cuda, tmp_path):
+    import torch.multiprocessing as mp
+    from audio_deepfake_adversarial_attacks_amd import metrics
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [np.load(tmp_path / f"rank{k}.npz") for k in range(world)]
+    per_rank = (N_ITEMS // GLOBAL_BATCH) * GLOBAL_BATCH // world
+    assert not set(r[0]["mine"]) & set(r[1]["mine"]) and len(r[0]["mine"]) == len(r[1]["mine"]) == per_rank
+    # every rank ends with the same complete table and the same report
+    for key in ("sharded_pred", "sharded_label", "sharded_y", "report"):
+        assert np.array_equal(r[0][key], r[1][key]), key
+    # rank k's rows of the gathered table == a single-process run over rank k's shard, bit for bit
+    for k in range(world):
+        rows = slice(k * per_rank, (k + 1) * per_rank)
+        assert np.array_equal(r[0]["sharded_pred"][rows], r[k]["alone_pred"]), f"rank {k} scores"
+        assert np.array_equal(r[0]["sharded_label"][rows], r[k]["alone_label"])
+        assert np.array_equal(r[0]["sharded_y"][rows], r[k]["alone_y"])
+    assert np.unique(r[0]["sharded_pred"]).size > per_rank      # not a constant detector: the comparison has teeth
+    # the gathered report == the report over the concatenated single-process shard runs
+    pred = np.concatenate([r[k]["alone_pred"] for k in range(world)])
+    label = np.concatenate([r[k]["alone_label"] for k in range(world)])
+    y = np.concatenate([r[k]["alone_y"] for k in range(world)])
+    want = metrics.adversarial_report(y, pred, label)
+    got = json.loads(str(r[0]["report"]))
+    for key, value in want.items():
+        if key == "adv_eval/accuracy":
+            assert got[key] == pytest.approx(100.0 * float((label == y).mean()), abs=1e-12)
+        else:
+            assert got[key] == pytest.approx(value, abs=1e-12), key
+    assert got["num_total"] == world * per_rank
+
+
+@pytest.mark.timeout(900)
+def test_bench_launches_its_own_ranks(cuda):
+    """`python bench.py --gpus 2` with no launcher in the environment must start two ranks itself and print ONE JSON
+    line (rehearsed on one device: --share-device --backend gloo; on a >= 2-GPU node the defaults use RCCL)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--batch", "8",
+           "--share-device", "--backend", "gloo"]
+    proc = subprocess.run(cmd, cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=800)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    lines = [l for l in proc.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, proc.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 16 and line["scaling"] == "weak"
+    assert line["value"] == pytest.approx(16 / (line["ms_per_step"] * 1e-3), rel=1e-6)
+    assert "cpu_baseline" not in line and line["roofline"]["launches_timed"] == 40
