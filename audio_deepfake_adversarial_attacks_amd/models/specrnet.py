@@ -40,6 +40,11 @@ class Residual_block2D(nn.Module):
 
     def forward(self, x):
         # specrnet.py:73-91.  NB conv1 consumes x, not lrelu(bn1(x)) — reference behaviour, kept.
+        if not self.first and self.bn1.training:
+            # the reference computes bn1(x) and discards it (:75-78); in train mode that still updates bn1's running
+            # statistics, which end up in checkpoints — keep the side effect, skip the wasted pass otherwise
+            with torch.no_grad():
+                self.bn1(x)
         out = self.conv2(self.lrelu(self.bn2(self.conv1(x))))
         identity = self.conv_downsample(x) if self.downsample else x
         return self.mp(out + identity)

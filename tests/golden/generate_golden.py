@@ -5,8 +5,8 @@ Run ONLY in the build container, where the Python reference is mounted read-only
 
     python tests/golden/generate_golden.py
 
-It imports the reference's own modules (adversarial_attacks.torchattacks, src.aa.utils, src.metrics and the
-BaseLCNN / BaseSpecRNet bodies), runs them on small seeded inputs with torch CPU kernels and stores inputs,
+It imports the reference's own modules (adversarial_attacks.torchattacks, src.aa.utils, src.metrics, the
+BaseLCNN / BaseSpecRNet bodies and RawNet3 behind its first layer), runs them on small seeded inputs with torch CPU kernels and stores inputs,
 intermediate tensors and outputs as .npz files.  The .npz files are data (inputs + expected outputs); no
 reference source travels.  The GPU box never runs this script (there is no /root/reference there).
 
@@ -487,7 +487,55 @@ def gen_model_bodies():
         logits = body(spec)
     out = {f"sd_{k}": npy(v) for k, v in body.state_dict().items()}
     out.update({"spec": npy(spec), "logits": npy(logits)})
+    # attack mode (attack.py:311-319): train() with BatchNorm in eval — the GRU then runs its training-mode code path
+    body.train()
+    for m in body.modules():
+        if "BatchNorm" in m.__class__.__name__ or "Dropout" in m.__class__.__name__:
+            m.eval()
+    s = spec.clone().requires_grad_(True)
+    o = body(s)
+    out["logits_attackmode"] = npy(o)
+    out["grad_spec"] = npy(torch.autograd.grad(o.sum(), s)[0])
     np.savez_compressed(OUT / "specrnet_body.npz", **out)
+
+
+def gen_rawnet3_body():
+    """Everything the reference's RawNet3 computes after its first layer (src/models/rawnet3.py:81-137, 161-274).
+    `asteroid_filterbanks` (absent here) is replaced by tests/helpers.FixedEncoder, which returns a recorded tensor in
+    place of the sinc encoder's output: the recorded logits / gradients are functions of that tensor only, and the sinc
+    encoder itself is NOT pinned.  Full-size model (C = 1024); weights by the seeded recipe of helpers."""
+    import json
+
+    sys.path.insert(0, str(OUT.parent))
+    import helpers
+
+    afb = types.ModuleType("asteroid_filterbanks")
+    afb.Encoder = helpers.FixedEncoder
+    afb.ParamSincFB = lambda *a, **k: None
+    sys.modules["asteroid_filterbanks"] = afb
+    sys.modules.pop("src.models.rawnet3", None)
+    from src.models import rawnet3 as ref_rawnet3
+
+    model = helpers.rawnet3_fixture_weights(ref_rawnet3.prepare_model).eval()
+    g = torch.Generator().manual_seed(83)
+    frames = 900                                        # 900 -> pool 5 -> 180 -> pool 3 -> 60 (rawnet3.py:35-41)
+    h = torch.randn(2, 256, frames, generator=g) * 0.3
+    x = torch.rand(2, 16_000, generator=g)              # goes through preprocess only; conv1 ignores it
+    model.conv1.h = h
+    with torch.no_grad():
+        logits = model(x)
+    out = {"h": npy(h), "x": npy(x), "logits": npy(logits),
+           "digests": np.array(json.dumps(helpers.tensor_digests(model.state_dict())))}
+    model.train()
+    for m in model.modules():
+        if "BatchNorm" in m.__class__.__name__ or "Dropout" in m.__class__.__name__:
+            m.eval()
+    hh = h.clone().requires_grad_(True)
+    model.conv1.h = hh
+    o = model(x)
+    out["logits_attackmode"] = npy(o)
+    out["grad_h"] = npy(torch.autograd.grad(o.sum(), hh)[0])
+    np.savez_compressed(OUT / "rawnet3_body.npz", **out)
 
 
 def gen_datasets():
@@ -608,6 +656,7 @@ def main():
     gen_trainer()
     gen_metrics()
     gen_model_bodies()
+    gen_rawnet3_body()
     gen_datasets()
     for p in sorted(OUT.glob("*.npz")):
         print(f"{p.name}: {p.stat().st_size / 1e6:.2f} MB")

@@ -22,6 +22,53 @@ def surrogate_from(fixture: dict) -> Surrogate:
     return m.eval()
 
 
+class FixedEncoder(torch.nn.Module):
+    """Stand-in for RawNet3's sinc encoder (`conv1`, third-party and parity-unpinned): returns the tensor it was
+    given, so everything the reference computes AFTER conv1 can be pinned."""
+
+    def __init__(self, *_, **__):
+        super().__init__()
+        self.h = None
+
+    def forward(self, x):
+        return self.h
+
+
+RAWNET3_SEED = 81
+
+
+def rawnet3_fixture_weights(make_model):
+    """The full-size RawNet3 (15.5 M parameters: too large to store) of tests/golden/rawnet3_body.npz, rebuilt from a
+    seed: default initialisation under torch.manual_seed, then non-trivial BatchNorm statistics / affine terms and AFMS
+    alphas drawn from a dedicated generator in sorted key order.  The fixture stores a SHA-256 per tensor (taken from the
+    REFERENCE class built with this recipe), which the tests check before comparing outputs."""
+    torch.manual_seed(RAWNET3_SEED)
+    model = make_model()
+    g = torch.Generator().manual_seed(RAWNET3_SEED + 1)
+    with torch.no_grad():
+        for key, value in sorted(model.state_dict().items()):
+            if key.startswith("conv1."):
+                continue
+            if key.endswith("running_mean"):
+                value.copy_(torch.empty(value.shape).uniform_(-0.2, 0.2, generator=g))
+            elif key.endswith("running_var"):
+                value.copy_(torch.empty(value.shape).uniform_(0.5, 1.5, generator=g))
+            elif ".bn" in key or key.startswith("bn") or key.startswith("attention.2."):
+                if key.endswith("weight"):
+                    value.copy_(torch.empty(value.shape).uniform_(0.8, 1.2, generator=g))
+                elif key.endswith("bias"):
+                    value.copy_(torch.empty(value.shape).uniform_(-0.1, 0.1, generator=g))
+            elif key.endswith("afms.alpha"):
+                value.copy_(torch.empty(value.shape).uniform_(0.7, 1.3, generator=g))
+    return model
+
+
+def tensor_digests(state_dict, skip=("conv1.",)):
+    import hashlib
+    return {k: hashlib.sha256(np.ascontiguousarray(v.detach().cpu().numpy()).tobytes()).hexdigest()
+            for k, v in state_dict.items() if not k.startswith(skip)}
+
+
 def rand01(shape, seed):
     rng = np.random.default_rng(seed)
     return rng.random(shape, dtype=np.float32)

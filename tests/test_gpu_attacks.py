@@ -147,19 +147,24 @@ def test_attacks_on_lcnn_every_launch_checked(cuda, checked, lcnn_model, attack,
     lcnn_model.eval()
 
 
-def test_fgsm_on_lcnn_agrees_with_cpu_oracle(cuda, lcnn_model):
+def test_fgsm_on_lcnn_agrees_with_cpu_oracle(cuda, lcnn_model, parity_record):
     """BASELINE.json configs[0] (LCNN + LFCC, FGSM eps = 0.001, batch 8) — GPU product path vs the CPU oracle run of
     the same weights and data.  Cross-device conv/FFT rounding flips sign(grad) only where |grad| is at noise level
-    (the reference disagrees with ITSELF at 6 / 516 800 samples between 1 and 8 CPU threads)."""
+    (the reference disagrees with ITSELF at 6 / 516 800 samples between 1 and 8 CPU threads).
+    Stated rule: a sample's perturbation sign may differ only where the CPU gradient satisfies
+    |grad| <= FLIP_K * max|grad| of its utterance; everywhere else the perturbed waveform is within 1e-5 max-abs."""
     import copy
     from audio_deepfake_adversarial_attacks_amd import torchattacks
     from audio_deepfake_adversarial_attacks_amd.aa import utils as aa_utils
     from audio_deepfake_adversarial_attacks_amd.datasets.synthetic import synthetic_waveforms
+    FLIP_K, MIN_AGREEMENT = 2e-3, 0.9995
     x, y = synthetic_waveforms(8, seed=1234)
     cpu_model = copy.deepcopy(lcnn_model).cpu()
     x01_cpu, mn, mx = OA.to_minmax(x)
     with OA.attack_mode(cpu_model):
+        grad_cpu = OA._cost_and_grad(cpu_model, x01_cpu.clone().detach(), y)
         want01 = OA.fgsm(cpu_model, x01_cpu, y, eps=0.001)
+    assert torch.equal(want01, torch.clamp(x01_cpu + 0.001 * grad_cpu.sign(), min=0, max=1))
     want = OA.revert_minmax(want01, mn, mx)
 
     atk = armed(torchattacks.FGSM, lcnn_model, eps=0.001)
@@ -168,10 +173,18 @@ def test_fgsm_on_lcnn_agrees_with_cpu_oracle(cuda, lcnn_model):
     assert torch.equal(g01.cpu(), x01_cpu)
     got01 = atk(g01, y.to(cuda))
     got = aa_utils.revert_minmax(got01, gmn, gmx).cpu()
-    agree = sign_agreement(got01.cpu(), want01, x01_cpu)
-    assert agree >= 0.995, agree
     same = (got01.cpu() - x01_cpu).sign() == (want01 - x01_cpu).sign()
-    assert (got - want).abs()[same].max().item() <= 1e-5               # the north-star bound on agreeing samples
+    rel = grad_cpu.abs() / grad_cpu.abs().amax(dim=1, keepdim=True)
+    flipped = rel[~same]
+    fig = {"samples": same.numel(), "sign_flips": int((~same).sum()), "agreement": same.float().mean().item(),
+           "max_abs_on_agreeing_samples": (got - want).abs()[same].max().item(),
+           "flipped_grad_over_row_max_worst": flipped.max().item() if flipped.numel() else 0.0,
+           "flipped_grad_over_row_max_median": flipped.median().item() if flipped.numel() else 0.0,
+           "share_of_all_samples_below_flip_k": (rel <= FLIP_K).float().mean().item(), "flip_k": FLIP_K}
+    parity_record["configs0_fgsm_lcnn_gpu_vs_cpu_oracle"] = fig
+    assert fig["agreement"] >= MIN_AGREEMENT, fig
+    assert fig["flipped_grad_over_row_max_worst"] <= FLIP_K, fig       # flips happen only at noise-level gradients
+    assert fig["max_abs_on_agreeing_samples"] <= 1e-5, fig             # the north-star bound
     assert (got - want).abs().max().item() <= 2 * 0.001 * (mx - mn).max().item() * (1 + 1e-5)
 
 

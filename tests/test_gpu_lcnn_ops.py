@@ -235,7 +235,7 @@ def test_conv5_mfm_pool2_requires_frozen_weights(L, cuda):
         L.conv5_mfm_pool2(torch.randn(1, 2, 8, 8, device=cuda), w.detach(), None)
 
 
-def test_lcnn_with_fused_first_block_agrees_with_miopen_path(cuda, monkeypatch):
+def test_lcnn_with_fused_first_block_agrees_with_miopen_path(cuda, monkeypatch, parity_record):
     """Whole LCNN, attack mode, frozen parameters: fused first block + fused 1x1 blocks vs MIOpen convolutions.  The two
     convolutions round differently, so logits agree to float tolerance and input gradients to a small relative error."""
     from audio_deepfake_adversarial_attacks_amd.models.models import get_model
@@ -266,8 +266,12 @@ def test_lcnn_with_fused_first_block_agrees_with_miopen_path(cuda, monkeypatch):
     # different (equally valid) float rounding inside the convolution flips a handful of near-tie winners among the
     # 33 M max-feature-map / pool decisions; each flip re-routes one gradient entry.  Sparse, bounded differences:
     off = (g0 - g1).abs() > 1e-3 * g0.abs().max()
-    assert off.float().mean().item() <= 1e-3
-    assert (g0 - g1).norm().item() / g0.norm().item() <= 2e-2
+    fig = {"logit_max_abs": (z0 - z1).abs().max().item(), "grad_rel_l2": (g0 - g1).norm().item() / g0.norm().item(),
+           "grad_entries": g0.numel(), "grad_entries_off_by_1e-3_of_max": int(off.sum()),
+           "grad_max_abs_over_max": ((g0 - g1).abs().max() / g0.abs().max()).item()}
+    parity_record["lcnn_fused_kernels_vs_miopen_path"] = fig
+    assert off.float().mean().item() <= 1e-3, fig
+    assert fig["grad_rel_l2"] <= 2e-2, fig
     for p in model.parameters():
         p.requires_grad_(True)
 

@@ -1,0 +1,92 @@
+"""`-m gpu`: the detectors' SHIPPED device paths (fused HIP kernels with frozen parameters, i.e. what runs inside an
+attack) against the logits and input gradients the REFERENCE's own model classes produced on CPU
+(tests/golden/{lcnn,specrnet,rawnet3}_body.npz — reference src/models/lcnn.py:166-208, specrnet.py:141-181,
+rawnet3.py:81-137).  Tolerances are float32 cross-device bounds, stated per test; the measured figures go to the parity
+record (profiles/r02_parity.json)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+
+
+def sd_of(fixture):
+    return {k[3:]: T(v) for k, v in fixture.items() if k.startswith("sd_")}
+
+
+def attack_mode_frozen(model):
+    """attack.py:311-319 + the parameter freeze Attack.__call__ applies: the fused kernels engage."""
+    model.train()
+    for m in model.modules():
+        if "BatchNorm" in m.__class__.__name__ or "Dropout" in m.__class__.__name__:
+            m.eval()
+    for p in model.parameters():
+        p.requires_grad_(False)
+    return model
+
+
+def gradient_figures(got, want):
+    d = (got - want).abs()
+    scale = want.abs().max().item()
+    return {"grad_rel_l2": ((got - want).norm() / want.norm()).item(), "grad_max_abs_over_max": d.max().item() / scale,
+            "grad_frac_off_by_1e-3_of_max": (d > 1e-3 * scale).float().mean().item(), "grad_max": scale}
+
+
+def test_lcnn_fused_device_path_matches_reference_body(cuda, golden, parity_record):
+    """BaseLCNN: first-block kernel, Winograd 3x3 blocks on the matrix cores, 1x1 blocks, folded BatchNorm, persistent
+    LSTM — vs the reference's CPU logits / grad_spec.  Bounds: logits 2e-5 abs (|logit| ~ 0.1); gradient relative L2
+    5e-3 and at most 0.1 % of entries off by more than 1e-3 of the largest entry (near-tie max-feature-map / pool
+    winners may legitimately go the other way under a different summation order)."""
+    from audio_deepfake_adversarial_attacks_amd.models import lcnn
+    g = golden("lcnn_body")
+    body = lcnn.BaseLCNN(input_channels=1, num_coefficients=80)
+    body.load_state_dict(sd_of(g), strict=True)
+    body = attack_mode_frozen(body.to(cuda))
+    spec = T(g["spec"]).to(cuda).requires_grad_(True)
+    out = body(spec)
+    (grad,) = torch.autograd.grad(out.sum(), spec)
+    want_z, want_g = T(g["logits_attackmode"]).to(cuda), T(g["grad_spec"]).to(cuda)
+    fig = gradient_figures(grad, want_g)
+    fig["logit_max_abs"] = (out - want_z).abs().max().item()
+    with torch.no_grad():
+        fig["logit_eval_max_abs"] = (body.eval()(spec.detach()) - T(g["logits"]).to(cuda)).abs().max().item()
+    parity_record["lcnn_body_fused_vs_reference"] = fig
+    assert fig["logit_max_abs"] <= 2e-5 and fig["logit_eval_max_abs"] <= 2e-5, fig
+    assert fig["grad_rel_l2"] <= 5e-3 and fig["grad_frac_off_by_1e-3_of_max"] <= 1e-3, fig
+
+
+def test_specrnet_device_path_matches_reference_body(cuda, golden, parity_record):
+    """BaseSpecRNet on the device (residual blocks + the fused GRU kernels) vs the reference's CPU logits / grad_spec.
+    Bounds: logits 2e-5 abs; gradient relative L2 2e-3 (max-pool near-ties)."""
+    from audio_deepfake_adversarial_attacks_amd.models import specrnet
+    g = golden("specrnet_body")
+    body = specrnet.BaseSpecRNet(specrnet.get_config(2), device=str(cuda))
+    body.load_state_dict(sd_of(g), strict=True)
+    body = attack_mode_frozen(body.to(cuda))
+    spec = T(g["spec"]).to(cuda).requires_grad_(True)
+    out = body(spec)
+    (grad,) = torch.autograd.grad(out.sum(), spec)
+    fig = gradient_figures(grad, T(g["grad_spec"]).to(cuda))
+    fig["logit_max_abs"] = (out - T(g["logits_attackmode"]).to(cuda)).abs().max().item()
+    parity_record["specrnet_body_device_vs_reference"] = fig
+    assert fig["logit_max_abs"] <= 2e-5, fig
+    assert fig["grad_rel_l2"] <= 2e-3 and fig["grad_frac_off_by_1e-3_of_max"] <= 1e-3, fig
+
+
+def test_rawnet3_device_path_matches_reference_body(cuda, golden, parity_record):
+    """RawNet3 after its first layer on the device — the dilated Res2Net convolutions as GEMMs over shifted views
+    (models/rawnet3.py:_same_conv1d), library GEMMs for the 1x1 convolutions — vs the reference class's CPU logits and
+    gradient w.r.t. the tensor leaving conv1.  Bounds: logits 1e-4 abs (2 300 GEMM-accumulated channels ahead of the
+    statistics pooling); gradient relative L2 1e-3."""
+    from tests.test_models import rawnet3_like_fixture
+    g = golden("rawnet3_body")
+    model = attack_mode_frozen(rawnet3_like_fixture(g).to(cuda))
+    h = T(g["h"]).to(cuda).requires_grad_(True)
+    model.conv1.h = h
+    out = model(T(g["x"]).to(cuda))
+    (grad,) = torch.autograd.grad(out.sum(), h)
+    fig = gradient_figures(grad, T(g["grad_h"]).to(cuda))
+    fig["logit_max_abs"] = (out - T(g["logits_attackmode"]).to(cuda)).abs().max().item()
+    parity_record["rawnet3_body_device_vs_reference"] = fig
+    assert fig["logit_max_abs"] <= 1e-4, fig
+    assert fig["grad_rel_l2"] <= 1e-3, fig

@@ -1,5 +1,6 @@
-"""CPU: the detector restatements against logits / input-gradients produced by the reference's own BaseLCNN and
-BaseSpecRNet (tests/golden/*_body.npz), plus structure checks for RawNet3 (whose first layer is parity-unpinned)."""
+"""CPU: the detector restatements against logits / input-gradients produced by the reference's own BaseLCNN,
+BaseSpecRNet and RawNet3-after-its-first-layer (tests/golden/*_body.npz), plus structure checks for RawNet3's sinc
+encoder (third-party, parity-unpinned)."""
 import pytest
 import torch
 
@@ -63,6 +64,25 @@ def test_specrnet_body_equals_reference(golden):
     with torch.no_grad():
         assert torch.equal(body(T(g["spec"])), T(g["logits"]))
     assert sum(p.numel() for p in body.parameters()) == 278_165       # SURVEY.md section 2 (2 input channels)
+    s = T(g["spec"]).clone().requires_grad_(True)
+    out = attack_mode(body)(s)
+    assert torch.equal(out, T(g["logits_attackmode"]))
+    (grad,) = torch.autograd.grad(out.sum(), s)
+    assert torch.equal(grad, T(g["grad_spec"]))
+
+
+def test_specrnet_unused_bn1_still_tracks_statistics_in_train_mode():
+    """specrnet.py:75-78: the reference evaluates bn1(x) and drops the result; in train mode the running statistics
+    (which are saved in checkpoints) still move."""
+    block = specrnet.Residual_block2D([4, 4], first=False).train()
+    before = block.bn1.running_mean.clone()
+    x = torch.randn(2, 4, 8, 8) + 3.0
+    block(x)
+    assert not torch.equal(block.bn1.running_mean, before) and int(block.bn1.num_batches_tracked) == 1
+    block.eval()
+    frozen = block.bn1.running_mean.clone()
+    block(x)
+    assert torch.equal(block.bn1.running_mean, frozen)
 
 
 def test_specrnet_full_model_and_registry():
@@ -121,6 +141,36 @@ def test_rawnet3_structure_and_forward():
     assert out.shape == (2, 1) and torch.isfinite(out).all()
     (g,) = torch.autograd.grad(out.sum(), x)
     assert torch.isfinite(g).all() and g.abs().max() > 0
+
+
+def rawnet3_like_fixture(g):
+    """The in-tree RawNet3 carrying the fixture's weights (seeded recipe, verified tensor by tensor against the SHA-256
+    digests taken from the reference class) with the recorded tensor standing in for the sinc encoder's output."""
+    import json
+    from tests.helpers import FixedEncoder, rawnet3_fixture_weights, tensor_digests
+    model = rawnet3_fixture_weights(rawnet3.prepare_model)
+    want = json.loads(str(g["digests"]))
+    got = tensor_digests(model.state_dict())
+    assert set(got) == set(want)                                       # the reference's key names, conv1.* aside
+    assert [k for k in want if got[k] != want[k]] == []
+    model.conv1 = FixedEncoder()
+    return model.eval()
+
+
+def test_rawnet3_body_equals_reference(golden):
+    """src/models/rawnet3.py:81-137 (+ Bottle2neck / AFMS :161-274): logits and the attack-mode gradient w.r.t. the
+    tensor leaving conv1, bit for bit."""
+    g = golden("rawnet3_body")
+    model = rawnet3_like_fixture(g)
+    model.conv1.h = T(g["h"])
+    with torch.no_grad():
+        assert torch.equal(model(T(g["x"])), T(g["logits"]))
+    h = T(g["h"]).clone().requires_grad_(True)
+    model.conv1.h = h
+    out = attack_mode(model)(T(g["x"]))
+    assert torch.equal(out, T(g["logits_attackmode"]))
+    (grad,) = torch.autograd.grad(out.sum(), h)
+    assert torch.equal(grad, T(g["grad_h"]))
 
 
 def test_preemphasis_matches_definition():
