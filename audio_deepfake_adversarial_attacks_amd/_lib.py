@@ -109,6 +109,12 @@ def load() -> ctypes.CDLL:
             "`python -c 'import __graft_entry__ as g; g.build()'` (or "
             "`python -m audio_deepfake_adversarial_attacks_amd.build`) from the repository root. "
             "There is no CPU fallback for the attack kernels.")
+    from . import build as _build
+    if _LIB_PATH == _build.LIB and not _build.is_current():
+        raise AdvstepError(
+            f"{_LIB_PATH} was not built from the present csrc/*.hip, include/*.h and compiler flags (its build key "
+            f"{_build.STAMP.name} is missing or differs): rebuild with `python -m audio_deepfake_adversarial_attacks_amd.build`. "
+            "A stale kernel library is never loaded silently.")
     lib = ctypes.CDLL(str(_LIB_PATH))
     for name, (restype, argtypes) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol

@@ -80,8 +80,11 @@ class AttackAnalyser:
     @staticmethod
     def sample_diffs(mean_abs, batch_y, batch_preds_noattack_label, batch_preds_label, rows_meta):
         """The reference's stdout line per utterance (:51-68)."""
+        import torch.distributed as dist
+        # multi-rank runs: every line names its rank (ranks print concurrently; the reference has one process)
+        prefix = (f"[rank {dist.get_rank()}]",) if dist.is_available() and dist.is_initialized() else ()
         for i in range(len(batch_y)):
-            print(i, mean_abs[i], batch_preds_noattack_label[i] != batch_preds_label[i], "y:", batch_y[i],
+            print(*prefix, i, mean_abs[i], batch_preds_noattack_label[i] != batch_preds_label[i], "y:", batch_y[i],
                   "y_noadvatk_pred:", batch_preds_noattack_label[i], "y_pred:", batch_preds_label[i], *rows_meta[i])
 
     def save_waves(self, batch_rows, waves, waves_attacked, rows_meta, suffix):

@@ -1,6 +1,7 @@
 """Compile csrc/*.hip into libadvstep.so for gfx950 (hipcc cross-compiles without a GPU)."""
 from __future__ import annotations
 
+import hashlib
 import shutil
 import subprocess
 from pathlib import Path
@@ -14,6 +15,7 @@ SOURCES = [PKG / "csrc" / "advstep.hip", PKG / "csrc" / "lcnn_mfm.hip", PKG / "c
 HEADERS = [ROOT / "include" / "advstep.h", ROOT / "include" / "advstep_lcnn.h", ROOT / "include" / "advstep_frontend.h",
            ROOT / "include" / "advstep_fab.h", ROOT / "include" / "advstep_dataset.h"]
 LIB = PKG / "libadvstep.so"
+STAMP = PKG / "libadvstep.so.buildkey"   # git-ignored like the library; travels with it to the GPU box
 
 # -ffp-contract=off: the kernels must round exactly like the reference's one-ATen-op-per-expression chains
 # (bit-exactness rules); f32 division/sqrt stay IEEE (hipcc default).
@@ -23,17 +25,33 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
                "-shared"]
 
 
+def build_key() -> str:
+    """SHA-256 over the compiler flags and the bytes of every source and header: what the library was built from."""
+    h = hashlib.sha256(" ".join(HIPCC_FLAGS).encode())
+    for p in SOURCES + HEADERS:
+        h.update(p.name.encode())
+        h.update(p.read_bytes())
+    return h.hexdigest()
+
+
+def is_current() -> bool:
+    """True when libadvstep.so exists and was built from exactly the present sources, headers and flags (a library that
+    is merely newer than its sources — a stale copy, a checkout that rewound a file — does not count)."""
+    return LIB.exists() and STAMP.exists() and STAMP.read_text().strip() == build_key()
+
+
 def build(force: bool = False, verbose: bool = False) -> Path:
-    newest_src = max(p.stat().st_mtime for p in SOURCES + HEADERS)
-    if not force and LIB.exists() and LIB.stat().st_mtime >= newest_src:
+    if not force and is_current():
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     cmd = [hipcc, *HIPCC_FLAGS, f"-I{ROOT / 'include'}", *map(str, SOURCES), "-o", str(LIB)]
     if verbose:
         print(" ".join(cmd))
+    STAMP.unlink(missing_ok=True)
     proc = subprocess.run(cmd, capture_output=True, text=True)
     if proc.returncode != 0:
         raise RuntimeError(f"hipcc failed ({proc.returncode}):\n{proc.stdout}\n{proc.stderr}")
+    STAMP.write_text(build_key() + "\n")
     return LIB
 
 

@@ -198,7 +198,16 @@ class AdversarialGDTrainer(Trainer):
         if adversarial:
             self.init_adv_attacks(unwrap(attack_model), adversarial_attacks)
         model = _maybe_ddp(model, self.device)
-        _, world = rank_and_world()
+        rank, world = rank_and_world()
+        if world > 1:
+            # every rank was seeded alike so the replicas start equal; from here on only torch's generators are
+            # decorrelated — random starts (Philox keys come from torch's CPU generator) and dropout masks differ per
+            # shard, as evaluation.generate_attacks does.  Python's `random` stays shared: the strategies' draws and the
+            # adaptive attack weights must be the same on every rank.
+            base = torch.initial_seed()
+            torch.manual_seed(base + rank)
+            if torch.cuda.is_available():
+                torch.cuda.manual_seed(base + rank)
 
         for epoch in range(self.epochs):
             LOGGER.info(f"Epoch num: {epoch}")

@@ -44,7 +44,9 @@ def setup_logging():
 
 def parse_arguments(argv=None):
     parser = argparse.ArgumentParser()
-    # dataset roots: accepted for command-line compatibility; only --synthetic data is supported by this build
+    # dataset roots (reference :40-53 hard-codes the authors' paths as defaults; here the default is "not given", so a
+    # run names its data explicitly: corpus roots and/or --synthetic N).  WAVE corpora decode in-tree; FLAC / MP3 and the
+    # SoX silence trim use soundfile / torchaudio when importable (datasets/backends.py checks at start-up)
     parser.add_argument("--asv_path", type=str, default=None)
     parser.add_argument("--wavefake_path", type=str, default=None)
     parser.add_argument("--celeb_path", type=str, default=None)
@@ -62,8 +64,9 @@ def parse_arguments(argv=None):
     parser.add_argument("--synthetic", type=int, default=None, metavar="N",
                         help="evaluate on N seeded synthetic 64 600-sample utterances")
     parser.add_argument("--no_trim", default=False, action="store_true",
-                        help="real corpora: skip the SoX silence trim (SoX is not part of this build; without this "
-                             "flag a backend must be registered, datasets/base_dataset.py)")
+                        help="real corpora: skip the SoX silence trim.  DEPARTS from the reference preprocessing (which "
+                             "trims silence, base_dataset.py:29-33); without this flag a SoX backend must be importable "
+                             "(datasets/backends.py)")
     parser.add_argument("--num_workers", type=int, default=3, help="DataLoader workers (reference :202: 3)")
     parser.add_argument("--share_weights", default=False, action="store_true",
                         help="copy the target model's weights into the attack model (white-box, no checkpoints)")
@@ -96,11 +99,16 @@ def main(args):
         if args.attack_model_config is None:
             raise SystemExit("--qual names its folder after the attack model: pass --attack_model_config")
         results_folder = f"attack_{args.attack}_{Path(args.attack_model_config).stem}_on_{Path(args.config).stem}"
+        if world > 1:   # one folder per rank: ranks analyse disjoint shards and must not overwrite each other's files
+            results_folder = f"{results_folder}/rank{int(os.environ.get('RANK', '0'))}"
         attack_analyser = AttackAnalyser(Path("qualitative_results") / results_folder)
         on_attack_end_callback = attack_analyser.analyse
     corpora = [args.asv_path, args.wavefake_path, args.celeb_path]
     if args.synthetic is None and all(p is None for p in corpora):
         raise SystemExit("no data: pass --asv_path / --wavefake_path / --celeb_path, or --synthetic N")
+    if args.synthetic is None:
+        from audio_deepfake_adversarial_attacks_amd.datasets import backends
+        backends.require_for(*corpora, trim=not args.no_trim)      # one clear message now, not a worker exception later
 
     report = generate_attacks(
         datasets_paths=[args.asv_path, args.wavefake_path, args.celeb_path],

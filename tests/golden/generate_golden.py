@@ -538,6 +538,59 @@ def gen_rawnet3_body():
     np.savez_compressed(OUT / "rawnet3_body.npz", **out)
 
 
+def gen_frontends_xcheck():
+    """Independent THIRD-PARTY arithmetic for the whole LFCC and mel-spectrogram outputs — NOT the reference: torchaudio
+    0.10 (the package the reference calls, src/frontends.py:13-38) is neither in the reference tree nor installable, so
+    the frontends stay PARITY UNPINNED.  What this fixture adds is that a wrong reading of the published algorithm can no
+    longer pass every test: the restatement in frontends.py and the fused kernels are compared with code written by
+    others (transformers.audio_utils: framing / window / FFT / triangular banks / dB; scipy.fft: the DCT).
+
+      lfcc_<tag>  (80, frames): transformers `spectrogram` (periodic Hann 400, n_fft 512, hop 160, centred reflect pad,
+                  power 2) -> linear triangular bank (transformers' triangular-bank helper on linspace edges, 257 -> 128)
+                  -> `power_to_db(min 1e-10, db_range 80)` -> scipy ortho DCT-II, first 80 coefficients.  One utterance
+                  at a time: the floor is then max - 80 dB of that utterance, which is what frontends.LFCC computes for
+                  a batch of ONE.  (That torchaudio takes the maximum over the whole batch for a 3-D input is the
+                  restatement's reading and cannot be cross-checked here.)
+      mel_<tag>   (2, 80, frames): complex STFT with a rectangular 400-sample window — the reference calls torch.stft
+                  itself for this (src/frontends.py:62-68), so the STFT here is numpy's FFT over torch.stft's framing
+                  (window centred in the 512-point buffer; checked against torch.stft below) — then the HTK mel bank of
+                  transformers `mel_filter_bank(norm=None)` on real and imaginary parts, magnitude and phase."""
+    import scipy.fft
+    from transformers import audio_utils as au
+
+    out = {}
+    window = au.window_function(400, "hann", periodic=True)
+    fft_freqs = np.linspace(0, 8000, 257)
+    linear_bank = au._create_triangular_filter_bank(fft_freqs, np.linspace(0.0, 8000.0, 130))       # (257, 128)
+    mel_bank = au.mel_filter_bank(257, 80, 0.0, 8000.0, 16_000, norm=None, mel_scale="htk")          # (257, 80)
+    cases = {"full": waveforms(2, T_FULL, 91), "short": waveforms(1, 8_000, 92), "loud": waveforms(1, 16_160, 93) * 8.0}
+    cases["loud"][0, 5_000:9_000] *= 1e-4     # a near-silent stretch: the 80 dB floor is active for this utterance
+    for tag, batch in cases.items():
+        out[f"x_{tag}"] = npy(batch)
+        lf, mel = [], []
+        for row in batch.numpy():
+            power = au.spectrogram(row, window, frame_length=400, hop_length=160, fft_length=512, power=2.0, center=True,
+                                   pad_mode="reflect", onesided=True)                                # (257, frames)
+            bands = linear_bank.T @ power
+            db = au.power_to_db(bands, reference=1.0, min_value=1e-10, db_range=80.0)
+            lf.append(scipy.fft.dct(db, type=2, norm="ortho", axis=0)[:80])
+            # torch.stft framing: reflect pad n_fft // 2, frames of 512 every 160, the 400 ones centred (56 zeros each side)
+            padded = np.pad(row.astype(np.float64), 256, mode="reflect")
+            n_frames = 1 + (padded.size - 512) // 160
+            frames = np.stack([padded[t * 160:t * 160 + 512] for t in range(n_frames)])
+            frames[:, :56] = 0.0
+            frames[:, 456:] = 0.0
+            spec = np.fft.rfft(frames, axis=1).T                                                    # (257, frames)
+            want = torch.stft(torch.from_numpy(row), n_fft=512, hop_length=160, win_length=400,
+                              window=torch.ones(400), return_complex=True).numpy()
+            assert np.abs(spec - want).max() <= 2e-4 * np.abs(want).max()
+            m = mel_bank.T @ spec.real + 1j * (mel_bank.T @ spec.imag)
+            mel.append(np.stack([np.abs(m), np.angle(m)]))
+        out[f"lfcc_{tag}"] = np.stack(lf).astype(np.float32)
+        out[f"mel_{tag}"] = np.stack(mel).astype(np.float32)
+    np.savez_compressed(OUT / "frontends_xcheck.npz", **out)
+
+
 def gen_datasets():
     """PadDataset.apply_pad, wavefake_preprocessing_on_batch (SoX steps off), the corpus
     listings of DetectionDataset on the miniature corpora of tests/helpers.build_corpus_trees, and AttackAnalyser's
@@ -657,6 +710,7 @@ def main():
     gen_metrics()
     gen_model_bodies()
     gen_rawnet3_body()
+    gen_frontends_xcheck()
     gen_datasets()
     for p in sorted(OUT.glob("*.npz")):
         print(f"{p.name}: {p.stat().st_size / 1e6:.2f} MB")

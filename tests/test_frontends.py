@@ -100,3 +100,42 @@ def test_state_dict_keys_follow_torchaudio_names():
     assert sorted(F.LFCC().state_dict()) == ["Spectrogram.window", "dct_mat", "filter_mat"]
     assert sorted(F.MFCC().state_dict()) == ["MelSpectrogram.mel_scale.fb", "MelSpectrogram.spectrogram.window", "dct_mat"]
     assert F.MelSpecFrontend().state_dict() == {}   # a plain function in the reference: no checkpoint entries
+
+
+# ---- whole-output cross-check against independent third-party code (tests/golden/frontends_xcheck.npz) ---------------------
+# NOT the reference (torchaudio 0.10 is absent: the frontends stay PARITY UNPINNED); transformers.audio_utils + scipy.fft
+# implementations of the same published algorithms, generated by tests/golden/generate_golden.py::gen_frontends_xcheck.
+
+XCHECK_CASES = ("full", "short", "loud")
+
+
+def lfcc_error(frontend, fixture, tag, device="cpu"):
+    """max |LFCC(batch of one) - fixture| / max |fixture| over the utterances of a case."""
+    worst = 0.0
+    x = torch.from_numpy(fixture[f"x_{tag}"]).to(device)
+    for i in range(x.shape[0]):
+        want = torch.from_numpy(fixture[f"lfcc_{tag}"][i]).to(device)
+        got = frontend(x[i:i + 1])[0]
+        worst = max(worst, ((got - want).abs().max() / want.abs().max()).item())
+    return worst
+
+
+def mel_error(frontend, fixture, tag, device="cpu"):
+    """max |m e^{i phi} - m' e^{i phi'}| / max m' — magnitude and phase compared as the complex number they encode
+    (the phase of a near-zero bin is noise)."""
+    x = torch.from_numpy(fixture[f"x_{tag}"]).to(device)
+    want = torch.from_numpy(fixture[f"mel_{tag}"]).to(device)
+    got = frontend(x)
+    assert got.shape == want.shape
+    err = (torch.polar(got[:, 0], got[:, 1]) - torch.polar(want[:, 0], want[:, 1])).abs().max()
+    return (err / want[:, 0].max()).item()
+
+
+@pytest.mark.parametrize("tag", XCHECK_CASES)
+def test_lfcc_restatement_matches_independent_implementation(golden, tag):
+    assert lfcc_error(F.LFCC(), golden("frontends_xcheck"), tag) <= 1e-5          # measured 2e-6 .. 3e-6
+
+
+@pytest.mark.parametrize("tag", XCHECK_CASES)
+def test_mel_spec_restatement_matches_independent_implementation(golden, tag):
+    assert mel_error(F.MelSpecFrontend(), golden("frontends_xcheck"), tag) <= 2e-5  # measured 7e-6 .. 9e-6

@@ -140,3 +140,25 @@ def test_fused_mfcc_matches_torch_chain(cuda, monkeypatch):
     assert y.shape == y_ref.shape == (3, 80, 101)
     assert (y - y_ref).abs().max().item() <= 2e-3
     assert (g - g_ref).norm().item() / g_ref.norm().item() <= 1e-4
+
+
+# ---- fused kernels vs INDEPENDENT third-party arithmetic (transformers.audio_utils + scipy.fft) -------------------------------
+# tests/golden/frontends_xcheck.npz; not the reference (torchaudio 0.10 is absent: parity stays unpinned), but no longer
+# only this repository's own reading of the algorithm.
+
+@pytest.mark.parametrize("tag", ["full", "short", "loud"])
+def test_fused_lfcc_matches_independent_implementation(cuda, golden, parity_record, tag):
+    from audio_deepfake_adversarial_attacks_amd import frontends
+    from tests.test_frontends import lfcc_error
+    err = lfcc_error(frontends.LFCC().to(cuda), golden("frontends_xcheck"), tag, cuda)
+    parity_record[f"fused_lfcc_vs_third_party_{tag}_max_over_scale"] = err
+    assert err <= 2e-5, err
+
+
+@pytest.mark.parametrize("tag", ["full", "short", "loud"])
+def test_fused_mel_spec_matches_independent_implementation(cuda, golden, parity_record, tag):
+    from audio_deepfake_adversarial_attacks_amd import frontends
+    from tests.test_frontends import mel_error
+    err = mel_error(frontends.MelSpecFrontend().to(cuda), golden("frontends_xcheck"), tag, cuda)
+    parity_record[f"fused_mel_spec_vs_third_party_{tag}_max_over_scale"] = err
+    assert err <= 2e-5, err

@@ -14,7 +14,7 @@ PKG = ROOT / "audio_deepfake_adversarial_attacks_amd"
 @pytest.fixture(scope="module")
 def lib():
     from audio_deepfake_adversarial_attacks_amd import build
-    build.build()  # no-op when libadvstep.so is newer than its sources (hipcc cross-compiles gfx950 on CPU)
+    build.build()  # no-op when libadvstep.so carries the build key of the present sources + flags (hipcc cross-compiles gfx950 on CPU)
     from audio_deepfake_adversarial_attacks_amd import _lib
     return _lib.load()
 
@@ -103,7 +103,40 @@ def test_cli_surface_matches_reference_flags():
 
 def test_yaml_configs_follow_the_reference_schema():
     import yaml
-    for name, model in (("lcnn", "lcnn"), ("specrnet", "specrnet"), ("rawnet3", "rawnet3")):
+    for name, model in (("lcnn", "lcnn"), ("specrnet", "specrnet"), ("specrnet_melspec", "specrnet"), ("rawnet3", "rawnet3")):
         cfg = yaml.safe_load((ROOT / "configs" / "aa_evaluation" / f"{name}.yaml").read_text())
         assert cfg["model"]["name"] == model and cfg["checkpoint"]["path"] == "" and cfg["data"]["seed"] == 42
         assert isinstance(cfg["model"]["parameters"], dict) and isinstance(cfg["data"]["adversarial_attacks"], list)
+    # specrnet.yaml keeps the reference's model (LFCC, 1 channel) so its checkpoints load; the BASELINE variant is separate
+    ref_like = yaml.safe_load((ROOT / "configs" / "aa_evaluation" / "specrnet.yaml").read_text())["model"]["parameters"]
+    assert ref_like == {"input_channels": 1, "frontend_algorithm": ["lfcc"]}
+    mel = yaml.safe_load((ROOT / "configs" / "aa_evaluation" / "specrnet_melspec.yaml").read_text())["model"]["parameters"]
+    assert mel == {"input_channels": 2, "frontend_algorithm": ["mel_spec"]}
+
+
+def test_backend_start_up_check_names_what_is_missing():
+    from audio_deepfake_adversarial_attacks_amd.datasets import backends
+    none = {"sox": False, "codec": False, "flac": False, "mp3": False}
+    assert backends.missing_for(None, None, None, True, none) == []                       # synthetic runs need nothing
+    assert backends.missing_for(None, "/data/WaveFake", None, False, none) == []          # WAVE decodes in-tree
+    msgs = backends.missing_for("/data/asv", "/data/wf", "/data/celeb", True, none)
+    assert len(msgs) == 3 and "FLAC" in msgs[0] and "MP3" in msgs[1] and "DEPARTS from the reference" in msgs[2]
+    assert backends.missing_for("/a", None, "/c", True, {"sox": True, "codec": True, "flac": True, "mp3": True}) == []
+    have = backends.register_available_backends()
+    assert set(have) == {"sox", "codec", "flac", "mp3"}
+    if not have["flac"]:
+        with pytest.raises(SystemExit, match="cannot run on the requested corpora"):
+            backends.require_for("/data/asv", None, None, trim=False)
+
+
+def test_stale_library_is_refused(monkeypatch):
+    """build() reuses libadvstep.so only when its build key (SHA-256 of flags + sources + headers) matches; a library
+    that is merely newer than its sources is neither reused nor loaded."""
+    from audio_deepfake_adversarial_attacks_amd import _lib, build
+    build.build()
+    assert build.is_current() and build.STAMP.read_text().strip() == build.build_key()
+    monkeypatch.setattr(build, "HIPCC_FLAGS", build.HIPCC_FLAGS + ["-DSOMETHING_ELSE"])
+    assert not build.is_current()
+    monkeypatch.setattr(_lib, "_lib", None)
+    with pytest.raises(_lib.AdvstepError, match="stale"):
+        _lib.load()

@@ -55,7 +55,7 @@ def main():
     args = ap.parse_args()
     run("configs[1] LCNN+LFCC, PGD-40 eps 0.003 (white box)", "lcnn", "lcnn", "PGD40_eps003", 128, 2 * args.batches)
     run("configs[1] ... with 3 DataLoader workers (CLI default)", "lcnn", "lcnn", "PGD40_eps003", 128, 2 * args.batches, 3)
-    run("configs[2] SpecRNet+mel, PGDL2-40 eps 0.1 (white box)", "specrnet", "specrnet", "PGDL2_40", 128, args.batches)
+    run("configs[2] SpecRNet+mel, PGDL2-40 eps 0.1 (white box)", "specrnet_melspec", "specrnet_melspec", "PGDL2_40", 128, args.batches)
     run("configs[3] RawNet3 -> LCNN+LFCC, FGSM eps 0.0005", "lcnn", "rawnet3", "FGSM", 64, 2 * args.batches)
     run("configs[3] RawNet3 -> LCNN+LFCC, CW-100 c = 1", "lcnn", "rawnet3", "CW", 64, 4)
     run("           LCNN+LFCC, FAB (eta 10, 10 steps)", "lcnn", "lcnn", "FAB", 128, args.batches)

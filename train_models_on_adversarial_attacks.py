@@ -131,6 +131,9 @@ def main(args):
     if world > 1 and not dist.is_initialized():
         dist.init_process_group(backend="nccl", device_id=torch.device(device))  # "nccl" is RCCL on ROCm
 
+    if not args.synthetic:
+        from audio_deepfake_adversarial_attacks_amd.datasets import backends
+        backends.require_for(args.asv_path, args.wavefake_path, args.celeb_path, trim=not args.no_trim)
     model_dir = Path(args.ckpt)
     model_dir.mkdir(parents=True, exist_ok=True)
     synthetic = tuple(int(v) for v in args.synthetic.split(",")) if args.synthetic else None
