@@ -1,4 +1,5 @@
 """PGD, L-inf (reference: adversarial_attacks/torchattacks/attacks/pgd.py:7-78)."""
+from .. import graphed
 from ..attack import Attack
 
 
@@ -39,10 +40,10 @@ class PGD(Attack):
         else:
             adv = images.clone()
 
-        spare = None  # ping-pong buffer: the step writes where the model is not reading
-        for _ in range(self.steps):
-            grad, _ = self._input_gradient(adv, labels, target)     # pgd.py:60-72
-            # pgd.py:74-76 fused: sign step, eps-ball projection around `images`, [0, 1] clamp
-            nxt = ops.pgd_linf_step(adv.detach(), grad, images, self.alpha, self.eps, out=spare)
-            spare, adv = adv.detach(), nxt
-        return adv.detach()
+        # pgd.py:60-76, `steps` times: model forward + input-backward, then the fused sign step / eps-ball projection around
+        # `images` / [0, 1] clamp, writing where the model is not reading (ping-pong).  Replayed from a hipGraph once the
+        # same (model state, shape) has been seen twice (graphed.py); eager otherwise — bit-identical either way.
+        def step(cur, grad, orig, out):
+            ops.pgd_linf_step(cur, grad, orig, self.alpha, self.eps, out=out)
+
+        return graphed.run_iterations(self, adv, images, labels, target, self.steps, step, (self.eps, self.alpha))

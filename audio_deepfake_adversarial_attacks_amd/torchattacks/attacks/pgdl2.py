@@ -1,4 +1,5 @@
 """PGD, L2 (reference: adversarial_attacks/torchattacks/attacks/pgdl2.py:7-90)."""
+from .. import graphed
 from ..attack import Attack
 
 
@@ -42,10 +43,10 @@ class PGDL2(Attack):
         else:
             adv = images.clone()
 
-        spare = None
-        for _ in range(self.steps):
-            grad, _ = self._input_gradient(adv, labels, target)     # pgdl2.py:64-77
-            # pgdl2.py:78-88 fused: normalise the gradient row-wise, step, project onto the L2 ball, clamp
-            nxt = ops.pgd_l2_step(adv.detach(), grad, images, self.alpha, self.eps, self.eps_for_division, out=spare)
-            spare, adv = adv.detach(), nxt
-        return adv.detach()
+        # pgdl2.py:64-88, `steps` times: model forward + input-backward, then the fused step (normalise the gradient row-wise,
+        # step, project onto the L2 ball, clamp), ping-pong; hipGraph replay as in PGD (graphed.py)
+        def step(cur, grad, orig, out):
+            ops.pgd_l2_step(cur, grad, orig, self.alpha, self.eps, self.eps_for_division, out=out)
+
+        return graphed.run_iterations(self, adv, images, labels, target, self.steps, step,
+                                      (self.eps, self.alpha, self.eps_for_division))

@@ -1,0 +1,126 @@
+"""hipGraph replay of the iterative attacks' inner loop (PGD, PGDL2).
+
+One attack iteration on LCNN is ~48 kernel launches (model forward + input-backward through the fused kernels, the
+closed-form loss gradient, the fused update step) of fixed shapes; the launching thread needs about half of the 2.2 ms the
+GPU takes for them, so with the data loader's collation on the same thread — or eight ranks sharing one host — the loop
+turns host-bound.  Here two iterations (adv A -> adv B -> adv A, ping-pong) are captured ONCE into
+a hipGraph per (model state, batch shape, attack hyper-parameters) and replayed steps / 2 times: the host issues one
+graph launch per two iterations.
+
+What is baked into a captured graph and therefore part of its key: the device pointers of the static input buffers (owned
+here), of the model's parameters and of every cache derived from them (prepared Winograd weights, packed GRU weights,
+filterbank tables) — so the key carries the parameters' version counters and the modules' train/eval flags; a graph is
+captured only when the same key shows up a second time (an adversarial-training step changes the weights before every
+attack call: those calls stay eager).  Random starts are drawn OUTSIDE the graph (a fresh Philox key per call).
+
+Eager fallback, always bit-identical: CPU op tables / checked ops (tests), active launch profiling (bench.py brackets
+the update kernel with HIP events, which cannot be recorded into a graph), ADVSTEP_ATTACK_GRAPH=0, or a failed capture."""
+from __future__ import annotations
+
+import os
+import warnings
+from typing import Callable, Dict, Optional, Tuple
+
+import torch
+
+_GRAPHS: Dict[tuple, "_Captured"] = {}
+_SEEN: Dict[tuple, int] = {}
+_MAX_GRAPHS = 8
+_failed_once = False
+
+
+def enabled() -> bool:
+    return os.environ.get("ADVSTEP_ATTACK_GRAPH", "1") != "0"
+
+
+def _state_signature(model: torch.nn.Module) -> Tuple:
+    versions = tuple((p.data_ptr(), p._version) for p in model.parameters())
+    buffers = tuple((b.data_ptr(), b._version) for b in model.buffers())
+    flags = tuple(m.training for m in model.modules())
+    return versions, buffers, flags
+
+
+class _Captured:
+    def __init__(self, attack, images, labels, target, step_fn):
+        dev = images.device
+        self.images = torch.empty_like(images)
+        self.adv_a = torch.empty_like(images)
+        self.adv_b = torch.empty_like(images)
+        self.labels = torch.empty_like(labels)
+        self.target = torch.empty_like(target) if target is not None else None
+        self.images.copy_(images), self.labels.copy_(labels), self.adv_a.copy_(images)
+        if target is not None:
+            self.target.copy_(target)
+
+        def two_iterations():
+            grad, _ = attack._input_gradient(self.adv_a, self.labels, self.target)
+            step_fn(self.adv_a.detach(), grad, self.images, self.adv_b)
+            grad, _ = attack._input_gradient(self.adv_b, self.labels, self.target)
+            step_fn(self.adv_b.detach(), grad, self.images, self.adv_a)
+
+        # warm-up on a side stream (torch's capture protocol): builds every lazily created cache and workspace
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            two_iterations()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            two_iterations()
+
+    def run(self, adv, images, labels, target, pairs: int) -> torch.Tensor:
+        # (adv_a / adv_b became autograd leaves during the capture: write through detached views)
+        self.images.copy_(images), self.labels.copy_(labels), self.adv_a.detach().copy_(adv)
+        if target is not None:
+            self.target.copy_(target)
+        for _ in range(pairs):
+            self.graph.replay()
+        return self.adv_a.detach()
+
+
+def run_iterations(attack, adv: torch.Tensor, images: torch.Tensor, labels: torch.Tensor, target: Optional[torch.Tensor],
+                   steps: int, step_fn: Callable, hyper: Tuple) -> torch.Tensor:
+    """`steps` iterations of  adv <- step_fn(adv, grad(adv), images, out)  starting from `adv`; returns the final adv
+    (detached, own storage).  step_fn(adv, grad, images, out) must write `out` (a different buffer than `adv`)."""
+    global _failed_once
+    from .. import hip_ops
+    ops = attack.ops
+    use_graph = (enabled() and ops is hip_ops and hip_ops._profile is None and adv.is_cuda and steps >= 4
+                 and not torch.cuda.is_current_stream_capturing())
+    done = 0
+    if use_graph:
+        key = (id(attack.model), attack.__class__.__name__, hyper, attack._targeted, tuple(adv.shape), str(adv.device),
+               _state_signature(attack.model))
+        cap = _GRAPHS.get(key)
+        if cap is None:
+            _SEEN[key] = _SEEN.get(key, 0) + 1
+            if len(_SEEN) > 64:
+                _SEEN.clear()
+            if _SEEN.get(key, 0) >= 2 and not _failed_once:
+                try:
+                    cap = _Captured(attack, images, labels, target, step_fn)
+                    if len(_GRAPHS) >= _MAX_GRAPHS:
+                        _GRAPHS.pop(next(iter(_GRAPHS)))
+                    _GRAPHS[key] = cap
+                except Exception as exc:  # noqa: BLE001 — any capture problem means: stay eager, loudly, once
+                    _failed_once = True
+                    torch.cuda.synchronize()
+                    warnings.warn(f"hipGraph capture of the {attack.__class__.__name__} iteration failed ({exc!r}); "
+                                  "continuing with eager launches")
+                    cap = None
+        if cap is not None:
+            adv = cap.run(adv, images, labels, target, steps // 2).detach().clone()
+            done = 2 * (steps // 2)
+    spare = None
+    for _ in range(steps - done):
+        grad, _ = attack._input_gradient(adv, labels, target)
+        out = spare if spare is not None else torch.empty_like(adv)
+        step_fn(adv.detach(), grad, images, out)
+        spare, adv = adv.detach(), out
+    return adv.detach()
+
+
+def clear() -> None:
+    """Drop every captured graph (tests; also releases the graphs' private memory pools)."""
+    _GRAPHS.clear()
+    _SEEN.clear()

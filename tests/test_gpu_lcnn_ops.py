@@ -237,7 +237,8 @@ def test_conv5_mfm_pool2_requires_frozen_weights(L, cuda):
 
 def test_lcnn_with_fused_first_block_agrees_with_miopen_path(cuda, monkeypatch, parity_record):
     """Whole LCNN, attack mode, frozen parameters: fused first block + fused 1x1 blocks vs MIOpen convolutions.  The two
-    convolutions round differently, so logits agree to float tolerance and input gradients to a small relative error."""
+    convolutions round differently, so logits agree to float tolerance and input gradients to a small relative error.
+    Measured (profiles/r02_parity.json): logits 3e-8, gradient relative L2 7e-7, no entry off by 1e-3 of the maximum."""
     from audio_deepfake_adversarial_attacks_amd.models.models import get_model
     torch.manual_seed(0)
     model = get_model("lcnn", {"frontend_algorithm": ["lfcc"], "input_channels": 1}, str(cuda)).to(cuda)
@@ -270,8 +271,11 @@ def test_lcnn_with_fused_first_block_agrees_with_miopen_path(cuda, monkeypatch, 
            "grad_entries": g0.numel(), "grad_entries_off_by_1e-3_of_max": int(off.sum()),
            "grad_max_abs_over_max": ((g0 - g1).abs().max() / g0.abs().max()).item()}
     parity_record["lcnn_fused_kernels_vs_miopen_path"] = fig
-    assert off.float().mean().item() <= 1e-3, fig
-    assert fig["grad_rel_l2"] <= 2e-2, fig
+    # a near-tie max-feature-map / pool winner going the other way re-routes one gradient entry; none did on this input —
+    # the bounds leave room for a handful (each such entry moves the relative L2 by ~1e-3 at most)
+    assert fig["grad_entries_off_by_1e-3_of_max"] <= 8, fig
+    assert fig["grad_rel_l2"] <= 1e-4 or fig["grad_entries_off_by_1e-3_of_max"] > 0, fig
+    assert fig["grad_rel_l2"] <= 5e-3, fig
     for p in model.parameters():
         p.requires_grad_(True)
 
