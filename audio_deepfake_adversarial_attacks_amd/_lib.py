@@ -13,7 +13,7 @@ ABI_VERSION = 1
 _p, _i64, _f32, _f64, _u64, _sz = (ctypes.c_void_p, ctypes.c_int64, ctypes.c_float, ctypes.c_double,
                                    ctypes.c_uint64, ctypes.c_size_t)
 
-# name -> (restype, argtypes); one entry per symbol declared in include/advstep.h, advstep_lcnn.h, advstep_frontend.h, advstep_fab.h and advstep_dataset.h
+# name -> (restype, argtypes); one entry per symbol declared in include/advstep.h, advstep_lcnn.h, advstep_frontend.h, advstep_fab.h, advstep_dataset.h and advstep_detector.h
 SIGNATURES = {
     "advstep_abi_version": (ctypes.c_int, []),
     "advstep_status_string": (ctypes.c_char_p, [ctypes.c_int]),
@@ -87,6 +87,14 @@ SIGNATURES = {
     "advstep_wave_pad_tile_f32": (ctypes.c_int, [_p, ctypes.c_int, _p, _p, _p, _p, _i64, _i64, _p]),
     "advstep_qual_select": (ctypes.c_int, [_p, _p, _p, _i64, _p, _p, _p]),
     "advstep_wave_gather_rows_f32": (ctypes.c_int, [_p, _p, _p, _i64, _i64, _p]),
+    # include/advstep_detector.h
+    "advstep_affine_act_forward_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _i64, _i64, ctypes.c_int, _f32, _p]),
+    "advstep_affine_act_backward_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, ctypes.c_int, _f32, _p]),
+    "advstep_add_maxpool2_forward_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p]),
+    "advstep_maxpool2_backward_f32": (ctypes.c_int, [_p, _p, _p, _i64, _i64, _i64, _i64, _p]),
+    "advstep_gate_maxpool2_blocks": (_sz, [_i64, _i64]),
+    "advstep_gate_maxpool2_forward_f32": (ctypes.c_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _p]),
+    "advstep_gate_maxpool2_backward_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p]),
 }
 
 

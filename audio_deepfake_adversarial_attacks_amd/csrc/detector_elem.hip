@@ -1,0 +1,301 @@
+// detector_elem.hip — fused elementwise / pooling kernels of the SpecRNet and RawNet3 detectors (C ABI:
+// include/advstep_detector.h).  All HBM-bound: 16 B per lane, one pass per tensor, grid (N * C, tiles) so the channel of a
+// workgroup is uniform (per-channel constants are scalar loads).  Planes (n, c) ride on grid.x, tiles of a plane on grid.y.
+//
+// Replaced ATen / MIOpen chains (each op a full read + write of the activation, at B = 128 up to 331 MB per tensor):
+//   conv bias add_ -> MIOpenBatchNormFwdInfer -> leaky_relu            =>  affine_act_forward (mode 0)
+//   leaky_relu_backward -> batch_norm_elementwise_backward_eval         =>  affine_act_backward
+//   conv bias add_ -> relu -> batch_norm (RawNet3)                      =>  affine_act_forward (mode 1)
+//   2 x conv bias add_ -> add -> max_pool_forward (values + int64 idx)  =>  add_maxpool2_forward (values + 1 byte)
+//   max_pool_backward_nchw (98 us average in the SpecRNet step)         =>  maxpool2_backward
+//   mul -> add -> max_pool_forward and their backward                   =>  gate_maxpool2_forward / _backward
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "advstep_detector.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+inline hipStream_t as_stream(advstep_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+inline int status_after_launch() { return hipGetLastError() == hipSuccess ? ADVSTEP_OK : ADVSTEP_ELAUNCH; }
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ---- per-channel affine + activation: grid (ceil(P / (4 * kBlock * 4)), N * C) ------------------------------------------
+constexpr int kVecPerThread = 4;
+
+template <int MODE>
+__device__ __forceinline__ float act_fwd(float x, float s, float t, float pre, float slope) {
+    if (MODE == 0) {
+        const float v = x * s + t;
+        return v > 0.0f ? v : v * slope;
+    }
+    const float r = x + pre;
+    return (r > 0.0f ? r : 0.0f) * s + t;          // relu keeps NaN out like at::relu: max(0, NaN) -> NaN handled below
+}
+template <int MODE>
+__device__ __forceinline__ float act_bwd(float gy, float x, float s, float t, float pre, float slope) {
+    if (MODE == 0) return gy * ((x * s + t) > 0.0f ? 1.0f : slope) * s;
+    return (x + pre) > 0.0f ? gy * s : 0.0f;
+}
+
+template <int MODE, bool BWD, bool VEC>
+__global__ __launch_bounds__(kBlock) void affine_act_kernel(const float *__restrict__ gy, const float *__restrict__ x,
+                                                            const float *__restrict__ scale, const float *__restrict__ shift,
+                                                            const float *__restrict__ pre, float *__restrict__ out, int64_t C,
+                                                            int64_t P, float slope) {
+    const int64_t nc = blockIdx.x;       // plane on x (up to 2^31 - 1 of them), tile on y
+    const int c = (int)(nc % C);
+    const float s = scale[c], t = shift[c], pr = pre ? pre[c] : 0.0f;
+    const float *xp = x + nc * P;
+    const float *gp = BWD ? gy + nc * P : nullptr;
+    float *op = out + nc * P;
+    if (VEC) {
+        const int64_t G = P / 4;
+        const int64_t g0 = (int64_t)blockIdx.y * (kBlock * kVecPerThread) + threadIdx.x;
+        float4 xv[kVecPerThread], gv[kVecPerThread];
+#pragma unroll
+        for (int k = 0; k < kVecPerThread; ++k) {
+            const int64_t g = g0 + (int64_t)k * kBlock;
+            if (g < G) {
+                xv[k] = reinterpret_cast<const float4 *>(xp)[g];
+                if (BWD) gv[k] = reinterpret_cast<const float4 *>(gp)[g];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kVecPerThread; ++k) {
+            const int64_t g = g0 + (int64_t)k * kBlock;
+            if (g < G) {
+                float4 o;
+                if (BWD) {
+                    o.x = act_bwd<MODE>(gv[k].x, xv[k].x, s, t, pr, slope);
+                    o.y = act_bwd<MODE>(gv[k].y, xv[k].y, s, t, pr, slope);
+                    o.z = act_bwd<MODE>(gv[k].z, xv[k].z, s, t, pr, slope);
+                    o.w = act_bwd<MODE>(gv[k].w, xv[k].w, s, t, pr, slope);
+                } else {
+                    o.x = act_fwd<MODE>(xv[k].x, s, t, pr, slope);
+                    o.y = act_fwd<MODE>(xv[k].y, s, t, pr, slope);
+                    o.z = act_fwd<MODE>(xv[k].z, s, t, pr, slope);
+                    o.w = act_fwd<MODE>(xv[k].w, s, t, pr, slope);
+                }
+                reinterpret_cast<float4 *>(op)[g] = o;
+            }
+        }
+    } else {
+        const int64_t i0 = ((int64_t)blockIdx.y * (kBlock * kVecPerThread) + threadIdx.x) * 4;
+#pragma unroll
+        for (int k = 0; k < kVecPerThread; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int64_t i = i0 + (int64_t)k * kBlock * 4 + e;
+                if (i < P) op[i] = BWD ? act_bwd<MODE>(gp[i], xp[i], s, t, pr, slope) : act_fwd<MODE>(xp[i], s, t, pr, slope);
+            }
+    }
+}
+
+template <bool BWD>
+int launch_affine(const float *gy, const float *x, const float *scale, const float *shift, const float *pre, float *out,
+                  int64_t N, int64_t C, int64_t P, int mode, float slope, hipStream_t st) {
+    if (N < 0 || C < 0 || P < 0 || (mode != 0 && mode != 1)) return ADVSTEP_EINVAL;
+    if (N * C * P == 0) return ADVSTEP_OK;
+    const int64_t tiles = ceil_div(ceil_div(P, 4), kBlock * kVecPerThread);
+    if (!x || !scale || !shift || !out || (BWD && !gy) || N * C > 0x7fffffffLL || tiles > 65535) return ADVSTEP_EINVAL;
+    const bool vec = P % 4 == 0 && aligned16(x) && aligned16(out) && (!BWD || aligned16(gy));
+    const dim3 grid((unsigned)(N * C), (unsigned)tiles), block(kBlock);
+#define GO(MODE, VEC)                                                                                                   \
+    hipLaunchKernelGGL((affine_act_kernel<MODE, BWD, VEC>), grid, block, 0, st, gy, x, scale, shift, pre, out, C, P, slope)
+    if (mode == 0) { if (vec) GO(0, true); else GO(0, false); }
+    else { if (vec) GO(1, true); else GO(1, false); }
+#undef GO
+    return status_after_launch();
+}
+
+// ---- 2x2 max pooling family: thread = 2 horizontally adjacent pooled outputs -------------------------------------------
+// at::native::max_pool_forward_nchw: scan the window row-major, take val when (val > max) || isnan(val); start max = -inf.
+__device__ __forceinline__ float pool4(float v00, float v01, float v10, float v11, int &code) {
+    float best = -INFINITY;
+    code = 0;
+    if (v00 > best || v00 != v00) { best = v00; code = 0; }
+    if (v01 > best || v01 != v01) { best = v01; code = 1; }
+    if (v10 > best || v10 != v10) { best = v10; code = 2; }
+    if (v11 > best || v11 != v11) { best = v11; code = 3; }
+    return best;
+}
+
+// KIND 0: a (+ b) (+ bias[c]);  KIND 1: x * gate[n, c] + gate[n, c]
+template <int KIND>
+__global__ __launch_bounds__(kBlock) void pool2_forward_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                               const float *__restrict__ bias, const float *__restrict__ gate,
+                                                               float *__restrict__ y, uint8_t *__restrict__ sel, int64_t C,
+                                                               int H, int W) {
+    const int64_t nc = blockIdx.x;
+    const int Ho = H >> 1, Wo = W >> 1, Wp = (Wo + 1) >> 1;      // Wp pairs of pooled outputs per row
+    const int64_t idx = (int64_t)blockIdx.y * kBlock + threadIdx.x;
+    if (idx >= (int64_t)Ho * Wp) return;
+    const int i = (int)(idx / Wp), jp = (int)(idx - (int64_t)i * Wp), j0 = 2 * jp;
+    const float add = KIND == 0 ? (bias ? bias[nc % C] : 0.0f) : gate[nc];
+    const float mul = KIND == 1 ? gate[nc] : 1.0f;
+    const float *ap = a + (nc * H + 2 * i) * W + 2 * j0;
+    const float *bp = (KIND == 0 && b) ? b + (nc * H + 2 * i) * W + 2 * j0 : nullptr;
+    const bool two = j0 + 1 < Wo;
+    float r0[4], r1[4];
+    if (two && (W & 3) == 0 && ((reinterpret_cast<uintptr_t>(a) | (bp ? reinterpret_cast<uintptr_t>(b) : 0)) & 15u) == 0) {
+        float4 t0 = *reinterpret_cast<const float4 *>(ap), t1 = *reinterpret_cast<const float4 *>(ap + W);
+        r0[0] = t0.x, r0[1] = t0.y, r0[2] = t0.z, r0[3] = t0.w;
+        r1[0] = t1.x, r1[1] = t1.y, r1[2] = t1.z, r1[3] = t1.w;
+        if (bp) {
+            t0 = *reinterpret_cast<const float4 *>(bp), t1 = *reinterpret_cast<const float4 *>(bp + W);
+            r0[0] += t0.x, r0[1] += t0.y, r0[2] += t0.z, r0[3] += t0.w;
+            r1[0] += t1.x, r1[1] += t1.y, r1[2] += t1.z, r1[3] += t1.w;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool in = e < 2 || two;
+            r0[e] = in ? ap[e] + (bp ? bp[e] : 0.0f) : 0.0f;
+            r1[e] = in ? ap[W + e] + (bp ? bp[W + e] : 0.0f) : 0.0f;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (KIND == 0) { r0[e] += add; r1[e] += add; }
+        else { r0[e] = r0[e] * mul + add; r1[e] = r1[e] * mul + add; }
+    }
+    int c0, c1;
+    const float v0 = pool4(r0[0], r0[1], r1[0], r1[1], c0), v1 = pool4(r0[2], r0[3], r1[2], r1[3], c1);
+    const int64_t o = (nc * Ho + i) * Wo + j0;
+    y[o] = v0;
+    sel[o] = (uint8_t)c0;
+    if (two) {
+        y[o + 1] = v1;
+        sel[o + 1] = (uint8_t)c1;
+    }
+}
+
+// thread = one input row segment of 4 floats (2 pooled outputs); writes the full-resolution gradient incl. odd tails
+template <bool GATE>
+__global__ __launch_bounds__(kBlock) void pool2_backward_kernel(const float *__restrict__ gy, const uint8_t *__restrict__ sel,
+                                                                const float *__restrict__ x, const float *__restrict__ gate,
+                                                                float *__restrict__ g, float *__restrict__ partial, int H,
+                                                                int W, int blocks) {
+    const int64_t nc = blockIdx.x;
+    const int Ho = H >> 1, Wo = W >> 1;
+    const int Wq = (W + 3) >> 2;                                  // 4-float segments per input row
+    const int64_t idx = (int64_t)blockIdx.y * kBlock + threadIdx.x;
+    float acc = 0.0f;
+    if (idx < (int64_t)H * Wq) {
+        const int h = (int)(idx / Wq), q = (int)(idx - (int64_t)h * Wq), w0 = 4 * q;
+        const int i = h >> 1, dh = h & 1;
+        const float gt = GATE ? gate[nc] : 1.0f;
+        float out[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (i < Ho) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int j = 2 * q + e;
+                if (j < Wo) {
+                    const int64_t o = (nc * Ho + i) * Wo + j;
+                    const int code = sel[o];
+                    if ((code >> 1) == dh) {
+                        const float gv = gy[o];
+                        out[2 * e + (code & 1)] = gv * gt;
+                        if (GATE) acc += gv * (x[(nc * H + h) * W + w0 + 2 * e + (code & 1)] + 1.0f);
+                    }
+                }
+            }
+        }
+        float *gp = g + (nc * H + h) * W + w0;
+        if (w0 + 3 < W && (W & 3) == 0) *reinterpret_cast<float4 *>(gp) = make_float4(out[0], out[1], out[2], out[3]);
+        else
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (w0 + e < W) gp[e] = out[e];
+    }
+    if (GATE) {
+        // fixed-order workgroup sum: wave butterfly, then the 4 wave sums in index order
+        __shared__ float ws[kBlock / 64];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+        if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) partial[nc * blocks + blockIdx.y] = ((ws[0] + ws[1]) + ws[2]) + ws[3];
+    }
+}
+
+inline bool pool_dims_ok(int64_t N, int64_t C, int64_t H, int64_t W) {
+    // planes on grid.x, tiles of a plane on grid.y (<= 65535 workgroups of 256 threads per plane)
+    return N >= 0 && C >= 0 && H >= 0 && W >= 0 && N * C <= 0x7fffffffLL && H * ((W + 3) / 4) <= 65535LL * kBlock;
+}
+
+}  // namespace
+
+extern "C" {
+
+int advstep_affine_act_forward_f32(const float *x, const float *scale, const float *shift, const float *pre, float *y,
+                                   int64_t N, int64_t C, int64_t P, int mode, float slope, advstep_stream_t stream) {
+    return launch_affine<false>(nullptr, x, scale, shift, pre, y, N, C, P, mode, slope, as_stream(stream));
+}
+
+int advstep_affine_act_backward_f32(const float *gy, const float *x, const float *scale, const float *shift,
+                                    const float *pre, float *gx, int64_t N, int64_t C, int64_t P, int mode, float slope,
+                                    advstep_stream_t stream) {
+    return launch_affine<true>(gy, x, scale, shift, pre, gx, N, C, P, mode, slope, as_stream(stream));
+}
+
+int advstep_add_maxpool2_forward_f32(const float *a, const float *b, const float *bias, float *y, uint8_t *sel, int64_t N,
+                                     int64_t C, int64_t H, int64_t W, advstep_stream_t stream) {
+    if (!pool_dims_ok(N, C, H, W)) return ADVSTEP_EINVAL;
+    const int64_t Ho = H / 2, Wo = W / 2;
+    if (N * C * Ho * Wo == 0) return ADVSTEP_OK;
+    if (!a || !y || !sel) return ADVSTEP_EINVAL;
+    const dim3 grid((unsigned)(N * C), (unsigned)ceil_div(Ho * ((Wo + 1) / 2), kBlock)), block(kBlock);
+    hipLaunchKernelGGL(pool2_forward_kernel<0>, grid, block, 0, as_stream(stream), a, b, bias, (const float *)nullptr, y, sel, C,
+                       (int)H, (int)W);
+    return status_after_launch();
+}
+
+int advstep_maxpool2_backward_f32(const float *gy, const uint8_t *sel, float *g, int64_t N, int64_t C, int64_t H, int64_t W,
+                                  advstep_stream_t stream) {
+    if (!pool_dims_ok(N, C, H, W)) return ADVSTEP_EINVAL;
+    if (N * C * H * W == 0) return ADVSTEP_OK;
+    if (!g || ((H / 2) * (W / 2) > 0 && (!gy || !sel))) return ADVSTEP_EINVAL;
+    const dim3 grid((unsigned)(N * C), (unsigned)ceil_div(H * ((W + 3) / 4), kBlock)), block(kBlock);
+    hipLaunchKernelGGL(pool2_backward_kernel<false>, grid, block, 0, as_stream(stream), gy, sel, (const float *)nullptr,
+                       (const float *)nullptr, g, (float *)nullptr, (int)H, (int)W, 0);
+    return status_after_launch();
+}
+
+size_t advstep_gate_maxpool2_blocks(int64_t H, int64_t W) {
+    if (H <= 0 || W <= 0) return 0;
+    return (size_t)ceil_div(H * ((W + 3) / 4), kBlock);
+}
+
+int advstep_gate_maxpool2_forward_f32(const float *x, const float *gate, float *y, uint8_t *sel, int64_t N, int64_t C,
+                                      int64_t H, int64_t W, advstep_stream_t stream) {
+    if (!pool_dims_ok(N, C, H, W)) return ADVSTEP_EINVAL;
+    const int64_t Ho = H / 2, Wo = W / 2;
+    if (N * C * Ho * Wo == 0) return ADVSTEP_OK;
+    if (!x || !gate || !y || !sel) return ADVSTEP_EINVAL;
+    const dim3 grid((unsigned)(N * C), (unsigned)ceil_div(Ho * ((Wo + 1) / 2), kBlock)), block(kBlock);
+    hipLaunchKernelGGL(pool2_forward_kernel<1>, grid, block, 0, as_stream(stream), x, (const float *)nullptr,
+                       (const float *)nullptr, gate, y, sel, C, (int)H, (int)W);
+    return status_after_launch();
+}
+
+int advstep_gate_maxpool2_backward_f32(const float *gy, const uint8_t *sel, const float *x, const float *gate, float *gx,
+                                       float *ggate_partial, int64_t N, int64_t C, int64_t H, int64_t W,
+                                       advstep_stream_t stream) {
+    if (!pool_dims_ok(N, C, H, W)) return ADVSTEP_EINVAL;
+    if (N * C * H * W == 0) return ADVSTEP_OK;
+    if (!gx || !ggate_partial || !x || !gate || ((H / 2) * (W / 2) > 0 && (!gy || !sel))) return ADVSTEP_EINVAL;
+    const int blocks = (int)advstep_gate_maxpool2_blocks(H, W);
+    const dim3 grid((unsigned)(N * C), (unsigned)blocks), block(kBlock);
+    hipLaunchKernelGGL(pool2_backward_kernel<true>, grid, block, 0, as_stream(stream), gy, sel, x, gate, gx, ggate_partial, (int)H,
+                       (int)W, blocks);
+    return status_after_launch();
+}
+
+}  // extern "C"

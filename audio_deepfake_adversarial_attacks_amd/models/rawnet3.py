@@ -46,7 +46,27 @@ def _gemm_conv1d_enabled() -> bool:
     return os.environ.get("ADVSTEP_RAWNET3_GEMM_CONV", "1") != "0"
 
 
-def _same_conv1d(x: torch.Tensor, conv: nn.Conv1d) -> torch.Tensor:
+def _fused_elem_enabled() -> bool:
+    import os
+    return os.environ.get("ADVSTEP_RAWNET3_ELEM", "1") != "0"
+
+
+def _conv_relu_bn(x: torch.Tensor, conv: nn.Conv1d, bn: nn.BatchNorm1d) -> torch.Tensor:
+    """`bn(relu(conv(x)))` (rawnet3.py:240-242, 252-254, 262-264).  On a HIP tensor with frozen parameters and an eval-mode
+    BatchNorm the convolution runs without its bias and  relu(. + bias[c]) * scale[c] + shift[c]  is ONE pass
+    (detector_ops.relu_affine) instead of bias add, ReLU and BatchNorm kernels over activations of up to 1.7 GB."""
+    if x.is_cuda and x.dtype == torch.float32 and _fused_elem_enabled():
+        from .. import detector_ops as D
+        frozen = not (torch.is_grad_enabled() and (conv.weight.requires_grad or (conv.bias is not None and conv.bias.requires_grad)
+                                                   or any(p.requires_grad for p in bn.parameters())))
+        if frozen and D.foldable_bn(bn):
+            scale, shift = D.bn_eval_affine(bn)
+            h = _same_conv1d(x, conv, with_bias=False)
+            return D.relu_affine(h, scale, shift, conv.bias.detach() if conv.bias is not None else None)
+    return bn(torch.relu(_same_conv1d(x, conv)))
+
+
+def _same_conv1d(x: torch.Tensor, conv: nn.Conv1d, with_bias: bool = True) -> torch.Tensor:
     """`conv(x)` for the dilated "same" Conv1d(width, width, 3, dilation=d, padding=d) of the Res2Net branches.
 
     On a HIP device MIOpen (no tuned solver for these 128-channel dilated 1-D convolutions) runs them with its NAIVE
@@ -54,14 +74,15 @@ def _same_conv1d(x: torch.Tensor, conv: nn.Conv1d) -> torch.Tensor:
     as k GEMMs over shifted views of the padded input, W[:, :, j] (Cout x Cin) . x[:, :, t + j d], goes to rocBLAS /
     hipBLASLt instead (autograd included).  CPU tensors and any other geometry take the module itself."""
     k, d = conv.kernel_size[0], conv.dilation[0]
-    if not (x.is_cuda and _gemm_conv1d_enabled() and conv.stride == (1,) and conv.groups == 1 and k % 2 == 1
+    bias = conv.bias if with_bias else None
+    if not (x.is_cuda and _gemm_conv1d_enabled() and conv.stride == (1,) and conv.groups == 1 and k % 2 == 1 and k > 1
             and conv.padding == ((k // 2) * d,) and conv.padding_mode == "zeros"):
-        return conv(x)
+        return F.conv1d(x, conv.weight, bias, conv.stride, conv.padding, conv.dilation, conv.groups)
     T = x.shape[-1]
     xp = torch.nn.functional.pad(x, ((k // 2) * d, (k // 2) * d))
     B = x.shape[0]
     # bias and the running sum ride in the GEMM epilogue (C operand of baddbmm): no separate add kernels
-    out = conv.bias.view(1, -1, 1).expand(B, -1, T) if conv.bias is not None else None
+    out = bias.view(1, -1, 1).expand(B, -1, T) if bias is not None else None
     for j in range(k):
         wj = conv.weight[:, :, j].unsqueeze(0).expand(B, -1, -1)
         xj = xp[:, :, j * d:j * d + T]
@@ -95,18 +116,18 @@ class Bottle2neck(nn.Module):
 
     def forward(self, x):
         residual = self.residual(x)
-        out = self.bn1(self.relu(self.conv1(x)))
+        out = _conv_relu_bn(x, self.conv1, self.bn1)
 
         groups = torch.split(out, self.width, 1)
         pieces, carry = [], None
         for i in range(self.nums):
             carry = groups[i] if i == 0 else carry + groups[i]
-            carry = self.bns[i](self.relu(_same_conv1d(carry, self.convs[i])))
+            carry = _conv_relu_bn(carry, self.convs[i], self.bns[i])
             pieces.append(carry)
         pieces.append(groups[self.nums])
         out = torch.cat(pieces, 1)
 
-        out = self.bn3(self.relu(self.conv3(out)))
+        out = _conv_relu_bn(out, self.conv3, self.bn3)
         out = out + residual
         if self.mp:
             out = self.mp(out)

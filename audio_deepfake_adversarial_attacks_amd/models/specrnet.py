@@ -38,8 +38,39 @@ class Residual_block2D(nn.Module):
             self.conv_downsample = nn.Conv2d(cin, cout, kernel_size=1, padding=0, stride=1)
         self.mp = nn.MaxPool2d(2)
 
+    def _fused(self, x) -> bool:
+        """The fused kernels of detector_ops apply: HIP tensor, frozen parameters (an attack is running: only the input
+        gradient is needed, so conv biases and BatchNorm terms are per-channel constants), eval-mode bn2."""
+        if not (x.is_cuda and x.dtype == torch.float32 and _fused_elem_enabled()):
+            return False
+        from .. import detector_ops
+        frozen = not (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()))
+        return frozen and detector_ops.foldable_bn(self.bn2)
+
+    def _forward_fused(self, x):
+        """Same arithmetic as `forward` with the full-resolution elementwise passes folded:
+        conv1 bias + bn2 + LeakyReLU in one pass; conv2 bias + downsample bias + residual add + MaxPool2d in one pass."""
+        import torch.nn.functional as F
+        from .. import detector_ops as D
+        scale, shift = D.bn_eval_affine(self.bn2)
+        if self.conv1.bias is not None:
+            shift = shift + self.conv1.bias.detach() * scale
+        h = F.conv2d(x, self.conv1.weight, None, 1, 1)
+        h = D.affine_lrelu(h, scale, shift, self.lrelu.negative_slope)
+        h = F.conv2d(h, self.conv2.weight, None, 1, 1)
+        bias = self.conv2.bias.detach() if self.conv2.bias is not None else None
+        if self.downsample:
+            identity = F.conv2d(x, self.conv_downsample.weight, None)
+            if self.conv_downsample.bias is not None:
+                bias = self.conv_downsample.bias.detach() if bias is None else bias + self.conv_downsample.bias.detach()
+        else:
+            identity = x
+        return D.add_maxpool2(h, identity, bias)
+
     def forward(self, x):
         # specrnet.py:73-91.  NB conv1 consumes x, not lrelu(bn1(x)) — reference behaviour, kept.
+        if self._fused(x):
+            return self._forward_fused(x)
         if not self.first and self.bn1.training:
             # the reference computes bn1(x) and discards it (:75-78); in train mode that still updates bn1's running
             # statistics, which end up in checkpoints — keep the side effect, skip the wasted pass otherwise
@@ -48,6 +79,12 @@ class Residual_block2D(nn.Module):
         out = self.conv2(self.lrelu(self.bn2(self.conv1(x))))
         identity = self.conv_downsample(x) if self.downsample else x
         return self.mp(out + identity)
+
+
+def _fused_elem_enabled() -> bool:
+    """ADVSTEP_SPECRNET_ELEM=0 keeps the plain ATen / MIOpen elementwise chains (A/B measurements); default on."""
+    import os
+    return os.environ.get("ADVSTEP_SPECRNET_ELEM", "1") != "0"
 
 
 def _fused_gru_enabled() -> bool:
@@ -89,11 +126,20 @@ class BaseSpecRNet(nn.Module):
         gate = gate.view(gate.size(0), gate.size(1), 1, 1)
         return feats * gate + gate
 
+    def _attend_pool(self, feats, fc):
+        """`self.pool(self._attend(feats, fc))` (specrnet.py:163-172); on a HIP tensor the gate multiply-add and the 2x2 pooling
+        are one pass (detector_ops.gate_maxpool2: differentiable in the features and in the gate)."""
+        if feats.is_cuda and feats.dtype == torch.float32 and _fused_elem_enabled():
+            from .. import detector_ops
+            gate = self.sig(fc(self.avgpool(feats).view(feats.size(0), -1)))
+            return detector_ops.gate_maxpool2(feats, gate)
+        return self.pool(self._attend(feats, fc))
+
     def _compute_embedding(self, x):
         x = self.selu(self.first_bn(x))
-        x = self.pool(self._attend(self.block0(x), self.fc_attention0))
-        x = self.pool(self._attend(self.block2(x), self.fc_attention2))
-        x = self.pool(self._attend(self.block4(x), self.fc_attention4))
+        x = self._attend_pool(self.block0(x), self.fc_attention0)
+        x = self._attend_pool(self.block2(x), self.fc_attention2)
+        x = self._attend_pool(self.block4(x), self.fc_attention4)
         x = self.selu(self.bn_before_gru(x))
         x = x.squeeze(-2).permute(0, 2, 1)
         x = self._run_gru(x)

@@ -1,0 +1,57 @@
+/* advstep_detector.h — C ABI of the fused elementwise / pooling kernels of the SpecRNet and RawNet3 detectors
+ * (csrc/detector_elem.hip; SURVEY.md section 8, rows a12 / a13: these op chains run 40-100 times per batch inside
+ * `model(adv)` and are pure HBM streaming over the detectors' largest activations).
+ *
+ * Conventions as in advstep.h: raw device pointers, contiguous float32 NCHW / NCL tensors, caller-owned outputs, launches on
+ * the given HIP stream, status code returned, no global state.  P = H * W (or L) is the per-channel plane size. */
+#ifndef ADVSTEP_DETECTOR_H
+#define ADVSTEP_DETECTOR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "advstep.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- per-channel affine + activation --------------------------------------------------------------------------------
+ * mode 0  y = leaky_relu(x * scale[c] + shift[c], slope)    SpecRNet: Conv2d bias + BatchNorm2d(eval) -> LeakyReLU(0.3)
+ *                                                            (src/models/specrnet.py:76-81: bn2 -> lrelu between conv1, conv2)
+ * mode 1  y = relu(x + pre[c]) * scale[c] + shift[c]         RawNet3: Conv1d bias -> ReLU -> BatchNorm1d(eval)
+ *                                                            (src/models/rawnet3.py:240-242, 252-254, 262-264)
+ * x, y (N, C, P); scale, shift, pre (C) (pre may be NULL = 0).  One read + one write instead of two or three of each. */
+int advstep_affine_act_forward_f32(const float *x, const float *scale, const float *shift, const float *pre, float *y,
+                                   int64_t N, int64_t C, int64_t P, int mode, float slope, advstep_stream_t stream);
+/* gx = gy * d y / d x, recomputed from x (mode 0: slope where x * scale + shift <= 0; mode 1: 0 where x + pre <= 0). */
+int advstep_affine_act_backward_f32(const float *gy, const float *x, const float *scale, const float *shift,
+                                    const float *pre, float *gx, int64_t N, int64_t C, int64_t P, int mode, float slope,
+                                    advstep_stream_t stream);
+
+/* ---- residual add + MaxPool2d(2) --------------------------------------------------------------------------------------
+ * y (N, C, H/2, W/2) = MaxPool2d(2)(a + b + bias[c]), sel = one byte per pooled output (bit 1 = dh, bit 0 = dw of the
+ * winner; ATen's scan order and NaN rule).  SpecRNet: `mp(out + identity)` (src/models/specrnet.py:83-90) with the two
+ * convolutions' bias adds folded in (bias = bias_conv2 + bias_downsample, or NULL).  b may be NULL (plain pooling). */
+int advstep_add_maxpool2_forward_f32(const float *a, const float *b, const float *bias, float *y, uint8_t *sel, int64_t N,
+                                     int64_t C, int64_t H, int64_t W, advstep_stream_t stream);
+/* g (N, C, H, W): gy at the winner of every 2x2 window, 0 elsewhere (trailing odd row / column included) — the gradient
+ * of both a and b. */
+int advstep_maxpool2_backward_f32(const float *gy, const uint8_t *sel, float *g, int64_t N, int64_t C, int64_t H, int64_t W,
+                                  advstep_stream_t stream);
+
+/* ---- channel gate + MaxPool2d(2) --------------------------------------------------------------------------------------
+ * y = MaxPool2d(2)(x * gate[n, c] + gate[n, c]) (src/models/specrnet.py:145-149 followed by `self.pool`, :163-172).
+ * Backward: gx = gate * scatter(gy); ggate_partial (N * C, blocks) holds per-workgroup partial sums of
+ * gy * (x_winner + 1) in a fixed order — the caller sums the last dimension (advstep_gate_maxpool2_blocks gives it). */
+size_t advstep_gate_maxpool2_blocks(int64_t H, int64_t W);
+int advstep_gate_maxpool2_forward_f32(const float *x, const float *gate, float *y, uint8_t *sel, int64_t N, int64_t C,
+                                      int64_t H, int64_t W, advstep_stream_t stream);
+int advstep_gate_maxpool2_backward_f32(const float *gy, const uint8_t *sel, const float *x, const float *gate, float *gx,
+                                       float *ggate_partial, int64_t N, int64_t C, int64_t H, int64_t W,
+                                       advstep_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -154,10 +154,11 @@ def test_fgsm_on_lcnn_agrees_with_cpu_oracle(cuda, lcnn_model, parity_record, mo
     Stated rule: a sample's perturbation sign may differ only where the CPU gradient satisfies
     |grad| <= FLIP_K * max|grad| of its utterance (a near-tie max-feature-map / pool winner going the other way re-routes
     gradient entries of that size); everywhere else the perturbed waveform is within 1e-5 max-abs.  Measured on MI355X
-    (profiles/r02_parity.json): 12 flips in 516 800 samples — the reference's own 1-vs-8-thread figure is 6 — the largest at
-    1.2 % of its row's maximum, 0.0 difference on the agreeing samples.  The same comparison with every fused kernel
-    switched off (plain PyTorch-ROCm: MIOpen, rocFFT) is recorded next to it: the flips are cross-device arithmetic, not
-    the kernels'."""
+    (profiles/r02_parity.json): 12 flips in 516 800 samples (2.3e-5; the reference's own 1-vs-8-thread figure is 6), the
+    largest at 1.2 % of its row's maximum, 0.0 difference on every agreeing sample.  The same comparison with every fused
+    kernel switched off (plain PyTorch-ROCm: MIOpen, rocFFT) is recorded next to it and shows 0 flips on this input: the
+    12 come from the fused kernels' different — equally valid — summation orders (fp32 Winograd, in-LDS FFT), not from
+    the device as such."""
     import copy
     from audio_deepfake_adversarial_attacks_amd import torchattacks
     from audio_deepfake_adversarial_attacks_amd.aa import utils as aa_utils

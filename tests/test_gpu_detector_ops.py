@@ -1,0 +1,150 @@
+"""`-m gpu`: the fused elementwise / pooling kernels of include/advstep_detector.h (SpecRNet, RawNet3) against the ATen op
+chains they replace — same arithmetic in the same order, so forward values, selections and input gradients are compared
+bit for bit where the order is the same, and within float rounding where a reduction order differs (the gate gradient)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def D(cuda):
+    from audio_deepfake_adversarial_attacks_amd import detector_ops
+    return detector_ops
+
+
+def rnd(shape, seed, cuda, scale=1.0):
+    return (torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale).to(cuda)
+
+
+@pytest.mark.parametrize("shape", [(3, 20, 16, 24), (2, 5, 7, 9), (1, 64, 1, 3), (4, 128, 1001), (2, 3, 6435)])
+def test_affine_lrelu_and_relu_affine_match_aten(D, cuda, shape):
+    C = shape[1]
+    x = rnd(shape, 1, cuda).requires_grad_(True)
+    scale, shift, pre = rnd((C,), 2, cuda).abs() + 0.5, rnd((C,), 3, cuda), rnd((C,), 4, cuda)
+    gy = rnd(shape, 5, cuda)
+    view = (1, C) + (1,) * (len(shape) - 2)
+    # mode 0: leaky_relu(x * s + t, 0.3)
+    ref = F.leaky_relu(x * scale.view(view) + shift.view(view), 0.3)
+    (g_ref,) = torch.autograd.grad(ref, x, gy)
+    got = D.affine_lrelu(x, scale, shift, 0.3)
+    (g_got,) = torch.autograd.grad(got, x, gy)
+    assert torch.equal(got, ref)
+    assert torch.allclose(g_got, g_ref, rtol=1e-6, atol=0)          # (gy * d) * s vs autograd's grouping: one rounding apart
+    # mode 1: relu(x + pre) * s + t
+    ref = torch.relu(x + pre.view(view)) * scale.view(view) + shift.view(view)
+    (g_ref,) = torch.autograd.grad(ref, x, gy)
+    got = D.relu_affine(x, scale, shift, pre)
+    (g_got,) = torch.autograd.grad(got, x, gy)
+    assert torch.equal(got, ref) and torch.equal(g_got, g_ref)
+    got = D.relu_affine(x, scale, shift, None)
+    assert torch.equal(got, torch.relu(x) * scale.view(view) + shift.view(view))
+
+
+def test_bn_eval_affine_equals_batch_norm(D, cuda):
+    bn = torch.nn.BatchNorm2d(6).to(cuda).eval()
+    with torch.no_grad():
+        bn.running_mean.uniform_(-1, 1), bn.running_var.uniform_(0.5, 2), bn.weight.uniform_(0.5, 1.5), bn.bias.uniform_(-1, 1)
+    x = rnd((3, 6, 5, 7), 7, cuda)
+    scale, shift = D.bn_eval_affine(bn)
+    want = bn(x)
+    got = x * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    assert (got - want).abs().max().item() <= 2e-6 * want.abs().max().item()
+    assert D.bn_eval_affine(bn)[0] is scale                         # cached
+    with torch.no_grad():
+        bn.weight.mul_(2.0)
+    assert D.bn_eval_affine(bn)[0] is not scale                      # refreshed when a parameter changes
+
+
+@pytest.mark.parametrize("shape", [(2, 20, 80, 404), (3, 5, 7, 9), (1, 2, 2, 2), (2, 64, 20, 101), (2, 3, 5, 25), (1, 4, 3, 2)])
+@pytest.mark.parametrize("kind", ["ab_bias", "a_only", "ties", "nans"])
+def test_add_maxpool2_matches_aten(D, cuda, shape, kind):
+    N, C, H, W = shape
+    a = rnd(shape, 11, cuda)
+    b = rnd(shape, 12, cuda) if kind != "a_only" else None
+    bias = rnd((C,), 13, cuda) if kind == "ab_bias" else None
+    if kind == "ties":
+        a = torch.round(a)                                           # many equal values inside a window
+        b = torch.round(b)
+    if kind == "nans":
+        a = a.clone()
+        a.view(-1)[::7] = float("nan")
+    a.requires_grad_(True)
+    s = a if b is None else a + b
+    if bias is not None:
+        s = s + bias.view(1, -1, 1, 1)
+    ref = F.max_pool2d(s, 2)
+    got = D.add_maxpool2(a, b, bias)
+    assert got.shape == ref.shape == (N, C, H // 2, W // 2)
+    assert torch.equal(torch.nan_to_num(got, nan=-7.0), torch.nan_to_num(ref, nan=-7.0))
+    if ref.numel() == 0:
+        return
+    gy = rnd(tuple(ref.shape), 14, cuda)
+    (g_ref,) = torch.autograd.grad(ref, a, gy)
+    (g_got,) = torch.autograd.grad(got, a, gy)
+    assert torch.equal(g_got, g_ref)                                  # same winner at ties and NaNs, zeros in odd tails
+
+
+@pytest.mark.parametrize("shape", [(2, 20, 40, 202), (3, 5, 7, 9), (2, 64, 10, 50), (1, 3, 2, 12)])
+def test_gate_maxpool2_matches_aten(D, cuda, shape):
+    N, C, H, W = shape
+    x = rnd(shape, 21, cuda).requires_grad_(True)
+    gate = torch.sigmoid(rnd((N, C), 22, cuda)).requires_grad_(True)
+    g4 = gate.view(N, C, 1, 1)
+    ref = F.max_pool2d(x * g4 + g4, 2)
+    got = D.gate_maxpool2(x, gate)
+    assert torch.equal(got, ref)
+    gy = rnd(tuple(ref.shape), 23, cuda)
+    gx_ref, gg_ref = torch.autograd.grad(ref, (x, gate), gy)
+    gx, gg = torch.autograd.grad(got, (x, gate), gy)
+    assert torch.equal(gx, gx_ref)
+    assert torch.allclose(gg, gg_ref, rtol=2e-5, atol=2e-5 * gg_ref.abs().max().item())
+    # fixed summation order: bit-reproducible
+    gx2, gg2 = torch.autograd.grad(D.gate_maxpool2(x, gate), (x, gate), gy)
+    assert torch.equal(gg, gg2) and torch.equal(gx, gx2)
+
+
+def attack_mode_frozen(model):
+    model.train()
+    for m in model.modules():
+        if "BatchNorm" in m.__class__.__name__ or "Dropout" in m.__class__.__name__:
+            m.eval()
+    for p in model.parameters():
+        p.requires_grad_(False)
+    return model
+
+
+@pytest.mark.parametrize("name,cfg,switch", [("specrnet", {"frontend_algorithm": ["mel_spec"], "input_channels": 2}, "ADVSTEP_SPECRNET_ELEM"),
+                                             ("rawnet3", {}, "ADVSTEP_RAWNET3_ELEM")])
+def test_detectors_with_fused_elementwise_passes_agree_with_plain_modules(cuda, monkeypatch, parity_record, name, cfg, switch):
+    """Whole detector, attack mode, frozen parameters: fused elementwise / pooling passes vs the plain torch modules.  Bias
+    adds move behind the convolution (one rounding apart), so logits agree to float tolerance; a max-pool winner at a
+    near tie may go the other way (SpecRNet), so the gradient bound is relative."""
+    from audio_deepfake_adversarial_attacks_amd.models.models import get_model
+    torch.manual_seed(3)
+    model = attack_mode_frozen(get_model(name, dict(cfg), str(cuda)).to(cuda))
+    with torch.no_grad():                                             # non-trivial BatchNorm statistics
+        g = torch.Generator().manual_seed(4)
+        for m in model.modules():
+            if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+                m.running_mean.copy_(torch.empty(m.running_mean.shape).uniform_(-0.2, 0.2, generator=g))
+                m.running_var.copy_(torch.empty(m.running_var.shape).uniform_(0.5, 1.5, generator=g))
+    x = (torch.randn(2, 64_600, generator=torch.Generator().manual_seed(5)) * 0.05).to(cuda)
+
+    def run(on):
+        monkeypatch.setenv(switch, "1" if on else "0")
+        a = x.clone().requires_grad_(True)
+        z = model(a)
+        (gr,) = torch.autograd.grad(z.sum(), a)
+        return z.detach(), gr
+
+    z0, g0 = run(False)
+    z1, g1 = run(True)
+    fig = {"logit_max_abs": (z0 - z1).abs().max().item(), "logit_scale": z0.abs().max().item(),
+           "grad_rel_l2": ((g0 - g1).norm() / g0.norm()).item()}
+    parity_record[f"{name}_fused_elementwise_vs_plain_modules"] = fig
+    assert fig["logit_max_abs"] <= 1e-4 * max(fig["logit_scale"], 1.0), fig
+    assert fig["grad_rel_l2"] <= 5e-3, fig
+    for p in model.parameters():
+        p.requires_grad_(True)

@@ -20,7 +20,7 @@ def lib():
 
 
 def declared_symbols():
-    header = "".join((ROOT / "include" / h).read_text() for h in ("advstep.h", "advstep_lcnn.h", "advstep_frontend.h", "advstep_fab.h", "advstep_dataset.h"))
+    header = "".join(h.read_text() for h in sorted((ROOT / "include").glob("*.h")))
     header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
     return sorted(set(re.findall(r"\b(advstep_[a-z0-9_]+)\s*\(", header)))
 
