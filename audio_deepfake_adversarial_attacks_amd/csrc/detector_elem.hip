@@ -43,6 +43,10 @@ __device__ __forceinline__ float act_bwd(float gy, float x, float s, float t, fl
     return (x + pre) > 0.0f ? gy * s : 0.0f;
 }
 
+// VEC: every tensor base is 16-byte aligned.  A plane (n, c) starts at element nc * P, which is 16-byte aligned only when
+// P % 4 == 0 (SpecRNet's 2-D planes) — RawNet3's planes are 6435 / 1287 / 429 frames long — so a plane is split into a
+// scalar head (up to its first aligned element), a float4 body and a scalar tail; the head and tail (<= 6 elements) are
+// handled by the first threads of the plane's first workgroup.
 template <int MODE, bool BWD, bool VEC>
 __global__ __launch_bounds__(kBlock) void affine_act_kernel(const float *__restrict__ gy, const float *__restrict__ x,
                                                             const float *__restrict__ scale, const float *__restrict__ shift,
@@ -55,15 +59,20 @@ __global__ __launch_bounds__(kBlock) void affine_act_kernel(const float *__restr
     const float *gp = BWD ? gy + nc * P : nullptr;
     float *op = out + nc * P;
     if (VEC) {
-        const int64_t G = P / 4;
+        int64_t head = (4 - ((nc * P) & 3)) & 3;
+        if (head > P) head = P;
+        const int64_t G = (P - head) / 4, tail0 = head + 4 * G;
+        const float4 *xv4 = reinterpret_cast<const float4 *>(xp + head);
+        const float4 *gv4 = BWD ? reinterpret_cast<const float4 *>(gp + head) : nullptr;
+        float4 *ov4 = reinterpret_cast<float4 *>(op + head);
         const int64_t g0 = (int64_t)blockIdx.y * (kBlock * kVecPerThread) + threadIdx.x;
         float4 xv[kVecPerThread], gv[kVecPerThread];
 #pragma unroll
         for (int k = 0; k < kVecPerThread; ++k) {
             const int64_t g = g0 + (int64_t)k * kBlock;
             if (g < G) {
-                xv[k] = reinterpret_cast<const float4 *>(xp)[g];
-                if (BWD) gv[k] = reinterpret_cast<const float4 *>(gp)[g];
+                xv[k] = xv4[g];
+                if (BWD) gv[k] = gv4[g];
             }
         }
 #pragma unroll
@@ -82,8 +91,14 @@ __global__ __launch_bounds__(kBlock) void affine_act_kernel(const float *__restr
                     o.z = act_fwd<MODE>(xv[k].z, s, t, pr, slope);
                     o.w = act_fwd<MODE>(xv[k].w, s, t, pr, slope);
                 }
-                reinterpret_cast<float4 *>(op)[g] = o;
+                ov4[g] = o;
             }
+        }
+        if (blockIdx.y == 0 && threadIdx.x < 8) {
+            // threads 0-3: head element threadIdx.x; threads 4-7: tail element tail0 + threadIdx.x - 4
+            const int64_t i = threadIdx.x < 4 ? (int64_t)threadIdx.x : tail0 + threadIdx.x - 4;
+            const bool live = threadIdx.x < 4 ? i < head : i < P;
+            if (live) op[i] = BWD ? act_bwd<MODE>(gp[i], xp[i], s, t, pr, slope) : act_fwd<MODE>(xp[i], s, t, pr, slope);
         }
     } else {
         const int64_t i0 = ((int64_t)blockIdx.y * (kBlock * kVecPerThread) + threadIdx.x) * 4;
@@ -104,7 +119,7 @@ int launch_affine(const float *gy, const float *x, const float *scale, const flo
     if (N * C * P == 0) return ADVSTEP_OK;
     const int64_t tiles = ceil_div(ceil_div(P, 4), kBlock * kVecPerThread);
     if (!x || !scale || !shift || !out || (BWD && !gy) || N * C > 0x7fffffffLL || tiles > 65535) return ADVSTEP_EINVAL;
-    const bool vec = P % 4 == 0 && aligned16(x) && aligned16(out) && (!BWD || aligned16(gy));
+    const bool vec = aligned16(x) && aligned16(out) && (!BWD || aligned16(gy));
     const dim3 grid((unsigned)(N * C), (unsigned)tiles), block(kBlock);
 #define GO(MODE, VEC)                                                                                                   \
     hipLaunchKernelGGL((affine_act_kernel<MODE, BWD, VEC>), grid, block, 0, st, gy, x, scale, shift, pre, out, C, P, slope)
@@ -225,6 +240,41 @@ __global__ __launch_bounds__(kBlock) void pool2_backward_kernel(const float *__r
     }
 }
 
+
+// ---- residual add + MaxPool1d(k) (kernel = stride = k, 2 <= k <= 8): thread = one pooled output ---------------------------
+// at::native max-pool scan rule as pool4 above; sel = winner's offset inside its window (one byte).
+__global__ __launch_bounds__(kBlock) void pool1d_forward_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                                float *__restrict__ y, uint8_t *__restrict__ sel, int64_t L,
+                                                                int64_t Lo, int k) {
+    const int64_t nc = blockIdx.x;
+    const int64_t j = (int64_t)blockIdx.y * kBlock + threadIdx.x;
+    if (j >= Lo) return;
+    const float *ap = a + nc * L + j * k;
+    const float *bp = b ? b + nc * L + j * k : nullptr;
+    float best = -INFINITY;
+    int code = 0;
+    for (int e = 0; e < k; ++e) {
+        const float v = bp ? ap[e] + bp[e] : ap[e];
+        if (v > best || v != v) { best = v; code = e; }
+    }
+    y[nc * Lo + j] = best;
+    sel[nc * Lo + j] = (uint8_t)code;
+}
+
+// thread = one pooled output: writes its k-wide window of the gradient (and, for the last window, the dropped tail)
+__global__ __launch_bounds__(kBlock) void pool1d_backward_kernel(const float *__restrict__ gy, const uint8_t *__restrict__ sel,
+                                                                 float *__restrict__ g, int64_t L, int64_t Lo, int k) {
+    const int64_t nc = blockIdx.x;
+    const int64_t j = (int64_t)blockIdx.y * kBlock + threadIdx.x;
+    if (j >= Lo) return;
+    const float gv = gy[nc * Lo + j];
+    const int code = sel[nc * Lo + j];
+    float *gp = g + nc * L + j * k;
+    for (int e = 0; e < k; ++e) gp[e] = e == code ? gv : 0.0f;
+    if (j == Lo - 1)
+        for (int64_t i = Lo * k; i < L; ++i) g[nc * L + i] = 0.0f;
+}
+
 inline bool pool_dims_ok(int64_t N, int64_t C, int64_t H, int64_t W) {
     // planes on grid.x, tiles of a plane on grid.y (<= 65535 workgroups of 256 threads per plane)
     return N >= 0 && C >= 0 && H >= 0 && W >= 0 && N * C <= 0x7fffffffLL && H * ((W + 3) / 4) <= 65535LL * kBlock;
@@ -254,6 +304,31 @@ int advstep_add_maxpool2_forward_f32(const float *a, const float *b, const float
     const dim3 grid((unsigned)(N * C), (unsigned)ceil_div(Ho * ((Wo + 1) / 2), kBlock)), block(kBlock);
     hipLaunchKernelGGL(pool2_forward_kernel<0>, grid, block, 0, as_stream(stream), a, b, bias, (const float *)nullptr, y, sel, C,
                        (int)H, (int)W);
+    return status_after_launch();
+}
+
+int advstep_add_maxpool1d_forward_f32(const float *a, const float *b, float *y, uint8_t *sel, int64_t N, int64_t C, int64_t L,
+                                     int64_t k, advstep_stream_t stream) {
+    if (N < 0 || C < 0 || L < 0 || k < 2 || k > 8 || N * C > 0x7fffffffLL) return ADVSTEP_EINVAL;
+    const int64_t Lo = L / k;
+    if (N * C * Lo == 0) return ADVSTEP_OK;
+    if (!a || !y || !sel || ceil_div(Lo, kBlock) > 65535) return ADVSTEP_EINVAL;
+    const dim3 grid((unsigned)(N * C), (unsigned)ceil_div(Lo, kBlock)), block(kBlock);
+    hipLaunchKernelGGL(pool1d_forward_kernel, grid, block, 0, as_stream(stream), a, b, y, sel, L, Lo, (int)k);
+    return status_after_launch();
+}
+
+int advstep_maxpool1d_backward_f32(const float *gy, const uint8_t *sel, float *g, int64_t N, int64_t C, int64_t L, int64_t k,
+                                   advstep_stream_t stream) {
+    if (N < 0 || C < 0 || L < 0 || k < 2 || k > 8 || N * C > 0x7fffffffLL) return ADVSTEP_EINVAL;
+    if (N * C * L == 0) return ADVSTEP_OK;
+    const int64_t Lo = L / k;
+    if (!g || ceil_div(Lo, kBlock) > 65535) return ADVSTEP_EINVAL;
+    if (Lo == 0)
+        return hipMemsetAsync(g, 0, (size_t)(N * C * L) * sizeof(float), as_stream(stream)) == hipSuccess ? ADVSTEP_OK : ADVSTEP_ELAUNCH;
+    if (!gy || !sel) return ADVSTEP_EINVAL;
+    const dim3 grid((unsigned)(N * C), (unsigned)ceil_div(Lo, kBlock)), block(kBlock);
+    hipLaunchKernelGGL(pool1d_backward_kernel, grid, block, 0, as_stream(stream), gy, sel, g, L, Lo, (int)k);
     return status_after_launch();
 }
 

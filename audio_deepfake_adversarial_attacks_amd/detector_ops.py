@@ -117,6 +117,54 @@ def add_maxpool2(a: torch.Tensor, b: Optional[torch.Tensor] = None, bias: Option
     return _AddMaxPool2.apply(a.contiguous(), None if b is None else b.contiguous(), bias)
 
 
+class _AddMaxPool1d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, k):
+        _require(a, "a")
+        if a.dim() != 3:
+            raise ValueError(f"expected (N, C, L), got {tuple(a.shape)}")
+        if b is not None:
+            _require(b, "b")
+            if b.shape != a.shape:
+                raise ValueError("a and b must have the same shape")
+        N, C, L = a.shape
+        y = torch.empty((N, C, L // k), dtype=a.dtype, device=a.device)
+        sel = torch.empty(max(y.numel(), 1), dtype=torch.uint8, device=a.device)
+        with _Launch("add_maxpool1d_forward", a.device):
+            st = _lib.load().advstep_add_maxpool1d_forward_f32(a.data_ptr(), b.data_ptr() if b is not None else None, y.data_ptr(),
+                                                               sel.data_ptr(), N, C, L, k, _stream(a.device))
+        _lib.check(st, "advstep_add_maxpool1d_forward_f32")
+        ctx.save_for_backward(sel)
+        ctx.meta = (N, C, L, k, b is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (sel,) = ctx.saved_tensors
+        N, C, L, k, two = ctx.meta
+        gy = gy.contiguous()
+        g = torch.empty((N, C, L), dtype=gy.dtype, device=gy.device)
+        with _Launch("maxpool1d_backward", gy.device):
+            st = _lib.load().advstep_maxpool1d_backward_f32(gy.data_ptr(), sel.data_ptr(), g.data_ptr(), N, C, L, k,
+                                                            _stream(gy.device))
+        _lib.check(st, "advstep_maxpool1d_backward_f32")
+        return g, (g if two else None), None
+
+
+def add_maxpool1d(a: torch.Tensor, b: Optional[torch.Tensor], k: int) -> torch.Tensor:
+    """MaxPool1d(k)(a + b) over (N, C, L), kernel = stride = k in 2..8; b optional."""
+    return _AddMaxPool1d.apply(a.contiguous(), None if b is None else b.contiguous(), int(k))
+
+
+def maxpool1d_supported(pool) -> bool:
+    """nn.MaxPool1d with kernel = stride in 2..8, no padding / dilation / ceil mode / indices."""
+    k = pool.kernel_size if isinstance(pool.kernel_size, int) else pool.kernel_size[0]
+    st = pool.stride if isinstance(pool.stride, int) else pool.stride[0]
+    pad = pool.padding if isinstance(pool.padding, int) else pool.padding[0]
+    dil = pool.dilation if isinstance(pool.dilation, int) else pool.dilation[0]
+    return 2 <= k <= 8 and st == k and pad == 0 and dil == 1 and not pool.ceil_mode and not pool.return_indices
+
+
 class _GateMaxPool2(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gate):

@@ -66,6 +66,17 @@ def _conv_relu_bn(x: torch.Tensor, conv: nn.Conv1d, bn: nn.BatchNorm1d) -> torch
     return bn(torch.relu(_same_conv1d(x, conv)))
 
 
+def _add_pool(a: torch.Tensor, b, pool: nn.MaxPool1d) -> torch.Tensor:
+    """`pool(a + b)` (b may be None): fused on a HIP tensor (detector_ops.add_maxpool1d: one byte per output instead of
+    int64 indices, the sum never written), the torch modules otherwise."""
+    if a.is_cuda and a.dtype == torch.float32 and _fused_elem_enabled():
+        from .. import detector_ops as D
+        if D.maxpool1d_supported(pool):
+            k = pool.kernel_size if isinstance(pool.kernel_size, int) else pool.kernel_size[0]
+            return D.add_maxpool1d(a, b, k)
+    return pool(a if b is None else a + b)
+
+
 def _same_conv1d(x: torch.Tensor, conv: nn.Conv1d, with_bias: bool = True) -> torch.Tensor:
     """`conv(x)` for the dilated "same" Conv1d(width, width, 3, dilation=d, padding=d) of the Res2Net branches.
 
@@ -128,9 +139,10 @@ class Bottle2neck(nn.Module):
         out = torch.cat(pieces, 1)
 
         out = _conv_relu_bn(out, self.conv3, self.bn3)
-        out = out + residual
         if self.mp:
-            out = self.mp(out)
+            out = _add_pool(out, residual, self.mp)        # `out += residual` -> MaxPool1d, one pass on a HIP tensor
+        else:
+            out = out + residual
         return self.afms(out)
 
 
@@ -186,8 +198,9 @@ class RawNet3(nn.Module):
 
         x1 = self.layer1(x)
         x2 = self.layer2(x1)
-        x3 = self.layer3(self.mp3(x1) + x2) if self.summed else self.layer3(x2)
-        x = self.relu(self.layer4(torch.cat((self.mp3(x1), x2, x3), dim=1)))
+        x1p = _add_pool(x1, None, self.mp3)      # the reference evaluates mp3(x1) twice (:96, :102): same values, once here
+        x3 = self.layer3(x1p + x2) if self.summed else self.layer3(x2)
+        x = self.relu(self.layer4(torch.cat((x1p, x2, x3), dim=1)))
 
         t = x.size()[-1]
         if self.context:

@@ -40,6 +40,15 @@ int advstep_add_maxpool2_forward_f32(const float *a, const float *b, const float
 int advstep_maxpool2_backward_f32(const float *gy, const uint8_t *sel, float *g, int64_t N, int64_t C, int64_t H, int64_t W,
                                   advstep_stream_t stream);
 
+/* ---- residual add + MaxPool1d(k), kernel = stride = k (2 <= k <= 8) -----------------------------------------------------
+ * y (N, C, L/k) = MaxPool1d(k)(a + b); b may be NULL; sel = winner's offset inside its window, one byte per output.
+ * RawNet3: `out += residual` -> `MaxPool1d(5 | 3)` (src/models/rawnet3.py:266-269) and `mp3(x1)` (:96, 102).
+ * Backward: g (N, C, L) = gy at the winners, 0 elsewhere (the dropped tail of L % k elements included). */
+int advstep_add_maxpool1d_forward_f32(const float *a, const float *b, float *y, uint8_t *sel, int64_t N, int64_t C, int64_t L,
+                                      int64_t k, advstep_stream_t stream);
+int advstep_maxpool1d_backward_f32(const float *gy, const uint8_t *sel, float *g, int64_t N, int64_t C, int64_t L, int64_t k,
+                                   advstep_stream_t stream);
+
 /* ---- channel gate + MaxPool2d(2) --------------------------------------------------------------------------------------
  * y = MaxPool2d(2)(x * gate[n, c] + gate[n, c]) (src/models/specrnet.py:145-149 followed by `self.pool`, :163-172).
  * Backward: gx = gate * scatter(gy); ggate_partial (N * C, blocks) holds per-workgroup partial sums of

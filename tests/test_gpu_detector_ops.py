@@ -86,6 +86,31 @@ def test_add_maxpool2_matches_aten(D, cuda, shape, kind):
     assert torch.equal(g_got, g_ref)                                  # same winner at ties and NaNs, zeros in odd tails
 
 
+@pytest.mark.parametrize("shape,k", [((2, 16, 6435), 5), ((3, 7, 1287), 3), ((1, 2, 17), 5), ((2, 3, 4), 5), ((2, 4, 30), 2)])
+@pytest.mark.parametrize("kind", ["ab", "a_only", "ties", "nans"])
+def test_add_maxpool1d_matches_aten(D, cuda, shape, k, kind):
+    a = rnd(shape, 31, cuda)
+    b = rnd(shape, 32, cuda) if kind != "a_only" else None
+    if kind == "ties":
+        a, b = torch.round(a), torch.round(b)
+    if kind == "nans":
+        a = a.clone()
+        a.view(-1)[::11] = float("nan")
+    a.requires_grad_(True)
+    s = a if b is None else a + b
+    got = D.add_maxpool1d(a, b, k)
+    if shape[2] < k:
+        assert got.shape == (shape[0], shape[1], 0)
+        return
+    ref = F.max_pool1d(s, k)
+    assert got.shape == ref.shape
+    assert torch.equal(torch.nan_to_num(got, nan=-7.0), torch.nan_to_num(ref, nan=-7.0))
+    gy = rnd(tuple(ref.shape), 33, cuda)
+    (g_ref,) = torch.autograd.grad(ref, a, gy)
+    (g_got,) = torch.autograd.grad(got, a, gy)
+    assert torch.equal(g_got, g_ref)
+
+
 @pytest.mark.parametrize("shape", [(2, 20, 40, 202), (3, 5, 7, 9), (2, 64, 10, 50), (1, 3, 2, 12)])
 def test_gate_maxpool2_matches_aten(D, cuda, shape):
     N, C, H, W = shape

@@ -21,11 +21,11 @@ import re
 import sys
 
 T = 64_600
-# entry point -> (kernel-name patterns of ONE call, algorithmic bytes per sample)
+# entry point -> (kernel-name patterns of ONE call, algorithmic bytes per sample, batch size of the pass = bench.py's)
 ENTRY_POINTS = {
-    "pgd_linf_step": ([r"flat_vec_kernel<3,.*PgdLinfOp"], 16),
-    "pgd_l2_step": ([r"sumsq_partial_kernel", r"pgd_l2_delta_kernel", r"pgd_l2_project_kernel"], 16),
-    "cw_adam_step": ([r"cw_adam_vec_kernel"], 32),
+    "pgd_linf_step": ([r"flat_vec_kernel<3,.*PgdLinfOp"], 16, 128),
+    "pgd_l2_step": ([r"sumsq_partial_kernel", r"pgd_l2_delta_kernel", r"pgd_l2_project_kernel"], 16, 128),
+    "cw_adam_step": ([r"cw_adam_vec_kernel"], 32, 64),
 }
 
 
@@ -38,9 +38,9 @@ def main():
             for r in csv.DictReader(f):
                 rows[r["Kernel_Name"]][r["Counter_Name"]].append((int(r["Grid_Size"]), float(r["Counter_Value"])))
     table = {}
-    for entry, (patterns, bytes_per_sample) in ENTRY_POINTS.items():
+    for entry, (patterns, bytes_per_sample, batch) in ENTRY_POINTS.items():
         fetch = write = 0.0
-        batch, launches, found = None, None, True
+        launches, found = None, True
         for pat in patterns:
             names = [k for k in rows if re.search(pat, k)]
             if not names or not all(c in rows[names[0]] for c in ("FETCH_SIZE", "WRITE_SIZE")):
@@ -54,9 +54,10 @@ def main():
             launches = len(f_vals)
         if not found:
             continue
-        # the batch size is recovered from the written bytes: every priced kernel writes whole (B, T) f32 arrays
+        # sanity: every priced kernel writes whole (batch, T) f32 arrays (1, 1 and 3 of them)
         arrays_written = {"pgd_linf_step": 1, "pgd_l2_step": 1, "cw_adam_step": 3}[entry]
-        batch = round(write / arrays_written / (T * 4))
+        if abs(write / arrays_written / (batch * T * 4) - 1.0) > 0.02:
+            raise SystemExit(f"{entry}: {write:.0f} B written per launch does not look like {arrays_written} x ({batch}, {T}) f32")
         table[entry] = {"batch": batch, "hbm_bytes_per_launch": fetch + write, "fetch_bytes_corrected": fetch,
                         "write_bytes": write, "algorithmic_bytes_per_launch": bytes_per_sample * batch * T,
                         "ratio_to_algorithmic": (fetch + write) / (bytes_per_sample * batch * T), "launches_averaged": launches}
