@@ -551,6 +551,106 @@ __global__ __launch_bounds__(kBlock) void pgd_l2_project_kernel(const float *__r
     if (tile == 0 && threadIdx.x == 0 && dnorm) dnorm[b] = dn;
 }
 
+
+// ---- a6 in ONE pass: the row's workgroups keep their tiles in registers across the two row reductions ----------------------
+// 16 B per sample (adv, grad, orig read once; out written once) instead of 32.  A row is 16 workgroups (T = 64 600); its
+// two norms are exchanged INSIDE the launch through 8-byte {tag, value} granules (one per workgroup and phase, written by ONE
+// agent-scope store, re-read with agent-scope loads until every tag of the row shows the phase: the data is the flag, no
+// fence — /opt/skills/guides/cdna_hip_programming.md Guideline 16, form R2).  The granules are zeroed by a memset node
+// before every launch; tag = phase (1, 2).  The partial sums and their re-reduction are the three-kernel path's own
+// (same block_reduce, same order): results are bit-identical to it.  Used only when every workgroup of the launch is
+// resident at once (B * C <= 8 per CU * 256 CUs at <= 64 VGPRs), so a spinning workgroup never waits for one that has no
+// slot; spins are bounded all the same.
+typedef unsigned long long __attribute__((address_space(1))) gu64;
+
+__device__ __forceinline__ float row_exchange_sum(unsigned long long *granules, int C, int tile, float mine, unsigned phase,
+                                                  float *lds) {
+    if (threadIdx.x == 0)
+        __hip_atomic_store((gu64 *)(granules + tile), ((unsigned long long)phase << 32) | __float_as_uint(mine),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (a sweep that never completes — a workgroup of the row that is never scheduled — leaves NaN: the row comes out NaN
+    // instead of the launch hanging or a wrong number passing silently)
+    float v = (int)threadIdx.x < C ? __builtin_nanf("") : 0.0f;
+    if (threadIdx.x < 64) {                       // wave 0 sweeps the row's granules: lane i < C reads granule i
+        for (unsigned spins = 0; spins < (1u << 22); ++spins) {
+            bool ok = true;
+            unsigned long long x = 0;
+            if ((int)threadIdx.x < C) {
+                x = __hip_atomic_load((gu64 *)(granules + threadIdx.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = (unsigned)(x >> 32) == phase;
+            }
+            if (__all(ok)) {
+                v = (int)threadIdx.x < C ? __uint_as_float((unsigned)x) : 0.0f;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+    }
+    // same reduction as reduce_partials(): thread i holds partial i (C <= 64 on this path), the others the identity
+    return block_reduce(v, SumOp(), lds);
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(kBlock, 8) void pgd_l2_fused_kernel(const float *__restrict__ adv, const float *__restrict__ grad,
+                                                                 const float *__restrict__ orig, float *out, int64_t T,
+                                                                 float alpha, float eps, float eps_div, float lo, float hi,
+                                                                 unsigned long long *__restrict__ gran_g,
+                                                                 unsigned long long *__restrict__ gran_d,
+                                                                 float *__restrict__ gnorm, float *__restrict__ dnorm) {
+    __shared__ float lds[12];
+    const int tile = blockIdx.x, C = gridDim.x;
+    const int64_t b = blockIdx.y;
+    float4 a[kVecs], g[kVecs], x[kVecs];
+    load_tile<VEC>(adv + b * T, T, tile, 0.0f, a);
+    load_tile<VEC>(grad + b * T, T, tile, 0.0f, g);
+    load_tile<VEC>(orig + b * T, T, tile, 0.0f, x);
+    float s = 0.0f;
+#pragma unroll
+    for (int j = 0; j < kVecs; ++j) s += (g[j].x * g[j].x + g[j].y * g[j].y) + (g[j].z * g[j].z + g[j].w * g[j].w);
+    s = block_reduce(s, SumOp(), lds);
+    const float gsq = row_exchange_sum(gran_g + b * C, C, tile, s, 1u, lds + 4);
+    const float gn_raw = sqrtf(gsq);
+    const float gn = gn_raw + eps_div;
+    s = 0.0f;
+#pragma unroll
+    for (int j = 0; j < kVecs; ++j) {
+        float4 m;
+        m.x = (a[j].x + alpha * (g[j].x / gn)) - x[j].x;
+        m.y = (a[j].y + alpha * (g[j].y / gn)) - x[j].y;
+        m.z = (a[j].z + alpha * (g[j].z / gn)) - x[j].z;
+        m.w = (a[j].w + alpha * (g[j].w / gn)) - x[j].w;
+        if (!in_row(T, tile, j, 0)) m.x = 0.0f;
+        if (!in_row(T, tile, j, 1)) m.y = 0.0f;
+        if (!in_row(T, tile, j, 2)) m.z = 0.0f;
+        if (!in_row(T, tile, j, 3)) m.w = 0.0f;
+        s += (m.x * m.x + m.y * m.y) + (m.z * m.z + m.w * m.w);
+    }
+    s = block_reduce(s, SumOp(), lds + 8);
+    const float dn = sqrtf(row_exchange_sum(gran_d + b * C, C, tile, s, 2u, lds + 4));
+    const float f = min_nan((1.0f / dn) * eps, 1.0f);
+    // d is recomputed (same expressions, same bits) rather than kept across the exchange: 48 live data registers, 8
+    // workgroups per CU.  gn goes through an empty asm so that the compiler does not merge the two computations again.
+    float gn2 = gn;
+    asm volatile("" : "+v"(gn2));
+#pragma unroll
+    for (int j = 0; j < kVecs; ++j) {
+        float4 d;
+        d.x = (a[j].x + alpha * (g[j].x / gn2)) - x[j].x;
+        d.y = (a[j].y + alpha * (g[j].y / gn2)) - x[j].y;
+        d.z = (a[j].z + alpha * (g[j].z / gn2)) - x[j].z;
+        d.w = (a[j].w + alpha * (g[j].w / gn2)) - x[j].w;
+        a[j].x = clampf(x[j].x + d.x * f, lo, hi);
+        a[j].y = clampf(x[j].y + d.y * f, lo, hi);
+        a[j].z = clampf(x[j].z + d.z * f, lo, hi);
+        a[j].w = clampf(x[j].w + d.w * f, lo, hi);
+    }
+    store_tile<VEC>(out + b * T, T, tile, a);
+    if (tile == 0 && threadIdx.x == 0) {
+        if (gnorm) gnorm[b] = gn_raw;
+        if (dnorm) dnorm[b] = dn;
+    }
+}
+
 // ---- a6: PGD-L2 random start -----------------------------------------------------------------------------------
 
 // explicit draws: out = clamp(x + normal * ((r / nrm) * eps), lo, hi)
@@ -737,15 +837,24 @@ struct RowWs {
     float *p0;
     float *p1;
 };
-inline size_t row_ws_bytes(int64_t B, int64_t T) {
+// four planes of B x C floats: two partial-sum planes for the multi-kernel reductions, or — the single-pass PGD-L2 step —
+// two planes of B x C 8-byte granules laid over all four
+inline size_t row_ws_plane(int64_t B, int64_t T) {
     const size_t one = (size_t)B * (size_t)tiles_per_row(T) * sizeof(float);
-    return 2 * ((one + 15) & ~(size_t)15);
+    return (one + 15) & ~(size_t)15;
 }
+inline size_t row_ws_bytes(int64_t B, int64_t T) { return 4 * row_ws_plane(B, T); }
 inline bool carve_ws(void *ws, size_t ws_bytes, int64_t B, int64_t T, RowWs *out) {
     if (!ws || !aligned16(ws) || ws_bytes < row_ws_bytes(B, T)) return false;
     out->p0 = static_cast<float *>(ws);
-    out->p1 = reinterpret_cast<float *>(static_cast<char *>(ws) + row_ws_bytes(B, T) / 2);
+    out->p1 = reinterpret_cast<float *>(static_cast<char *>(ws) + row_ws_plane(B, T));
     return true;
+}
+
+// ADVSTEP_L2_SINGLE_PASS=0 keeps the three-kernel PGD-L2 step (A/B measurements, read at every call); default on.
+inline bool l2_single_pass() {
+    const char *e = getenv("ADVSTEP_L2_SINGLE_PASS");
+    return !(e && e[0] == '0');
 }
 
 // grid.y is limited to 65535 rows per launch; batches beyond that are launched in slabs.
@@ -978,6 +1087,20 @@ int advstep_pgd_l2_step_f32(const float *adv, const float *grad, const float *or
     hipStream_t st = as_stream(stream);
     const bool vec = rows_vec(T, {adv, grad, orig, out});
     const int C = tiles_per_row(T);
+    if (l2_single_pass() && C <= 64 && B * C <= 8 * 256) {
+        // every workgroup resident at once (8 per CU at <= 64 VGPRs): one launch, 16 B per sample
+        const size_t plane = 2 * row_ws_plane(B, T);
+        if (hipMemsetAsync(ws, 0, 2 * plane, st) != hipSuccess) return ADVSTEP_ELAUNCH;
+        unsigned long long *gg = static_cast<unsigned long long *>(ws);
+        unsigned long long *gd = reinterpret_cast<unsigned long long *>(static_cast<char *>(ws) + plane);
+        if (vec)
+            hipLaunchKernelGGL(pgd_l2_fused_kernel<true>, dim3(C, (unsigned)B), dim3(kBlock), 0, st, adv, grad, orig, out, T, alpha,
+                               eps, eps_div, lo, hi, gg, gd, gnorm, dnorm);
+        else
+            hipLaunchKernelGGL(pgd_l2_fused_kernel<false>, dim3(C, (unsigned)B), dim3(kBlock), 0, st, adv, grad, orig, out, T, alpha,
+                               eps, eps_div, lo, hi, gg, gd, gnorm, dnorm);
+        return status_after_launch();
+    }
     ADV_LAUNCH_ROWS(sumsq_partial_kernel, vec, B, T, st, grad + b0 * T, T, w.p0 + b0 * C);
     ADV_LAUNCH_ROWS(pgd_l2_delta_kernel, vec, B, T, st, adv + b0 * T, grad + b0 * T, orig + b0 * T, T, alpha, eps_div,
                     w.p0 + b0 * C, w.p1 + b0 * C, gnorm ? gnorm + b0 : nullptr);

@@ -286,3 +286,23 @@ def test_error_behaviour(ops, cuda):
     # empty batch is a no-op, not an error
     e = torch.empty(0, 100, device=cuda)
     assert ops.pgd_linf_step(e, e, e, 0.1, 0.1).shape == (0, 100)
+
+
+@pytest.mark.parametrize("B,T", [(128, 64_600), (5, 64_600), (3, 4_099), (2, 100), (1, 1)])
+def test_pgd_l2_single_pass_equals_three_kernel_path(cuda, monkeypatch, B, T):
+    """The single-launch PGD-L2 step (row norms exchanged inside the launch, 16 B per sample) forms the same partial sums
+    and re-reduces them with the same code as the three-kernel path (32 B per sample): bit-identical outputs and norms,
+    also at the full bench shape where all 2 048 workgroups spin on each other, and run to run."""
+    from audio_deepfake_adversarial_attacks_amd import hip_ops
+    g = torch.Generator().manual_seed(B * 31 + T)
+    orig = torch.rand(B, T, generator=g).to(cuda)
+    adv = (orig + (torch.rand(B, T, generator=g).to(cuda) - 0.5) * 0.01).clamp(0, 1)
+    grad = (torch.randn(B, T, generator=g) * 1e-3).to(cuda)
+    grad[0] = 0.0                                                   # a zero-gradient row: gn = eps_div
+    outs = []
+    for mode in ("0", "1", "1"):
+        monkeypatch.setenv("ADVSTEP_L2_SINGLE_PASS", mode)
+        outs.append(hip_ops.pgd_l2_step(adv, grad, orig, 0.2, 0.1, return_norms=True))
+    for out, gn, dn in outs[1:]:
+        assert torch.equal(out, outs[0][0]) and torch.equal(gn, outs[0][1]) and torch.equal(dn, outs[0][2])
+    assert ((outs[0][0] - orig).norm(dim=1) <= 0.1 * (1 + 1e-4)).all()
