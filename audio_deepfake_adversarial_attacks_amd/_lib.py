@@ -125,6 +125,10 @@ def load() -> ctypes.CDLL:
             f"{_LIB_PATH} was not built from the present csrc/*.hip, include/*.h and compiler flags (its build key "
             f"{_build.STAMP.name} is missing or differs): rebuild with `python -m audio_deepfake_adversarial_attacks_amd.build`. "
             "A stale kernel library is never loaded silently.")
+    # One HIP runtime per process: PyTorch-ROCm wheels carry their own libamdhip64.so.  If this library were loaded first it
+    # would bind /opt/rocm's copy, and kernels launched through that runtime on torch's streams and allocations fail
+    # (seen as "HIP kernel launch failed" on the first call).  Importing torch first makes its copy the one both use.
+    import torch  # noqa: F401
     lib = ctypes.CDLL(str(_LIB_PATH))
     for name, (restype, argtypes) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol

@@ -60,10 +60,15 @@ __device__ __forceinline__ float max_nan(float a, float b) {
 // butterfly (unnormalised inverse).  Result in `a` (4 stages = even number of swaps).  One wave-level sync per stage
 // orders this stage's writes before the next stage's reads (and, the buffers alternating, the next-but-one stage's
 // writes after this stage's reads).  `a` must be complete (and synced) on entry.
-// LDS index padding: one extra float2 every 16.  The Stockham writes of the first stages stride by 4 and 16 elements;
-// unpadded, 16 lanes land on 4 of the 16 eight-byte slots of an LDS row (4x the conflict-free time), padded they cover
-// all 16.  Every access to an FFT buffer goes through P().
-__device__ __forceinline__ int P(int i) { return i + (i >> 4); }
+// LDS index swizzle (/opt/skills/guides/MI355X_MICROARCH.md, LDS table): a ds_read_b64 is served in two groups of 32 lanes
+// over 64 four-byte banks — conflict-free when the 32 float2 slot numbers differ in their low 5 bits; a ds_write_b64 in four
+// groups of 16 lanes over 32 banks — conflict-free when the 16 slot numbers differ in their low 4 bits.  Across such a group
+// the transform's accesses vary these index bits: reads, the last stage's writes and the frame load bits {0..4} / {0..3};
+// the Stockham writes of stage 0 (stride 4) bits {2,3,4,5}, of stage 1 (groups of 4 every 16) bits {0,1,4,5}, of stage 2
+// bits {0..3}.  XOR-ing bit 4 into bits 0 and 2 and bit 5 into bits 1 and 3 makes the low 4 (reads: 5) bits a bijection of
+// every one of those sets.  (Round 1 padded one slot every 16, which is conflict-free for none of the write patterns: 37 %
+// of the kernels' LDS cycles were bank conflicts.)  Every access to an FFT buffer goes through P().
+__device__ __forceinline__ int P(int i) { return i ^ (((i >> 4) & 3) * 5); }
 constexpr int kNPad = kN + kN / 16;
 constexpr int kStageTw = 3 * (4 + 16 + 64);   // per-stage twiddle tables of the radix-4 stages 1..3
 

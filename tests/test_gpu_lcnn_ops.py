@@ -580,6 +580,7 @@ def test_gru_layer_matches_torch_gru(L, cuda, T, B, I, layers):
 
 def test_specrnet_uses_gru_kernel_when_frozen_and_matches_miopen(cuda, monkeypatch):
     from audio_deepfake_adversarial_attacks_amd.models.models import get_model
+    monkeypatch.setenv("ADVSTEP_SPECRNET_ELEM", "0")     # this test isolates the GRU kernels (the elementwise fusions have their own)
     torch.manual_seed(5)
     model = get_model("specrnet", {"frontend_algorithm": ["mel_spec"], "input_channels": 2}, str(cuda)).to(cuda)
     model.train()                      # attack mode (attack.py:311-319): train, BatchNorm / Dropout in eval

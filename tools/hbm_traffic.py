@@ -24,7 +24,7 @@ T = 64_600
 # entry point -> (kernel-name patterns of ONE call, algorithmic bytes per sample, batch size of the pass = bench.py's)
 ENTRY_POINTS = {
     "pgd_linf_step": ([r"flat_vec_kernel<3,.*PgdLinfOp"], 16, 128),
-    "pgd_l2_step": ([r"sumsq_partial_kernel", r"pgd_l2_delta_kernel", r"pgd_l2_project_kernel"], 16, 128),
+    "pgd_l2_step": ([r"pgd_l2_fused_kernel"], 16, 128),      # (three-kernel path: sumsq_partial + pgd_l2_delta + pgd_l2_project)
     "cw_adam_step": ([r"cw_adam_vec_kernel"], 32, 64),
 }
 
