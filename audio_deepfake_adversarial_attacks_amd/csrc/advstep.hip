@@ -590,6 +590,10 @@ __device__ __forceinline__ float row_exchange_sum(unsigned long long *granules, 
     return block_reduce(v, SumOp(), lds);
 }
 
+// Register budget: all 2 048 workgroups (8 192 waves) must be resident, i.e. 64 VGPRs per lane, and adv + grad + orig of a tile
+// are 48 of them — the three arrays of the batch are 100 MB, three quarters of the chip's register files.  `orig` therefore sits
+// in LDS (16 KB per workgroup, 8 workgroups per CU = 128 of the 160 KB) and is read back where it is used; adv and grad stay
+// in registers.  (With all three in registers hipcc spilled 15 dwords per lane: 31 MB of scratch writes per launch.)
 template <bool VEC>
 __global__ __launch_bounds__(kBlock, 8) void pgd_l2_fused_kernel(const float *__restrict__ adv, const float *__restrict__ grad,
                                                                  const float *__restrict__ orig, float *out, int64_t T,
@@ -597,13 +601,19 @@ __global__ __launch_bounds__(kBlock, 8) void pgd_l2_fused_kernel(const float *__
                                                                  unsigned long long *__restrict__ gran_g,
                                                                  unsigned long long *__restrict__ gran_d,
                                                                  float *__restrict__ gnorm, float *__restrict__ dnorm) {
+    __shared__ float4 xs[kTileVec];
     __shared__ float lds[12];
     const int tile = blockIdx.x, C = gridDim.x;
     const int64_t b = blockIdx.y;
-    float4 a[kVecs], g[kVecs], x[kVecs];
+    float4 a[kVecs], g[kVecs];
+    {
+        float4 x[kVecs];
+        load_tile<VEC>(orig + b * T, T, tile, 0.0f, x);
+#pragma unroll
+        for (int j = 0; j < kVecs; ++j) xs[j * kBlock + threadIdx.x] = x[j];      // each thread reads back only its own slots
+    }
     load_tile<VEC>(adv + b * T, T, tile, 0.0f, a);
     load_tile<VEC>(grad + b * T, T, tile, 0.0f, g);
-    load_tile<VEC>(orig + b * T, T, tile, 0.0f, x);
     float s = 0.0f;
 #pragma unroll
     for (int j = 0; j < kVecs; ++j) s += (g[j].x * g[j].x + g[j].y * g[j].y) + (g[j].z * g[j].z + g[j].w * g[j].w);
@@ -614,11 +624,12 @@ __global__ __launch_bounds__(kBlock, 8) void pgd_l2_fused_kernel(const float *__
     s = 0.0f;
 #pragma unroll
     for (int j = 0; j < kVecs; ++j) {
+        const float4 x = xs[j * kBlock + threadIdx.x];
         float4 m;
-        m.x = (a[j].x + alpha * (g[j].x / gn)) - x[j].x;
-        m.y = (a[j].y + alpha * (g[j].y / gn)) - x[j].y;
-        m.z = (a[j].z + alpha * (g[j].z / gn)) - x[j].z;
-        m.w = (a[j].w + alpha * (g[j].w / gn)) - x[j].w;
+        m.x = (a[j].x + alpha * (g[j].x / gn)) - x.x;
+        m.y = (a[j].y + alpha * (g[j].y / gn)) - x.y;
+        m.z = (a[j].z + alpha * (g[j].z / gn)) - x.z;
+        m.w = (a[j].w + alpha * (g[j].w / gn)) - x.w;
         if (!in_row(T, tile, j, 0)) m.x = 0.0f;
         if (!in_row(T, tile, j, 1)) m.y = 0.0f;
         if (!in_row(T, tile, j, 2)) m.z = 0.0f;
@@ -628,21 +639,18 @@ __global__ __launch_bounds__(kBlock, 8) void pgd_l2_fused_kernel(const float *__
     s = block_reduce(s, SumOp(), lds + 8);
     const float dn = sqrtf(row_exchange_sum(gran_d + b * C, C, tile, s, 2u, lds + 4));
     const float f = min_nan((1.0f / dn) * eps, 1.0f);
-    // d is recomputed (same expressions, same bits) rather than kept across the exchange: 48 live data registers, 8
-    // workgroups per CU.  gn goes through an empty asm so that the compiler does not merge the two computations again.
-    float gn2 = gn;
-    asm volatile("" : "+v"(gn2));
 #pragma unroll
-    for (int j = 0; j < kVecs; ++j) {
+    for (int j = 0; j < kVecs; ++j) {      // d recomputed (same expressions, same bits) rather than kept across the exchange
+        const float4 x = xs[j * kBlock + threadIdx.x];
         float4 d;
-        d.x = (a[j].x + alpha * (g[j].x / gn2)) - x[j].x;
-        d.y = (a[j].y + alpha * (g[j].y / gn2)) - x[j].y;
-        d.z = (a[j].z + alpha * (g[j].z / gn2)) - x[j].z;
-        d.w = (a[j].w + alpha * (g[j].w / gn2)) - x[j].w;
-        a[j].x = clampf(x[j].x + d.x * f, lo, hi);
-        a[j].y = clampf(x[j].y + d.y * f, lo, hi);
-        a[j].z = clampf(x[j].z + d.z * f, lo, hi);
-        a[j].w = clampf(x[j].w + d.w * f, lo, hi);
+        d.x = (a[j].x + alpha * (g[j].x / gn)) - x.x;
+        d.y = (a[j].y + alpha * (g[j].y / gn)) - x.y;
+        d.z = (a[j].z + alpha * (g[j].z / gn)) - x.z;
+        d.w = (a[j].w + alpha * (g[j].w / gn)) - x.w;
+        a[j].x = clampf(x.x + d.x * f, lo, hi);
+        a[j].y = clampf(x.y + d.y * f, lo, hi);
+        a[j].z = clampf(x.z + d.z * f, lo, hi);
+        a[j].w = clampf(x.w + d.w * f, lo, hi);
     }
     store_tile<VEC>(out + b * T, T, tile, a);
     if (tile == 0 && threadIdx.x == 0) {
@@ -726,6 +734,40 @@ __global__ __launch_bounds__(kBlock) void pgd_l2_init_philox_kernel(const float 
     const Quad rq = philox4x32_10((uint32_t)b, (uint32_t)((uint64_t)b >> 32), (uint32_t)off1, (uint32_t)(off1 >> 32),
                                   (uint32_t)seed, (uint32_t)(seed >> 32));
     const float scale = (u01(rq.v[0]) / nrm) * eps;
+#pragma unroll
+    for (int j = 0; j < kVecs; ++j) {
+        xv[j].x = clampf(xv[j].x + nz[j].x * scale, lo, hi);
+        xv[j].y = clampf(xv[j].y + nz[j].y * scale, lo, hi);
+        xv[j].z = clampf(xv[j].z + nz[j].z * scale, lo, hi);
+        xv[j].w = clampf(xv[j].w + nz[j].w * scale, lo, hi);
+    }
+    store_tile<VEC>(out + b * T, T, tile, xv);
+}
+
+// The same start in ONE launch: the normals are generated once and stay in registers across the row exchange of ||n||^2
+// (granule protocol of pgd_l2_fused_kernel; same partial sums and re-reduction as the two-kernel path: bit-identical).
+template <bool VEC>
+__global__ __launch_bounds__(kBlock, 8) void pgd_l2_init_philox_fused_kernel(const float *__restrict__ x, float *out, int64_t T,
+                                                                             float eps, float lo, float hi, uint64_t seed,
+                                                                             uint64_t offset,
+                                                                             unsigned long long *__restrict__ gran) {
+    __shared__ float lds[8];
+    const int tile = blockIdx.x, C = gridDim.x;
+    const int64_t b = blockIdx.y;
+    float4 nz[kVecs];
+    philox_normal_tile(T, tile, (uint32_t)b, seed, offset, nz);
+    float s = 0.0f;
+#pragma unroll
+    for (int j = 0; j < kVecs; ++j)
+        s += (nz[j].x * nz[j].x + nz[j].y * nz[j].y) + (nz[j].z * nz[j].z + nz[j].w * nz[j].w);
+    s = block_reduce(s, SumOp(), lds);
+    const float nrm = sqrtf(row_exchange_sum(gran + b * C, C, tile, s, 1u, lds + 4));
+    const uint64_t off1 = offset + 1;
+    const Quad rq = philox4x32_10((uint32_t)b, (uint32_t)((uint64_t)b >> 32), (uint32_t)off1, (uint32_t)(off1 >> 32),
+                                  (uint32_t)seed, (uint32_t)(seed >> 32));
+    const float scale = (u01(rq.v[0]) / nrm) * eps;
+    float4 xv[kVecs];
+    load_tile<VEC>(x + b * T, T, tile, 0.0f, xv);
 #pragma unroll
     for (int j = 0; j < kVecs; ++j) {
         xv[j].x = clampf(xv[j].x + nz[j].x * scale, lo, hi);
@@ -1071,6 +1113,18 @@ int advstep_pgd_l2_init_philox_f32(const float *x, float *out, int64_t B, int64_
     hipStream_t st = as_stream(stream);
     const bool vec = rows_vec(T, {x, out});
     const int C = tiles_per_row(T);
+    if (l2_single_pass() && C <= 64 && B * C <= 8 * 256) {
+        const size_t plane = 2 * row_ws_plane(B, T);
+        if (hipMemsetAsync(ws, 0, plane, st) != hipSuccess) return ADVSTEP_ELAUNCH;
+        unsigned long long *gran = static_cast<unsigned long long *>(ws);
+        if (vec)
+            hipLaunchKernelGGL(pgd_l2_init_philox_fused_kernel<true>, dim3(C, (unsigned)B), dim3(kBlock), 0, st, x, out, T, eps, lo,
+                               hi, seed, offset, gran);
+        else
+            hipLaunchKernelGGL(pgd_l2_init_philox_fused_kernel<false>, dim3(C, (unsigned)B), dim3(kBlock), 0, st, x, out, T, eps, lo,
+                               hi, seed, offset, gran);
+        return status_after_launch();
+    }
     hipLaunchKernelGGL(philox_normal_sumsq_kernel, dim3(C, (unsigned)B), dim3(kBlock), 0, st, T, seed, offset, w.p0);
     ADV_LAUNCH_ROWS(pgd_l2_init_philox_kernel, vec, B, T, st, x, out, T, eps, lo, hi, seed, offset, w.p0);
     return status_after_launch();

@@ -306,3 +306,17 @@ def test_pgd_l2_single_pass_equals_three_kernel_path(cuda, monkeypatch, B, T):
     for out, gn, dn in outs[1:]:
         assert torch.equal(out, outs[0][0]) and torch.equal(gn, outs[0][1]) and torch.equal(dn, outs[0][2])
     assert ((outs[0][0] - orig).norm(dim=1) <= 0.1 * (1 + 1e-4)).all()
+
+
+@pytest.mark.parametrize("B,T", [(128, 64_600), (3, 4_099), (2, 100)])
+def test_pgd_l2_philox_start_single_pass_equals_two_kernel_path(cuda, monkeypatch, B, T):
+    """The single-launch Philox random start keeps the normals in registers across the in-launch exchange of their row norm;
+    same draws, same partial sums: bit-identical to the two-kernel path (which generates the normals twice)."""
+    from audio_deepfake_adversarial_attacks_amd import hip_ops
+    x = torch.rand(B, T, generator=torch.Generator().manual_seed(B + T)).to(cuda)
+    outs = []
+    for mode in ("0", "1", "1"):
+        monkeypatch.setenv("ADVSTEP_L2_SINGLE_PASS", mode)
+        outs.append(hip_ops.pgd_l2_init(x, 0.1, seed=1234, offset=5))
+    assert torch.equal(outs[1], outs[0]) and torch.equal(outs[2], outs[0])
+    assert ((outs[0] - x).norm(dim=1) <= 0.1 * (1 + 1e-5)).all() and not torch.equal(outs[0], x)
