@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <type_traits>
 
@@ -137,16 +138,20 @@ __global__ void wino_prepare_kernel(const float *__restrict__ weight, const floa
 //        gy (N, C, H/2, W/2) and the selection bytes (advstep_mfm_pool2_forward_f32's encoding), K = 2C: channel k of
 //        half k / C at conv position (h, w) carries gy[k % C][h/2][w/2] if that position of that half won, else 0.  The
 //        4x4 patch of a lane is expanded from the 3x3 pooled cells around its tile; the dense gradient never exists.
-template <int EPI, bool STREAM, int SRC>
+// NT: accumulator tiles a wave computes — 2, or 1 for the input-gradient convolution's LAST slice when only its first 16 rows
+//     exist (Cin % 32 == 16, LCNN's 128 -> 48 layer): that slice is launched on its own with half the matrix instructions
+//     instead of multiplying 16 zero rows.  slice0: first slice of this launch.
+template <int EPI, bool STREAM, int SRC, int NT = 2>
 __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restrict__ x, const uint8_t *__restrict__ xsel,
                                                            const float *__restrict__ U,
                                                            const float *__restrict__ bias,
                                                            const float *__restrict__ bn_mean,
                                                            const float *__restrict__ bn_invstd, float *__restrict__ y,
                                                            uint8_t *__restrict__ idx, int N, int K, int H, int W, int Cout,
-                                                           int slices, int ranges) {
+                                                           int slices, int ranges, int slice0) {
+    static_assert(NT == 2 || EPI == 0, "one accumulator tile only for the plain-store epilogue");
     extern __shared__ __attribute__((aligned(16))) float u_s[];
-    const int slice = blockIdx.x % slices, range = blockIdx.x / slices;
+    const int slice = slice0 + blockIdx.x % slices, range = blockIdx.x / slices;
     const int chunks = K / kChunkCin, steps = K / 4;
     const float *Usl = U + (int64_t)slice * chunks * kChunkFloats;
     auto copy_chunk = [&](int chunk, int buf) {
@@ -203,7 +208,7 @@ __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restri
                     cell[i][j] = in ? ((uint32_t)(n * Cs + g)) * cplane + (uint32_t)(ci * Ws + cj) : 0x20000000u;
                 }
         }
-        f32x4 acc[16][2];
+        f32x4 acc[16][NT];
 
         // a patch in flight: SRC 0 the 16 taps; SRC 1 the 9 pooled gradients + their 9 selection bytes
         struct Patch {
@@ -288,7 +293,8 @@ __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restri
                 for (int e = 0; e < 2; ++e) {
                     const int xi = 2 * grp + e;
                     acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[grp][e].x, v[xi >> 2][xi & 3], decltype(first)::value ? zero : acc[xi][0], 0, 0, 0);
-                    acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[grp][e].y, v[xi >> 2][xi & 3], decltype(first)::value ? zero : acc[xi][1], 0, 0, 0);
+                    if (NT == 2)
+                        acc[xi][NT - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[grp][e].y, v[xi >> 2][xi & 3], decltype(first)::value ? zero : acc[xi][NT - 1], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -327,7 +333,7 @@ __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restri
         for (int r = 0; r < 4; ++r) {
             float yy[2][2][2];
 #pragma unroll
-            for (int m = 0; m < 2; ++m) {
+            for (int m = 0; m < NT; ++m) {
                 float s0[4], s1[4];
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
@@ -385,7 +391,7 @@ __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restri
                 }
             } else {
 #pragma unroll
-                for (int m = 0; m < 2; ++m) {
+                for (int m = 0; m < NT; ++m) {
                     const int ch = slice * 32 + m * 16 + 4 * g + r;
                     if (!(valid && ch < Cout)) continue;
                     float *o = y + (((size_t)n * Cout + ch) * H + 2 * th) * W + 2 * tw;
@@ -427,6 +433,12 @@ __global__ __launch_bounds__(256) void wino_mfm_backward_kernel(const float *__r
     }
 }
 
+// ADVSTEP_WINO_HALF_SLICE=0 (read at every call) keeps the single launch that multiplies the zero rows (A/B measurements).
+inline bool half_slice_enabled() {
+    const char *e = getenv("ADVSTEP_WINO_HALF_SLICE");
+    return !(e && e[0] == '0');
+}
+
 template <int EPI, int SRC>
 int launch_wino(const float *x, const uint8_t *xsel, const float *U, const float *bias, const float *bn_mean,
                 const float *bn_invstd, float *y, uint8_t *idx, int64_t N, int64_t K, int64_t H, int64_t W, int64_t Cout,
@@ -434,19 +446,30 @@ int launch_wino(const float *x, const uint8_t *xsel, const float *U, const float
     const int cus = 256;
     const int chunks = (int)(K / kChunkCin);
     const bool stream = chunks > kMaxResident;
-    int ranges = cus / slices;
     const int64_t groups = ceil_div(N * ((H + 1) / 2) * ((W + 1) / 2), 16);
-    if ((int64_t)ranges * kWaves > groups) ranges = (int)ceil_div(groups, kWaves);
-    if (ranges < 1) ranges = 1;
     const size_t lds = (size_t)(stream ? 2 : chunks) * kChunkFloats * sizeof(float);
-    const dim3 grid((unsigned)(slices * ranges)), block(kThreads);
-    auto go = [&](auto kernel) {
+    auto go = [&](auto kernel, int n_slices, int slice0) {
+        int ranges = cus / n_slices;
+        if ((int64_t)ranges * kWaves > groups) ranges = (int)ceil_div(groups, kWaves);
+        if (ranges < 1) ranges = 1;
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kernel, grid, block, lds, st, x, xsel, U, bias, bn_mean, bn_invstd, y, idx, (int)N, (int)K, (int)H,
-                           (int)W, (int)Cout, slices, ranges);
+        hipLaunchKernelGGL(kernel, dim3((unsigned)(n_slices * ranges)), dim3(kThreads), lds, st, x, xsel, U, bias, bn_mean, bn_invstd,
+                           y, idx, (int)N, (int)K, (int)H, (int)W, (int)Cout, n_slices, ranges, slice0);
     };
-    if (stream) go(wino3x3_kernel<EPI, true, SRC>);
-    else go(wino3x3_kernel<EPI, false, SRC>);
+    // plain-store epilogue with a half-empty last slice (Cout % 32 in 1..16): that slice on its own, one accumulator tile
+    int full = slices;
+    if constexpr (EPI == 0) {
+        const int live_last = (int)(Cout - (int64_t)(slices - 1) * 32);
+        if (live_last <= 16 && half_slice_enabled()) {
+            full = slices - 1;
+            if (stream) go(wino3x3_kernel<EPI, true, SRC, 1>, 1, slices - 1);
+            else go(wino3x3_kernel<EPI, false, SRC, 1>, 1, slices - 1);
+        }
+    }
+    if (full > 0) {
+        if (stream) go(wino3x3_kernel<EPI, true, SRC, 2>, full, 0);
+        else go(wino3x3_kernel<EPI, false, SRC, 2>, full, 0);
+    }
     return status_after_launch();
 }
 
