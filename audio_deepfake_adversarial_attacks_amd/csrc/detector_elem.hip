@@ -25,7 +25,7 @@ inline hipStream_t as_stream(advstep_stream_t s) { return reinterpret_cast<hipSt
 inline int status_after_launch() { return hipGetLastError() == hipSuccess ? ADVSTEP_OK : ADVSTEP_ELAUNCH; }
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-// ---- per-channel affine + activation: grid (ceil(P / (4 * kBlock * 4)), N * C) ------------------------------------------
+// ---- per-channel affine + activation: grid (N * C planes, tiles of 4 x 256 float4 per plane) -------------------------------
 constexpr int kVecPerThread = 4;
 
 template <int MODE>
@@ -35,12 +35,12 @@ __device__ __forceinline__ float act_fwd(float x, float s, float t, float pre, f
         return v > 0.0f ? v : v * slope;
     }
     const float r = x + pre;
-    return (r > 0.0f ? r : 0.0f) * s + t;          // relu keeps NaN out like at::relu: max(0, NaN) -> NaN handled below
+    return (r > 0.0f ? r : (r != r ? r : 0.0f)) * s + t;      // at::relu = clamp_min(0): NaN stays NaN
 }
 template <int MODE>
 __device__ __forceinline__ float act_bwd(float gy, float x, float s, float t, float pre, float slope) {
-    if (MODE == 0) return gy * ((x * s + t) > 0.0f ? 1.0f : slope) * s;
-    return (x + pre) > 0.0f ? gy * s : 0.0f;
+    if (MODE == 0) return gy * ((x * s + t) > 0.0f ? 1.0f : slope) * s;   // leaky_relu_backward: x > 0 ? g : g * slope
+    return (x + pre) <= 0.0f ? 0.0f : gy * s;                               // threshold_backward: x <= 0 ? 0 : g (NaN: g)
 }
 
 // VEC: every tensor base is 16-byte aligned.  A plane (n, c) starts at element nc * P, which is 16-byte aligned only when

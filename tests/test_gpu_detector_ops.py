@@ -21,7 +21,10 @@ def rnd(shape, seed, cuda, scale=1.0):
 @pytest.mark.parametrize("shape", [(3, 20, 16, 24), (2, 5, 7, 9), (1, 64, 1, 3), (4, 128, 1001), (2, 3, 6435)])
 def test_affine_lrelu_and_relu_affine_match_aten(D, cuda, shape):
     C = shape[1]
-    x = rnd(shape, 1, cuda).requires_grad_(True)
+    x = rnd(shape, 1, cuda)
+    x.view(-1)[::97] = float("nan")                                  # NaN inputs follow ATen's rules too
+    x.view(-1)[5::89] = 0.0
+    x.requires_grad_(True)
     scale, shift, pre = rnd((C,), 2, cuda).abs() + 0.5, rnd((C,), 3, cuda), rnd((C,), 4, cuda)
     gy = rnd(shape, 5, cuda)
     view = (1, C) + (1,) * (len(shape) - 2)
@@ -30,16 +33,17 @@ def test_affine_lrelu_and_relu_affine_match_aten(D, cuda, shape):
     (g_ref,) = torch.autograd.grad(ref, x, gy)
     got = D.affine_lrelu(x, scale, shift, 0.3)
     (g_got,) = torch.autograd.grad(got, x, gy)
-    assert torch.equal(got, ref)
-    assert torch.allclose(g_got, g_ref, rtol=1e-6, atol=0)          # (gy * d) * s vs autograd's grouping: one rounding apart
+    assert torch.equal(torch.nan_to_num(got, nan=7.0), torch.nan_to_num(ref, nan=7.0))
+    assert torch.allclose(g_got, g_ref, rtol=1e-6, atol=0, equal_nan=True)   # (gy * d) * s vs autograd's grouping: one rounding apart
     # mode 1: relu(x + pre) * s + t
     ref = torch.relu(x + pre.view(view)) * scale.view(view) + shift.view(view)
     (g_ref,) = torch.autograd.grad(ref, x, gy)
     got = D.relu_affine(x, scale, shift, pre)
     (g_got,) = torch.autograd.grad(got, x, gy)
-    assert torch.equal(got, ref) and torch.equal(g_got, g_ref)
+    assert torch.equal(torch.nan_to_num(got, nan=7.0), torch.nan_to_num(ref, nan=7.0))
+    assert torch.equal(torch.nan_to_num(g_got, nan=7.0), torch.nan_to_num(g_ref, nan=7.0))
     got = D.relu_affine(x, scale, shift, None)
-    assert torch.equal(got, torch.relu(x) * scale.view(view) + shift.view(view))
+    assert torch.equal(torch.nan_to_num(got, nan=7.0), torch.nan_to_num(torch.relu(x) * scale.view(view) + shift.view(view), nan=7.0))
 
 
 def test_bn_eval_affine_equals_batch_norm(D, cuda):
