@@ -61,6 +61,11 @@ SIGNATURES = {
     "advstep_conv3x3_mfm_forward_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p]),
     "advstep_conv3x3_mfm_backward_f32": (ctypes.c_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _p]),
     "advstep_conv3x3_backward_data_f32": (ctypes.c_int, [_p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p]),
+    "advstep_resconv_supported": (ctypes.c_int, [_i64, _i64, _i64]),
+    "advstep_resconv_prepared_floats": (_sz, [_i64, _i64, _i64]),
+    "advstep_resconv_prepare_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _i64, _i64, ctypes.c_int, _p]),
+    "advstep_resconv_forward_f32": (ctypes.c_int, [_p, _p, _p, _p, ctypes.c_float, _p, _i64, _i64, _i64, _i64, _i64, _i64, _p]),
+    "advstep_resconv_pool2_forward_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _p]),
     # include/advstep_frontend.h
     "advstep_lfcc_block_count": (_sz, [_i64, _i64, _i64]),
     "advstep_lfcc_bands_f32": (ctypes.c_int, [_p, _p, _p, _i64, _p, _p, _i64, _i64, _i64, _i64, _p]),

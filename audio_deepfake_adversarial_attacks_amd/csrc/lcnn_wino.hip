@@ -31,6 +31,7 @@
 
 #include <type_traits>
 
+#include "advstep_detector.h"
 #include "advstep_lcnn.h"
 
 namespace {
@@ -127,6 +128,63 @@ __global__ void wino_prepare_kernel(const float *__restrict__ weight, const floa
     for (int xi = 0; xi < 16; ++xi) dst[xi * (kChunkCin * 32)] = u[xi >> 2][xi & 3];
 }
 
+// Plain convolutions (advstep_resconv_*): R output rows, reduction over K1 channels with 3x3 taps followed by K2 channels
+// with a centre tap only (a 1x1 convolution of a second tensor).  transpose = 0: w3 (R, K1, 3, 3), w1 (R, K2).
+// transpose = 1 (input gradient of a convolution with weight w3 (K1, R, 3, 3) [and w1 (K2, R)]): taps rotated, channels swapped.
+// rscale (R) multiplies a row, kscale (K1) the 3x3 part's reduction channel.  Row (slice, j, m) = slice * 32 + m * 16 + j.
+__global__ void wino_prepare_plain_kernel(const float *__restrict__ w3, const float *__restrict__ w1,
+                                          const float *__restrict__ rscale, const float *__restrict__ kscale,
+                                          float *__restrict__ U, int R, int K1, int K2, int transpose, int slices, int chunks) {
+    const int Kp = chunks * kChunkCin;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= slices * 32 * Kp) return;
+    const int k = i % Kp, rowi = i / Kp, slice = rowi / 32, jm = rowi % 32, j = jm % 16, m = jm / 16;
+    const int row = slice * 32 + m * 16 + j;
+    float g[3][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
+    if (row < R && k < K1) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b)
+                g[a][b] = transpose ? w3[((int64_t)k * R + row) * 9 + (2 - a) * 3 + (2 - b)] : w3[((int64_t)row * K1 + k) * 9 + a * 3 + b];
+        if (kscale) {
+            const float f = kscale[k];
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) g[a][b] *= f;
+        }
+    } else if (row < R && k < K1 + K2) {
+        g[1][1] = transpose ? w1[(int64_t)(k - K1) * R + row] : w1[(int64_t)row * K2 + (k - K1)];
+    }
+    if (rscale && row < R) {
+        const float f = rscale[row];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) g[a][b] *= f;
+    }
+    float t[4][3], u[4][4];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        t[0][b] = g[0][b];
+        t[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]);
+        t[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
+        t[3][b] = g[2][b];
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        u[a][0] = t[a][0];
+        u[a][1] = 0.5f * (t[a][0] + t[a][1] + t[a][2]);
+        u[a][2] = 0.5f * (t[a][0] - t[a][1] + t[a][2]);
+        u[a][3] = t[a][2];
+    }
+    const int chunk = k / kChunkCin, kc = k % kChunkCin;
+    float *dst = U + ((int64_t)(slice * chunks + chunk)) * kChunkFloats + (kc * 16 + j) * 2 + m;
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi) dst[xi * (kChunkCin * 32)] = u[xi >> 2][xi & 3];
+}
+
 // ---- the convolution ---------------------------------------------------------------------------------------------------
 // EPI 0: plain store of min(32, Cout - slice * 32) channels per slice (the input-gradient convolution).
 // EPI 1: bias + max-feature-map + 2x2 pool [+ BatchNorm]; Cout = number of max-feature-map channels C.
@@ -138,21 +196,34 @@ __global__ void wino_prepare_kernel(const float *__restrict__ weight, const floa
 //        gy (N, C, H/2, W/2) and the selection bytes (advstep_mfm_pool2_forward_f32's encoding), K = 2C: channel k of
 //        half k / C at conv position (h, w) carries gy[k % C][h/2][w/2] if that position of that half won, else 0.  The
 //        4x4 patch of a lane is expanded from the 3x3 pooled cells around its tile; the dense gradient never exists.
-// NT: accumulator tiles a wave computes — 2, or 1 for the input-gradient convolution's LAST slice when only its first 16 rows
-//     exist (Cin % 32 == 16, LCNN's 128 -> 48 layer): that slice is launched on its own with half the matrix instructions
-//     instead of multiplying 16 zero rows.  slice0: first slice of this launch.
-template <int EPI, bool STREAM, int SRC, int NT = 2>
+// EPI 3: + shift[ch], LeakyReLU(slope), plain store            (the residual blocks of SpecRNet, advstep_detector.h)
+// EPI 4: + bias[ch], MaxPool2d(2) with ATen's selection byte (detector_elem.hip::pool4): the conv output never exists.
+// NT: accumulator tiles a wave computes — 2, or 1 for a convolution's LAST slice when only its first 16 rows exist
+//     (Cout % 32 in 1..16, LCNN's 128 -> 48 input gradient): that slice is launched on its own with half the matrix
+//     instructions instead of multiplying 16 zero rows.  slice0: first slice of this launch.
+// GEN (SRC 0 only): the reduction runs over the channels of TWO dense tensors, x (K1 channels, K1 % 4 == 0 when x2 is
+//     given) then x2 (Kreal - K1 channels) — a 1x1 convolution of x2 added to the 3x3 convolution of x is the same
+//     reduction with centre-tap-only weights — and Kreal need not fill the last k-steps: K is Kreal rounded up to 8,
+//     channels >= Kreal get an out-of-range offset (read 0; their U rows are 0 as well).
+struct GenArgs {
+    const float *x2;
+    int K1, Kreal;
+    float slope;
+};
+
+template <int EPI, bool STREAM, int SRC, int NT = 2, bool GEN = false>
 __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restrict__ x, const uint8_t *__restrict__ xsel,
                                                            const float *__restrict__ U,
                                                            const float *__restrict__ bias,
                                                            const float *__restrict__ bn_mean,
                                                            const float *__restrict__ bn_invstd, float *__restrict__ y,
                                                            uint8_t *__restrict__ idx, int N, int K, int H, int W, int Cout,
-                                                           int slices, int ranges, int slice0) {
-    static_assert(NT == 2 || EPI == 0, "one accumulator tile only for the plain-store epilogue");
+                                                           int slices, int ranges, int slice0, GenArgs ga) {
+    static_assert(NT == 2 || EPI == 0 || EPI == 3, "one accumulator tile only for the plain-store epilogues");
+    static_assert(!GEN || SRC == 0, "two-tensor reduction only over dense sources");
     extern __shared__ __attribute__((aligned(16))) float u_s[];
     const int slice = slice0 + blockIdx.x % slices, range = blockIdx.x / slices;
-    const int chunks = K / kChunkCin, steps = K / 4;
+    const int chunks = (K + kChunkCin - 1) / kChunkCin, steps = K / 4;
     const float *Usl = U + (int64_t)slice * chunks * kChunkFloats;
     auto copy_chunk = [&](int chunk, int buf) {
         const float4 *src = reinterpret_cast<const float4 *>(Usl + (int64_t)chunk * kChunkFloats);
@@ -172,9 +243,12 @@ __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restri
     // raw buffer over x: an out-of-range offset reads as 0 — the convolution's zero padding, for free
     const int Hs = H >> 1, Ws = W >> 1, Cs = K >> 1;      // SRC 1: pooled grid, max-feature-map channels
     const uint32_t cplane = (uint32_t)(Hs * Ws);
-    const size_t src_elems = SRC == 0 ? (size_t)N * K * plane : (size_t)N * Cs * cplane;
+    const int KA = GEN ? ga.K1 : K, KB = GEN ? ga.Kreal - ga.K1 : 0;      // channels of x and of x2
+    const size_t src_elems = SRC == 0 ? (size_t)N * KA * plane : (size_t)N * Cs * cplane;
     const __amdgpu_buffer_rsrc_t xr =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x), 0, (int)(src_elems * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t xr2 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(GEN && KB > 0 ? ga.x2 : x), 0, GEN && KB > 0 ? (int)((size_t)N * KB * plane * 4) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t sr =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(SRC == 1 ? xsel : reinterpret_cast<const uint8_t *>(x)), 0,
                                           (int)src_elems, 0x00020000);
@@ -187,7 +261,8 @@ __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restri
         const int n = tt / (TH * TW), rem = tt - n * (TH * TW), th = rem / TW, tw = rem - th * TW;
         // patch addressing: one lane base + compile-time (p, q) strides; the 16 validity flags live in scalar registers
         // as lane masks, and an invalid tap gets an out-of-range offset (reads 0) when the load is issued
-        const uint32_t lane_base = (((uint32_t)(n * K + g)) * plane + (uint32_t)((2 * th - 1) * W + (2 * tw - 1))) * 4u;
+        const uint32_t lane_base = (((uint32_t)(n * KA + g)) * plane + (uint32_t)((2 * th - 1) * W + (2 * tw - 1))) * 4u;
+        const uint32_t lane_base2 = (((uint32_t)(n * KB + g)) * plane + (uint32_t)((2 * th - 1) * W + (2 * tw - 1))) * 4u;
         bool ok[4][4];
         uint32_t cell[3][3];     // SRC 1: element offsets of the 3x3 pooled cells around the tile (0x20000000 = outside)
         if (SRC == 0) {
@@ -216,7 +291,19 @@ __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restri
             uint32_t code[SRC == 0 ? 1 : 9];
         };
         auto load_patch = [&](Patch &dst, int s) {
-            if (SRC == 0) {
+            if (SRC == 0 && GEN) {
+                const bool first = 4 * s < ga.K1;                          // wave-uniform: this k-step reads x (else x2)
+                const uint32_t soff = (uint32_t)(first ? 4 * s : 4 * s - ga.K1) * plane * 4u;
+                const uint32_t base = 4 * s + g < ga.Kreal ? (first ? lane_base : lane_base2) : 0x80000000u;
+                const __amdgpu_buffer_rsrc_t r = first ? xr : xr2;
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const uint32_t vo = ok[p][q] ? base + (uint32_t)((p * W + q) * 4) : 0x80000000u;
+                        dst.v[p * 4 + q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, vo, soff, 0));
+                    }
+            } else if (SRC == 0) {
                 const uint32_t soff = (uint32_t)(4 * s) * plane * 4u;
 #pragma unroll
                 for (int p = 0; p < 4; ++p)
@@ -389,11 +476,38 @@ __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restri
                     }
                     idx[((size_t)n * Cout + ch) * TH * TW + (size_t)th * TW + tw] = (uint8_t)bits;
                 }
+            } else if (EPI == 4) {
+#pragma unroll
+                for (int m = 0; m < NT; ++m) {
+                    const int ch = slice * 32 + m * 16 + 4 * g + r;
+                    const bool live = ch < Cout;
+                    const float b = bias ? bias[live ? ch : 0] : 0.0f;
+                    float best = -INFINITY;
+                    int code = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {      // ATen's scan: row-major, take when (v > best) || isnan(v)
+                        const float v = yy[m][e >> 1][e & 1] + b;
+                        if (v > best || v != v) { best = v; code = e; }
+                    }
+                    if (valid && live && th < Ho && tw < Wo) {
+                        const size_t o = ((size_t)n * Cout + ch) * Ho * Wo + (size_t)th * Wo + tw;
+                        y[o] = best;
+                        idx[o] = (uint8_t)code;
+                    }
+                }
             } else {
 #pragma unroll
                 for (int m = 0; m < NT; ++m) {
                     const int ch = slice * 32 + m * 16 + 4 * g + r;
                     if (!(valid && ch < Cout)) continue;
+                    if (EPI == 3) {
+                        const float b = bias ? bias[ch] : 0.0f;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float v = yy[m][e >> 1][e & 1] + b;
+                            yy[m][e >> 1][e & 1] = v > 0.0f ? v : v * ga.slope;
+                        }
+                    }
                     float *o = y + (((size_t)n * Cout + ch) * H + 2 * th) * W + 2 * tw;
                     const bool h1 = 2 * th + 1 < H;
                     if ((W & 1) == 0) {   // rows are 8-byte aligned: one 64-bit store per tile row
@@ -439,12 +553,12 @@ inline bool half_slice_enabled() {
     return !(e && e[0] == '0');
 }
 
-template <int EPI, int SRC>
+template <int EPI, int SRC, bool GEN = false>
 int launch_wino(const float *x, const uint8_t *xsel, const float *U, const float *bias, const float *bn_mean,
                 const float *bn_invstd, float *y, uint8_t *idx, int64_t N, int64_t K, int64_t H, int64_t W, int64_t Cout,
-                int slices, hipStream_t st) {
+                int slices, hipStream_t st, GenArgs ga = GenArgs{nullptr, 0, 0, 1.0f}) {
     const int cus = 256;
-    const int chunks = (int)(K / kChunkCin);
+    const int chunks = (int)ceil_div(K, kChunkCin);
     const bool stream = chunks > kMaxResident;
     const int64_t groups = ceil_div(N * ((H + 1) / 2) * ((W + 1) / 2), 16);
     const size_t lds = (size_t)(stream ? 2 : chunks) * kChunkFloats * sizeof(float);
@@ -454,21 +568,21 @@ int launch_wino(const float *x, const uint8_t *xsel, const float *U, const float
         if (ranges < 1) ranges = 1;
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kernel, dim3((unsigned)(n_slices * ranges)), dim3(kThreads), lds, st, x, xsel, U, bias, bn_mean, bn_invstd,
-                           y, idx, (int)N, (int)K, (int)H, (int)W, (int)Cout, n_slices, ranges, slice0);
+                           y, idx, (int)N, (int)K, (int)H, (int)W, (int)Cout, n_slices, ranges, slice0, ga);
     };
-    // plain-store epilogue with a half-empty last slice (Cout % 32 in 1..16): that slice on its own, one accumulator tile
+    // plain-store epilogues with a half-empty last slice (Cout % 32 in 1..16): that slice on its own, one accumulator tile
     int full = slices;
-    if constexpr (EPI == 0) {
+    if constexpr (EPI == 0 || EPI == 3) {
         const int live_last = (int)(Cout - (int64_t)(slices - 1) * 32);
         if (live_last <= 16 && half_slice_enabled()) {
             full = slices - 1;
-            if (stream) go(wino3x3_kernel<EPI, true, SRC, 1>, 1, slices - 1);
-            else go(wino3x3_kernel<EPI, false, SRC, 1>, 1, slices - 1);
+            if (stream) go(wino3x3_kernel<EPI, true, SRC, 1, GEN>, 1, slices - 1);
+            else go(wino3x3_kernel<EPI, false, SRC, 1, GEN>, 1, slices - 1);
         }
     }
     if (full > 0) {
-        if (stream) go(wino3x3_kernel<EPI, true, SRC, 2>, full, 0);
-        else go(wino3x3_kernel<EPI, false, SRC, 2>, full, 0);
+        if (stream) go(wino3x3_kernel<EPI, true, SRC, 2, GEN>, full, 0);
+        else go(wino3x3_kernel<EPI, false, SRC, 2, GEN>, full, 0);
     }
     return status_after_launch();
 }
@@ -566,6 +680,58 @@ int advstep_conv3x3_mfm_pool2_backward_f32(const float *gy, const uint8_t *idx, 
     WINO_REQUIRE((uint64_t)N * C * (H / 2) * (W / 2) < (1ull << 29) && (uint64_t)N * ((H + 1) / 2) * ((W + 1) / 2) < (1ull << 31));
     return launch_wino<0, 1>(gy, idx, U, nullptr, nullptr, nullptr, gx, nullptr, N, 2 * C, H, W, Cin, (int)ceil_div(Cin, 32),
                              as_stream(stream));
+}
+
+// ---- plain 3x3 convolutions of the detectors' residual blocks (include/advstep_detector.h) -----------------------------
+
+int advstep_resconv_supported(int64_t K1, int64_t K2, int64_t rows) {
+    return K1 >= 1 && K2 >= 0 && (K2 == 0 || K1 % 4 == 0) && K1 + K2 <= 256 && rows >= 1 && rows <= 256;
+}
+
+size_t advstep_resconv_prepared_floats(int64_t K1, int64_t K2, int64_t rows) {
+    if (!advstep_resconv_supported(K1, K2, rows)) return 0;
+    return (size_t)(ceil_div(rows, 32) * ceil_div(K1 + K2, kChunkCin) * kChunkFloats);
+}
+
+int advstep_resconv_prepare_f32(const float *w3, const float *w1, const float *rscale, const float *kscale, float *U,
+                                int64_t rows, int64_t K1, int64_t K2, int transpose, advstep_stream_t stream) {
+    WINO_REQUIRE(w3 && U && advstep_resconv_supported(K1, K2, rows) && (K2 == 0 || w1) && (transpose == 0 || transpose == 1));
+    const int slices = (int)ceil_div(rows, 32), chunks = (int)ceil_div(K1 + K2, kChunkCin);
+    const int total = slices * 32 * chunks * kChunkCin;
+    hipLaunchKernelGGL(wino_prepare_plain_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, as_stream(stream), w3, w1,
+                       rscale, kscale, U, (int)rows, (int)K1, (int)K2, transpose, slices, chunks);
+    return status_after_launch();
+}
+
+static int resconv_check(const float *x1, const float *x2, const float *U, const void *y, int64_t N, int64_t K1, int64_t K2,
+                         int64_t rows, int64_t H, int64_t W) {
+    WINO_REQUIRE(x1 && U && y && (K2 == 0 || x2));
+    WINO_REQUIRE((uint64_t)N * (K1 > K2 ? K1 : K2) * H * W * 4 < (1ull << 31) && (uint64_t)N * rows * H * W * 4 < (1ull << 33) &&
+                 (uint64_t)N * ((H + 1) / 2) * ((W + 1) / 2) < (1ull << 31));
+    return ADVSTEP_OK;
+}
+
+int advstep_resconv_forward_f32(const float *x1, const float *x2, const float *U, const float *shift, float slope, float *y,
+                                int64_t N, int64_t K1, int64_t K2, int64_t rows, int64_t H, int64_t W,
+                                advstep_stream_t stream) {
+    WINO_REQUIRE(N >= 0 && H >= 0 && W >= 0 && advstep_resconv_supported(K1, K2, rows));
+    if (N == 0 || H == 0 || W == 0) return ADVSTEP_OK;
+    if (const int st = resconv_check(x1, x2, U, y, N, K1, K2, rows, H, W)) return st;
+    const int64_t K = ceil_div(K1 + K2, 8) * 8;
+    return launch_wino<3, 0, true>(x1, nullptr, U, shift, nullptr, nullptr, y, nullptr, N, K, H, W, rows, (int)ceil_div(rows, 32),
+                                   as_stream(stream), GenArgs{x2, (int)K1, (int)(K1 + K2), slope});
+}
+
+int advstep_resconv_pool2_forward_f32(const float *x1, const float *x2, const float *U, const float *bias, float *y,
+                                      uint8_t *sel, int64_t N, int64_t K1, int64_t K2, int64_t rows, int64_t H, int64_t W,
+                                      advstep_stream_t stream) {
+    WINO_REQUIRE(N >= 0 && H >= 0 && W >= 0 && advstep_resconv_supported(K1, K2, rows));
+    if (N == 0 || H / 2 == 0 || W / 2 == 0) return ADVSTEP_OK;
+    WINO_REQUIRE(sel);
+    if (const int st = resconv_check(x1, x2, U, y, N, K1, K2, rows, H, W)) return st;
+    const int64_t K = ceil_div(K1 + K2, 8) * 8;
+    return launch_wino<4, 0, true>(x1, nullptr, U, bias, nullptr, nullptr, y, sel, N, K, H, W, rows, (int)ceil_div(rows, 32),
+                                   as_stream(stream), GenArgs{x2, (int)K1, (int)(K1 + K2), 1.0f});
 }
 
 }  // extern "C"

@@ -76,24 +76,31 @@ def relu_affine(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, pre: 
     return _AffineAct.apply(x.contiguous(), scale, shift, pre, MODE_RELU_AFFINE, 0.0)
 
 
+def _add_maxpool2_raw(a, b, bias):
+    """(MaxPool2d(2)(a + b + bias[c]), selection bytes) — the kernel call, no autograd."""
+    _require(a, "a")
+    if a.dim() != 4:
+        raise ValueError(f"expected (N, C, H, W), got {tuple(a.shape)}")
+    if b is not None:
+        _require(b, "b")
+        if b.shape != a.shape:
+            raise ValueError("a and b must have the same shape")
+    N, C, H, W = a.shape
+    y = torch.empty((N, C, H // 2, W // 2), dtype=a.dtype, device=a.device)
+    sel = torch.empty(max(y.numel(), 1), dtype=torch.uint8, device=a.device)
+    with _Launch("add_maxpool2_forward", a.device):
+        st = _lib.load().advstep_add_maxpool2_forward_f32(a.data_ptr(), b.data_ptr() if b is not None else None,
+                                                          bias.data_ptr() if bias is not None else None, y.data_ptr(),
+                                                          sel.data_ptr(), N, C, H, W, _stream(a.device))
+    _lib.check(st, "advstep_add_maxpool2_forward_f32")
+    return y, sel
+
+
 class _AddMaxPool2(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b, bias):
-        _require(a, "a")
-        if a.dim() != 4:
-            raise ValueError(f"expected (N, C, H, W), got {tuple(a.shape)}")
-        if b is not None:
-            _require(b, "b")
-            if b.shape != a.shape:
-                raise ValueError("a and b must have the same shape")
+        y, sel = _add_maxpool2_raw(a, b, bias)
         N, C, H, W = a.shape
-        y = torch.empty((N, C, H // 2, W // 2), dtype=a.dtype, device=a.device)
-        sel = torch.empty(max(y.numel(), 1), dtype=torch.uint8, device=a.device)
-        with _Launch("add_maxpool2_forward", a.device):
-            st = _lib.load().advstep_add_maxpool2_forward_f32(a.data_ptr(), b.data_ptr() if b is not None else None,
-                                                              bias.data_ptr() if bias is not None else None, y.data_ptr(),
-                                                              sel.data_ptr(), N, C, H, W, _stream(a.device))
-        _lib.check(st, "advstep_add_maxpool2_forward_f32")
         ctx.save_for_backward(sel)
         ctx.shape = (N, C, H, W)
         ctx.two = b is not None
@@ -201,3 +208,166 @@ class _GateMaxPool2(torch.autograd.Function):
 def gate_maxpool2(x: torch.Tensor, gate: torch.Tensor) -> torch.Tensor:
     """MaxPool2d(2)(x * gate[n, c] + gate[n, c]), gate (N, C) or (N, C, 1, 1); differentiable in x and gate."""
     return _GateMaxPool2.apply(x.contiguous(), gate.contiguous())
+
+
+# ---- SpecRNet's residual block on the matrix cores (advstep_resconv_*, csrc/lcnn_wino.hip) -------------------------------
+
+def resconv_supported(K1: int, K2: int, rows: int) -> bool:
+    return bool(_lib.load().advstep_resconv_supported(K1, K2, rows))
+
+
+def resconv_prepare(w3: torch.Tensor, w1: Optional[torch.Tensor] = None, rscale: Optional[torch.Tensor] = None,
+                    kscale: Optional[torch.Tensor] = None, transpose: bool = False) -> torch.Tensor:
+    """Transformed weights U of one operator (see advstep_detector.h).  transpose=False: w3 (rows, K1, 3, 3), w1 (rows, K2[, 1, 1]);
+    transpose=True: the input gradient of a convolution with forward weights w3 (K1, rows, 3, 3), w1 (K2, rows[, 1, 1])."""
+    _require(w3, "w3")
+    rows, K1 = (w3.shape[1], w3.shape[0]) if transpose else (w3.shape[0], w3.shape[1])
+    K2 = 0 if w1 is None else (w1.shape[0] if transpose else w1.shape[1])
+    lib = _lib.load()
+    n = lib.advstep_resconv_prepared_floats(K1, K2, rows)
+    if n == 0:
+        raise ValueError(f"unsupported convolution: K1={K1}, K2={K2}, rows={rows}")
+    U = torch.empty(n, dtype=torch.float32, device=w3.device)
+    ptr = lambda t: None if t is None else t.contiguous().data_ptr()
+    keep = [t.contiguous() for t in (w3, w1, rscale, kscale) if t is not None]
+    with _Launch("resconv_prepare", w3.device):
+        st = lib.advstep_resconv_prepare_f32(keep[0].data_ptr(), ptr(w1), ptr(rscale), ptr(kscale), U.data_ptr(), rows, K1, K2,
+                                             int(transpose), _stream(w3.device))
+    _lib.check(st, "advstep_resconv_prepare_f32")
+    del keep
+    return U
+
+
+def resconv(x1: torch.Tensor, x2: Optional[torch.Tensor], U: torch.Tensor, rows: int, shift: Optional[torch.Tensor] = None,
+            slope: float = 1.0) -> torch.Tensor:
+    """leaky_relu(conv3x3(x1) + conv1x1(x2) + shift[row], slope) with prepared weights U — no autograd (building block)."""
+    _require(x1, "x1")
+    N, K1, H, W = x1.shape
+    K2 = 0 if x2 is None else x2.shape[1]
+    if x2 is not None:
+        _require(x2, "x2")
+        if x2.shape[0] != N or tuple(x2.shape[2:]) != (H, W):
+            raise ValueError("x1 and x2 must share batch and spatial dimensions")
+    y = torch.empty((N, rows, H, W), dtype=x1.dtype, device=x1.device)
+    with _Launch("resconv_forward", x1.device):
+        st = _lib.load().advstep_resconv_forward_f32(x1.data_ptr(), None if x2 is None else x2.data_ptr(), U.data_ptr(),
+                                                     None if shift is None else shift.data_ptr(), float(slope), y.data_ptr(), N,
+                                                     K1, K2, rows, H, W, _stream(x1.device))
+    _lib.check(st, "advstep_resconv_forward_f32")
+    return y
+
+
+def resconv_pool2(x1: torch.Tensor, x2: Optional[torch.Tensor], U: torch.Tensor, rows: int,
+                  bias: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(MaxPool2d(2)(conv3x3(x1) + conv1x1(x2) + bias[row]), selection bytes) — no autograd (building block)."""
+    _require(x1, "x1")
+    N, K1, H, W = x1.shape
+    K2 = 0 if x2 is None else x2.shape[1]
+    if x2 is not None:
+        _require(x2, "x2")
+    y = torch.empty((N, rows, H // 2, W // 2), dtype=x1.dtype, device=x1.device)
+    sel = torch.empty(max(y.numel(), 1), dtype=torch.uint8, device=x1.device)
+    with _Launch("resconv_pool2_forward", x1.device):
+        st = _lib.load().advstep_resconv_pool2_forward_f32(x1.data_ptr(), None if x2 is None else x2.data_ptr(), U.data_ptr(),
+                                                           None if bias is None else bias.data_ptr(), y.data_ptr(), sel.data_ptr(),
+                                                           N, K1, K2, rows, H, W, _stream(x1.device))
+    _lib.check(st, "advstep_resconv_pool2_forward_f32")
+    return y, sel
+
+
+class ResBlockPlan:
+    """Everything `res_block` needs from one `Residual_block2D` with frozen parameters: folded per-channel constants and
+    the transformed weights of its convolutions.  Built by `res_block_plan`, cached on the module until a parameter changes."""
+
+    def __init__(self, conv1, bn2, conv2, down, slope: float):
+        with torch.no_grad():
+            self.cin, self.cout, self.slope = conv1.in_channels, conv1.out_channels, float(slope)
+            scale, shift = bn_eval_affine(bn2)
+            if conv1.bias is not None:
+                shift = shift + conv1.bias * scale
+            self.scale, self.shift = scale.contiguous(), shift.contiguous()
+            w1, w2 = conv1.weight.detach(), conv2.weight.detach()
+            self.downsample = down is not None
+            wd = None if down is None else down.weight.detach().reshape(self.cout, self.cin).contiguous()
+            bias = None if conv2.bias is None else conv2.bias.detach()
+            if down is not None and down.bias is not None:
+                bias = down.bias.detach() if bias is None else bias + down.bias.detach()
+            self.bias = None if bias is None else bias.contiguous()
+            # forward: conv1 (+ bn2 scale on its rows), conv2 [+ downsample as centre taps over x]
+            self.U1 = resconv_prepare(w1, rscale=self.scale)
+            self.U2 = resconv_prepare(w2, wd)
+            # input gradients: d h1 from d h2; d x from d(conv1 out) [+ d h2 through the downsample]
+            self.U2T = resconv_prepare(w2, transpose=True)
+            self.U1T = resconv_prepare(w1, wd, kscale=self.scale, transpose=True)
+            self.ones, self.zeros = torch.ones_like(self.scale), torch.zeros_like(self.scale)
+
+
+def res_block_supported(conv1, conv2, down) -> bool:
+    def plain3(c):
+        return (c.kernel_size == (3, 3) and c.stride == (1, 1) and c.padding == (1, 1) and c.dilation == (1, 1) and c.groups == 1
+                and c.padding_mode == "zeros")
+    if not (plain3(conv1) and plain3(conv2) and conv2.in_channels == conv1.out_channels == conv2.out_channels):
+        return False
+    cin, cout = conv1.in_channels, conv1.out_channels
+    if down is not None and not (down.kernel_size == (1, 1) and down.stride == (1, 1) and down.padding == (0, 0)
+                                 and down.groups == 1 and down.in_channels == cin and down.out_channels == cout):
+        return False
+    if down is None and cin != cout:
+        return False
+    return (resconv_supported(cout, cin if down is not None else 0, cout)
+            and resconv_supported(cout, 0, cout) and resconv_supported(cin, 0, cout)
+            and resconv_supported(cout, cout if down is not None else 0, cin))
+
+
+def res_block_plan(block, conv1, bn2, conv2, down, slope: float) -> ResBlockPlan:
+    tensors = [t for m in (conv1, bn2, conv2, down) if m is not None for t in list(m.parameters()) + list(m.buffers())]
+    key = tuple((t.data_ptr(), t._version) for t in tensors)
+    if getattr(block, "_advstep_plan_key", None) != key:
+        block._advstep_plan_key, block._advstep_plan = key, ResBlockPlan(conv1, bn2, conv2, down, slope)
+    return block._advstep_plan
+
+
+class _ResBlock(torch.autograd.Function):
+    """MaxPool2d(2)(conv2(leaky_relu(bn2(conv1(x)))) + identity) of SpecRNet's Residual_block2D (src/models/specrnet.py:73-91),
+    identity = conv_downsample(x) or x; input gradient only.  The downsample convolution is part of conv2's reduction and the
+    pooling part of its epilogue; backward runs the transposed convolutions through the same kernel."""
+
+    @staticmethod
+    def forward(ctx, x, plan):
+        _require(x, "x")
+        p = plan
+        h1 = resconv(x, None, p.U1, p.cout, p.shift, p.slope)
+        if p.downsample:
+            y, sel = resconv_pool2(h1, x, p.U2, p.cout, p.bias)
+        else:
+            y, sel = _add_maxpool2_raw(resconv(h1, None, p.U2, p.cout), x, p.bias)
+        ctx.plan = p
+        ctx.save_for_backward(x, h1, sel)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        p = ctx.plan
+        x, h1, sel = ctx.saved_tensors
+        N, _, H, W = x.shape
+        gy = gy.contiguous()
+        lib = _lib.load()
+        g_h2 = torch.empty((N, p.cout, H, W), dtype=gy.dtype, device=gy.device)
+        with _Launch("maxpool2_backward", gy.device):
+            st = lib.advstep_maxpool2_backward_f32(gy.data_ptr(), sel.data_ptr(), g_h2.data_ptr(), N, p.cout, H, W, _stream(gy.device))
+        _lib.check(st, "advstep_maxpool2_backward_f32")
+        g_h1 = resconv(g_h2, None, p.U2T, p.cout)
+        g_pre = torch.empty_like(g_h1)                 # d(conv1 out) / scale = d h1 * lrelu'(h1)
+        with _Launch("affine_act_backward", gy.device):
+            st = lib.advstep_affine_act_backward_f32(g_h1.data_ptr(), h1.data_ptr(), p.ones.data_ptr(), p.zeros.data_ptr(), None,
+                                                     g_pre.data_ptr(), N, p.cout, H * W, MODE_AFFINE_LRELU, p.slope,
+                                                     _stream(gy.device))
+        _lib.check(st, "advstep_affine_act_backward_f32")
+        gx = resconv(g_pre, g_h2 if p.downsample else None, p.U1T, p.cin)
+        if not p.downsample:
+            gx += g_h2
+        return gx, None
+
+
+def res_block(x: torch.Tensor, plan: ResBlockPlan) -> torch.Tensor:
+    return _ResBlock.apply(x.contiguous(), plan)

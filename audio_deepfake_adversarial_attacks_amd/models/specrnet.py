@@ -52,6 +52,11 @@ class Residual_block2D(nn.Module):
         conv1 bias + bn2 + LeakyReLU in one pass; conv2 bias + downsample bias + residual add + MaxPool2d in one pass."""
         import torch.nn.functional as F
         from .. import detector_ops as D
+        down = self.conv_downsample if self.downsample else None
+        if _fused_conv_enabled() and x.dim() == 4 and D.res_block_supported(self.conv1, self.conv2, down):
+            # the whole block on the matrix cores (detector_ops._ResBlock): downsample inside conv2's reduction, pooling in
+            # its epilogue, transposed convolutions through the same kernel on the way back
+            return D.res_block(x, D.res_block_plan(self, self.conv1, self.bn2, self.conv2, down, self.lrelu.negative_slope))
         scale, shift = D.bn_eval_affine(self.bn2)
         if self.conv1.bias is not None:
             shift = shift + self.conv1.bias.detach() * scale
@@ -85,6 +90,12 @@ def _fused_elem_enabled() -> bool:
     """ADVSTEP_SPECRNET_ELEM=0 keeps the plain ATen / MIOpen elementwise chains (A/B measurements); default on."""
     import os
     return os.environ.get("ADVSTEP_SPECRNET_ELEM", "1") != "0"
+
+
+def _fused_conv_enabled() -> bool:
+    """ADVSTEP_SPECRNET_CONV=0 keeps ATen / MIOpen convolutions inside the residual blocks (A/B measurements); default on."""
+    import os
+    return os.environ.get("ADVSTEP_SPECRNET_CONV", "1") != "0"
 
 
 def _fused_gru_enabled() -> bool:

@@ -1,6 +1,7 @@
-/* advstep_detector.h — C ABI of the fused elementwise / pooling kernels of the SpecRNet and RawNet3 detectors
- * (csrc/detector_elem.hip; SURVEY.md section 8, rows a12 / a13: these op chains run 40-100 times per batch inside
- * `model(adv)` and are pure HBM streaming over the detectors' largest activations).
+/* advstep_detector.h — C ABI of the fused elementwise / pooling kernels and the residual-block convolutions of the SpecRNet
+ * and RawNet3 detectors (csrc/detector_elem.hip, csrc/lcnn_wino.hip; SURVEY.md section 8, rows a12 / a13: these op chains
+ * run 40-100 times per batch inside `model(adv)`; the elementwise ones are pure HBM streaming over the detectors' largest
+ * activations).
  *
  * Conventions as in advstep.h: raw device pointers, contiguous float32 NCHW / NCL tensors, caller-owned outputs, launches on
  * the given HIP stream, status code returned, no global state.  P = H * W (or L) is the per-channel plane size. */
@@ -59,6 +60,32 @@ int advstep_gate_maxpool2_forward_f32(const float *x, const float *gate, float *
 int advstep_gate_maxpool2_backward_f32(const float *gy, const uint8_t *sel, const float *x, const float *gate, float *gx,
                                        float *ggate_partial, int64_t N, int64_t C, int64_t H, int64_t W,
                                        advstep_stream_t stream);
+
+/* ---- 3x3 convolutions of SpecRNet's residual blocks on the fp32 matrix cores (csrc/lcnn_wino.hip) ------------------------
+ * Replaces the ATen / MIOpen calls behind `Residual_block2D.forward` (src/models/specrnet.py:73-91: conv1 -> bn2 -> lrelu ->
+ * conv2, `out += conv_downsample(x)`, `mp(out)`) and their input gradients while an attack runs (weights frozen).
+ *
+ * One operator: a stride-1, zero-padded 3x3 convolution over the K1 channels of x1 (N, K1, H, W) PLUS, optionally, a 1x1
+ * convolution over the K2 channels of x2 (N, K2, H, W) — one reduction of length K1 + K2 (Winograd F(2x2, 3x3), the 1x1
+ * part as centre-tap-only weights) — into `rows` output channels.  K1 % 4 == 0 when K2 > 0; K1 + K2, rows <= 256;
+ * every tensor < 2 GiB.  The weights are given once, transformed (advstep_resconv_prepare_f32) into U:
+ *   transpose 0   w3 (rows, K1, 3, 3), w1 (rows, K2)     the forward convolution(s)
+ *   transpose 1   w3 (K1, rows, 3, 3), w1 (K2, rows)     the input gradient of a convolution with these forward weights
+ *   rscale (rows) or NULL: factor on an output row (a folded eval BatchNorm scale);
+ *   kscale (K1) or NULL: factor on a reduction channel of the 3x3 part (the same scale, seen from the gradient side). */
+int advstep_resconv_supported(int64_t K1, int64_t K2, int64_t rows);
+size_t advstep_resconv_prepared_floats(int64_t K1, int64_t K2, int64_t rows);
+int advstep_resconv_prepare_f32(const float *w3, const float *w1, const float *rscale, const float *kscale, float *U,
+                                int64_t rows, int64_t K1, int64_t K2, int transpose, advstep_stream_t stream);
+/* y (N, rows, H, W) = leaky_relu(conv + shift[row], slope); shift may be NULL, slope = 1 is the plain convolution. */
+int advstep_resconv_forward_f32(const float *x1, const float *x2, const float *U, const float *shift, float slope, float *y,
+                                int64_t N, int64_t K1, int64_t K2, int64_t rows, int64_t H, int64_t W,
+                                advstep_stream_t stream);
+/* y (N, rows, H/2, W/2) = MaxPool2d(2)(conv + bias[row]) with the selection bytes of advstep_add_maxpool2_forward_f32
+ * (consumed by advstep_maxpool2_backward_f32): the full-resolution convolution output is never written. */
+int advstep_resconv_pool2_forward_f32(const float *x1, const float *x2, const float *U, const float *bias, float *y,
+                                      uint8_t *sel, int64_t N, int64_t K1, int64_t K2, int64_t rows, int64_t H, int64_t W,
+                                      advstep_stream_t stream);
 
 #ifdef __cplusplus
 }

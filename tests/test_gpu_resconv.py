@@ -1,0 +1,190 @@
+"""`-m gpu`: the residual-block convolutions of include/advstep_detector.h (advstep_resconv_*, Winograd F(2x2, 3x3) on the
+fp32 matrix cores) against ATen / MIOpen: the operator itself (3x3 over x1 + 1x1 over x2, shift, LeakyReLU), its pooled
+form, the transposed (input-gradient) preparation, and SpecRNet's whole Residual_block2D forward + input gradient.
+Winograd in fp32 rounds differently from a direct convolution, so values are compared with a tolerance relative to the
+output scale (written at each assert) and pooling selections are compared where the window's top two are not a near tie."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+REL = 2e-5          # max |difference| / max |reference| of one convolution
+
+
+@pytest.fixture(scope="module")
+def D(cuda):
+    from audio_deepfake_adversarial_attacks_amd import detector_ops
+    return detector_ops
+
+
+def rnd(shape, seed, cuda, scale=1.0):
+    return (torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale).to(cuda)
+
+
+# (N, K1, K2, rows, H, W): SpecRNet's layers at small sizes, odd sizes, padded reductions (K not a multiple of 8),
+# half-empty and single-tile last slices, a streamed reduction (K1 + K2 > 64)
+SHAPES = [(2, 20, 2, 20, 16, 24), (3, 64, 20, 64, 20, 101), (2, 64, 0, 64, 5, 25), (1, 20, 0, 64, 7, 9), (2, 64, 64, 20, 10, 12),
+          (1, 4, 0, 2, 6, 8), (2, 2, 0, 20, 8, 10), (2, 128, 0, 48, 9, 11), (1, 1, 0, 1, 3, 3), (2, 40, 0, 2, 6, 6),
+          (1, 20, 20, 33, 4, 6)]
+
+
+def reference(x1, x2, w3, w1, shift, slope):
+    y = F.conv2d(x1.double(), w3.double(), None, 1, 1)
+    if x2 is not None:
+        y = y + F.conv2d(x2.double(), w1.double()[:, :, None, None])
+    if shift is not None:
+        y = y + shift.double().view(1, -1, 1, 1)
+    return F.leaky_relu(y, slope)
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("slope,with_shift", [(1.0, False), (0.3, True)])
+def test_resconv_matches_direct_convolution(D, cuda, shape, slope, with_shift):
+    N, K1, K2, R, H, W = shape
+    x1, w3 = rnd((N, K1, H, W), 1, cuda), rnd((R, K1, 3, 3), 2, cuda, 0.2)
+    x2, w1 = (rnd((N, K2, H, W), 3, cuda), rnd((R, K2), 4, cuda, 0.3)) if K2 else (None, None)
+    shift = rnd((R,), 5, cuda) if with_shift else None
+    U = D.resconv_prepare(w3, w1)
+    y = D.resconv(x1, x2, U, R, shift, slope)
+    ref = reference(x1, x2, w3, w1, shift, slope)
+    assert y.shape == ref.shape
+    err = (y.double() - ref).abs().max().item()
+    assert err <= REL * ref.abs().max().item(), (err, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_resconv_transposed_preparation_is_the_input_gradient(D, cuda, shape):
+    """transpose=True with forward weights w3 (K1, rows, 3, 3) [, w1 (K2, rows)] and kscale: d/dx of
+    sum(g1 * (conv3x3(x, w3) * kscale)) + sum(g2 * conv1x1(x, w1))."""
+    N, K1, K2, R, H, W = shape
+    g1, w3, ks = rnd((N, K1, H, W), 1, cuda), rnd((K1, R, 3, 3), 2, cuda, 0.2), rnd((K1,), 6, cuda)
+    g2, w1 = (rnd((N, K2, H, W), 3, cuda), rnd((K2, R), 4, cuda, 0.3)) if K2 else (None, None)
+    U = D.resconv_prepare(w3, w1, kscale=ks, transpose=True)
+    gx = D.resconv(g1, g2, U, R)
+    x = torch.zeros((N, R, H, W), dtype=torch.float64, device=cuda, requires_grad=True)
+    out = (F.conv2d(x, w3.double(), None, 1, 1) * ks.double().view(1, -1, 1, 1) * g1.double()).sum()
+    if K2:
+        out = out + (F.conv2d(x, w1.double()[:, :, None, None]) * g2.double()).sum()
+    (ref,) = torch.autograd.grad(out, x)
+    err = (gx.double() - ref).abs().max().item()
+    assert err <= REL * ref.abs().max().item(), (err, ref.abs().max().item())
+
+
+def test_resconv_row_scale_is_folded_into_the_weights(D, cuda):
+    x, w3, rs = rnd((2, 20, 9, 10), 1, cuda), rnd((64, 20, 3, 3), 2, cuda, 0.2), rnd((64,), 3, cuda)
+    y = D.resconv(x, None, D.resconv_prepare(w3, rscale=rs), 64)
+    ref = F.conv2d(x.double(), w3.double(), None, 1, 1) * rs.double().view(1, -1, 1, 1)
+    assert (y.double() - ref).abs().max().item() <= REL * ref.abs().max().item()
+
+
+def test_padded_reduction_channels_do_not_read_the_next_sample(D, cuda):
+    """K1 + K2 = 22 is padded to 24: k-step 5 holds two channels that do not exist.  Their taps must come from the buffer
+    descriptor's out-of-range zero, not from the neighbouring sample's memory (here: NaN)."""
+    N, K1, K2, R, H, W = 2, 20, 2, 20, 8, 12
+    x1, x2 = rnd((N, K1, H, W), 1, cuda), rnd((N, K2, H, W), 2, cuda)
+    x1[1], x2[1] = float("nan"), float("nan")
+    w3, w1 = rnd((R, K1, 3, 3), 3, cuda, 0.2), rnd((R, K2), 4, cuda)
+    y = D.resconv(x1, x2, D.resconv_prepare(w3, w1), R)
+    assert torch.isfinite(y[0]).all() and torch.isnan(y[1]).all()
+    ref = reference(x1[:1], x2[:1], w3, w1, None, 1.0)
+    assert (y[:1].double() - ref).abs().max().item() <= REL * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("shape", [(2, 20, 2, 20, 16, 24), (3, 64, 20, 64, 20, 101), (2, 64, 0, 64, 5, 25), (1, 20, 2, 20, 7, 9),
+                                   (2, 32, 0, 40, 2, 2), (1, 8, 0, 3, 1, 6)])
+def test_resconv_pool2_matches_maxpool_of_the_convolution(D, cuda, shape):
+    N, K1, K2, R, H, W = shape
+    x1, w3 = rnd((N, K1, H, W), 1, cuda), rnd((R, K1, 3, 3), 2, cuda, 0.2)
+    x2, w1 = (rnd((N, K2, H, W), 3, cuda), rnd((R, K2), 4, cuda, 0.3)) if K2 else (None, None)
+    bias = rnd((R,), 5, cuda)
+    y, sel = D.resconv_pool2(x1, x2, D.resconv_prepare(w3, w1), R, bias)
+    full = reference(x1, x2, w3, w1, bias, 1.0)
+    Ho, Wo = H // 2, W // 2
+    assert y.shape == (N, R, Ho, Wo)
+    if Ho * Wo == 0:
+        return
+    ref, ref_idx = F.max_pool2d(full, 2, return_indices=True)
+    tol = REL * full.abs().max().item()
+    assert (y.double() - ref).abs().max().item() <= tol
+    # selection byte = 2 * dh + dw of the winner; compare where the window's best beats its runner-up by more than 2 tol
+    win = full[:, :, :2 * Ho, :2 * Wo].reshape(N, R, Ho, 2, Wo, 2).permute(0, 1, 2, 4, 3, 5).reshape(N, R, Ho, Wo, 4)
+    top = win.topk(2, dim=-1).values
+    clear = (top[..., 0] - top[..., 1]) > 2 * tol
+    ref_code = (((ref_idx // W) % 2) * 2 + (ref_idx % W) % 2).to(torch.uint8)
+    got = sel[:N * R * Ho * Wo].view(N, R, Ho, Wo)
+    assert clear.float().mean().item() > 0.9
+    assert torch.equal(got[clear], ref_code[clear])
+    assert (got < 4).all()
+    # and the byte is consistent with the value the kernel wrote, everywhere
+    picked = win.gather(-1, got.long().unsqueeze(-1)).squeeze(-1)
+    assert (picked - y.double()).abs().max().item() <= tol
+
+
+def make_block(cin, cout, first, cuda, seed):
+    from audio_deepfake_adversarial_attacks_amd.models.specrnet import Residual_block2D
+    torch.manual_seed(seed)
+    blk = Residual_block2D([cin, cout], first=first).to(cuda).eval()
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(seed + 1)
+        for m in blk.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.copy_(torch.empty(m.running_mean.shape).uniform_(-0.2, 0.2, generator=g))
+                m.running_var.copy_(torch.empty(m.running_var.shape).uniform_(0.5, 1.5, generator=g))
+                m.weight.copy_(torch.empty(m.weight.shape).uniform_(-1.0, 1.5, generator=g))   # some negative scales
+                m.bias.copy_(torch.empty(m.bias.shape).uniform_(-0.3, 0.3, generator=g))
+    for p in blk.parameters():
+        p.requires_grad_(False)
+    return blk
+
+
+@pytest.mark.parametrize("cin,cout,first,hw", [(2, 20, True, (16, 24)), (20, 64, False, (20, 101)), (64, 64, False, (5, 25)),
+                                               (2, 20, True, (80, 404))])
+def test_residual_block_matches_plain_modules(D, cuda, monkeypatch, parity_record, cin, cout, first, hw):
+    """Residual_block2D with frozen parameters: the matrix-core block (ADVSTEP_SPECRNET_CONV=1) against the plain torch modules
+    in float64 — output and input gradient.  A pooling winner at a near tie may go the other way, which moves single
+    gradient entries; the bound on the gradient is therefore on its relative L2 error."""
+    blk = make_block(cin, cout, first, cuda, 11)
+    x = rnd((2, cin) + hw, 7, cuda)
+    gy = rnd((2, cout, hw[0] // 2, hw[1] // 2), 8, cuda)
+
+    def run(module, inp, go):
+        a = inp.clone().requires_grad_(True)
+        y = module(a)
+        (gr,) = torch.autograd.grad(y, a, go)
+        return y.detach(), gr
+
+    monkeypatch.setenv("ADVSTEP_SPECRNET_CONV", "1")
+    monkeypatch.setenv("ADVSTEP_SPECRNET_ELEM", "1")
+    y1, g1 = run(blk, x, gy)
+    assert getattr(blk, "_advstep_plan", None) is not None, "the matrix-core block did not run"
+    import copy
+    ref = copy.deepcopy(blk).double()
+    monkeypatch.setenv("ADVSTEP_SPECRNET_ELEM", "0")
+    y0, g0 = run(ref, x.double(), gy.double())
+    fig = {"out_max_abs_over_max": ((y1.double() - y0).abs().max() / y0.abs().max()).item(),
+           "grad_rel_l2": ((g1.double() - g0).norm() / g0.norm()).item()}
+    parity_record[f"specrnet_block_{cin}_{cout}_{hw[0]}x{hw[1]}_matrix_cores_vs_float64_modules"] = fig
+    assert fig["out_max_abs_over_max"] <= 5e-5, fig
+    assert fig["grad_rel_l2"] <= 2e-3, fig
+
+
+def test_plan_is_rebuilt_when_a_parameter_changes(D, cuda, monkeypatch):
+    monkeypatch.setenv("ADVSTEP_SPECRNET_CONV", "1")
+    blk = make_block(20, 64, False, cuda, 5)
+    x = rnd((1, 20, 8, 10), 1, cuda)
+    y0 = blk(x)
+    plan0 = blk._advstep_plan
+    assert blk(x) is not None and blk._advstep_plan is plan0
+    with torch.no_grad():
+        blk.conv2.weight.mul_(2.0)
+    y1 = blk(x)
+    assert blk._advstep_plan is not plan0
+    assert not torch.allclose(y0, y1)
+
+
+def test_unsupported_shapes_are_refused(D, cuda):
+    assert not D.resconv_supported(0, 0, 4) and not D.resconv_supported(6, 2, 4) and not D.resconv_supported(200, 60, 4)
+    assert not D.resconv_supported(4, 0, 0) and not D.resconv_supported(4, 0, 257)
+    with pytest.raises(ValueError):
+        D.resconv_prepare(torch.zeros(4, 300, 3, 3, device=cuda))
