@@ -65,6 +65,7 @@ SIGNATURES = {
     "advstep_resconv_prepared_floats": (_sz, [_i64, _i64, _i64]),
     "advstep_resconv_prepare_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _i64, _i64, ctypes.c_int, _p]),
     "advstep_resconv_forward_f32": (ctypes.c_int, [_p, _p, _p, _p, ctypes.c_float, _p, _i64, _i64, _i64, _i64, _i64, _i64, _p]),
+    "advstep_resconv_pooled_grad_f32": (ctypes.c_int, [_p, _p, _p, _p, ctypes.c_float, _p, _i64, _i64, _i64, _i64, _i64, _p]),
     "advstep_resconv_pool2_forward_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _p]),
     # include/advstep_frontend.h
     "advstep_lfcc_block_count": (_sz, [_i64, _i64, _i64]),

@@ -196,8 +196,12 @@ __global__ void wino_prepare_plain_kernel(const float *__restrict__ w3, const fl
 //        gy (N, C, H/2, W/2) and the selection bytes (advstep_mfm_pool2_forward_f32's encoding), K = 2C: channel k of
 //        half k / C at conv position (h, w) carries gy[k % C][h/2][w/2] if that position of that half won, else 0.  The
 //        4x4 patch of a lane is expanded from the 3x3 pooled cells around its tile; the dense gradient never exists.
+// SRC 2: the same for a plain MaxPool2d(2) (no halves): gy (N, K, H/2, W/2) and ATen-order selection bytes (2 * dh + dw):
+//        channel k at (h, w) carries gy[k][h/2][w/2] if that position won its window, else 0 (odd trailing row / column: 0).
 // EPI 3: + shift[ch], LeakyReLU(slope), plain store            (the residual blocks of SpecRNet, advstep_detector.h)
 // EPI 4: + bias[ch], MaxPool2d(2) with ATen's selection byte (detector_elem.hip::pool4): the conv output never exists.
+// EPI 5: * (h > 0 ? 1 : slope) with h (N, Cout, H, W) passed in `bn_mean` — LeakyReLU's backward from its OUTPUT (same sign as
+//        its input for slope > 0) — plain store.
 // NT: accumulator tiles a wave computes — 2, or 1 for a convolution's LAST slice when only its first 16 rows exist
 //     (Cout % 32 in 1..16, LCNN's 128 -> 48 input gradient): that slice is launched on its own with half the matrix
 //     instructions instead of multiplying 16 zero rows.  slice0: first slice of this launch.
@@ -219,8 +223,8 @@ __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restri
                                                            const float *__restrict__ bn_invstd, float *__restrict__ y,
                                                            uint8_t *__restrict__ idx, int N, int K, int H, int W, int Cout,
                                                            int slices, int ranges, int slice0, GenArgs ga) {
-    static_assert(NT == 2 || EPI == 0 || EPI == 3, "one accumulator tile only for the plain-store epilogues");
-    static_assert(!GEN || SRC == 0, "two-tensor reduction only over dense sources");
+    static_assert(NT == 2 || EPI == 0 || EPI == 3 || EPI == 5, "one accumulator tile only for the plain-store epilogues");
+    static_assert(!GEN || SRC != 1, "the general reduction reads dense tensors or a plain pooled gradient");
     extern __shared__ __attribute__((aligned(16))) float u_s[];
     const int slice = slice0 + blockIdx.x % slices, range = blockIdx.x / slices;
     const int chunks = (K + kChunkCin - 1) / kChunkCin, steps = K / 4;
@@ -241,7 +245,8 @@ __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restri
     const int iters = (groups + ranges * kWaves - 1) / (ranges * kWaves);   // the same for every workgroup
     const uint32_t plane = (uint32_t)(H * W);
     // raw buffer over x: an out-of-range offset reads as 0 — the convolution's zero padding, for free
-    const int Hs = H >> 1, Ws = W >> 1, Cs = K >> 1;      // SRC 1: pooled grid, max-feature-map channels
+    // SRC 1: pooled grid, max-feature-map channels (two conv channels per pooled channel); SRC 2: pooled grid, Kreal channels
+    const int Hs = H >> 1, Ws = W >> 1, Cs = SRC == 1 ? K >> 1 : (GEN ? ga.Kreal : K);
     const uint32_t cplane = (uint32_t)(Hs * Ws);
     const int KA = GEN ? ga.K1 : K, KB = GEN ? ga.Kreal - ga.K1 : 0;      // channels of x and of x2
     const size_t src_elems = SRC == 0 ? (size_t)N * KA * plane : (size_t)N * Cs * cplane;
@@ -250,7 +255,7 @@ __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restri
     const __amdgpu_buffer_rsrc_t xr2 = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(GEN && KB > 0 ? ga.x2 : x), 0, GEN && KB > 0 ? (int)((size_t)N * KB * plane * 4) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t sr =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(SRC == 1 ? xsel : reinterpret_cast<const uint8_t *>(x)), 0,
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(SRC != 0 ? xsel : reinterpret_cast<const uint8_t *>(x)), 0,
                                           (int)src_elems, 0x00020000);
 
     for (int it = 0; it < iters; ++it) {
@@ -313,11 +318,12 @@ __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restri
                         dst.v[p * 4 + q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, vo, soff, 0));
                     }
             } else {
-                const int k0 = 4 * s, c0 = k0 >= Cs ? k0 - Cs : k0;      // wave-uniform: channel of lane group 0
+                const int k0 = 4 * s, c0 = SRC == 1 && k0 >= Cs ? k0 - Cs : k0;      // wave-uniform: channel of lane group 0
                 const uint32_t soff = (uint32_t)c0 * cplane;
+                const bool lane_ok = SRC == 1 || !GEN || k0 + g < ga.Kreal;        // padded reduction channels read 0
 #pragma unroll
                 for (int i = 0; i < 9; ++i) {
-                    const uint32_t e = cell[i / 3][i % 3];
+                    const uint32_t e = lane_ok ? cell[i / 3][i % 3] : 0x20000000u;
                     dst.v[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, e << 2, soff << 2, 0));
                     dst.code[i] = __builtin_amdgcn_raw_buffer_load_b8(sr, e, soff, 0);
                 }
@@ -331,7 +337,7 @@ __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restri
 #pragma unroll
                     for (int q = 0; q < 4; ++q) d[p][q] = src.v[p * 4 + q];
             } else {
-                const uint32_t half_bit = 4 * s >= Cs ? 4u : 0u;         // wave-uniform
+                const uint32_t half_bit = SRC == 1 && 4 * s >= Cs ? 4u : 0u;         // wave-uniform
 #pragma unroll
                 for (int p = 0; p < 4; ++p)
 #pragma unroll
@@ -510,6 +516,28 @@ __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restri
                     }
                     float *o = y + (((size_t)n * Cout + ch) * H + 2 * th) * W + 2 * tw;
                     const bool h1 = 2 * th + 1 < H;
+                    if (EPI == 5) {
+                        const float *hp = bn_mean + (((size_t)n * Cout + ch) * H + 2 * th) * W + 2 * tw;
+                        const bool w1 = 2 * tw + 1 < W;
+                        float hv[2][2] = {{1.0f, 1.0f}, {1.0f, 1.0f}};
+                        if ((W & 1) == 0) {
+                            const f32x2 a = *reinterpret_cast<const f32x2 *>(hp);
+                            hv[0][0] = a.x, hv[0][1] = a.y;
+                            if (h1) {
+                                const f32x2 b = *reinterpret_cast<const f32x2 *>(hp + W);
+                                hv[1][0] = b.x, hv[1][1] = b.y;
+                            }
+                        } else {
+                            hv[0][0] = hp[0];
+                            if (w1) hv[0][1] = hp[1];
+                            if (h1) {
+                                hv[1][0] = hp[W];
+                                if (w1) hv[1][1] = hp[W + 1];
+                            }
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) yy[m][e >> 1][e & 1] *= hv[e >> 1][e & 1] > 0.0f ? 1.0f : ga.slope;
+                    }
                     if ((W & 1) == 0) {   // rows are 8-byte aligned: one 64-bit store per tile row
                         *reinterpret_cast<f32x2 *>(o) = (f32x2){yy[m][0][0], yy[m][0][1]};
                         if (h1) *reinterpret_cast<f32x2 *>(o + W) = (f32x2){yy[m][1][0], yy[m][1][1]};
@@ -572,7 +600,7 @@ int launch_wino(const float *x, const uint8_t *xsel, const float *U, const float
     };
     // plain-store epilogues with a half-empty last slice (Cout % 32 in 1..16): that slice on its own, one accumulator tile
     int full = slices;
-    if constexpr (EPI == 0 || EPI == 3) {
+    if constexpr (EPI == 0 || EPI == 3 || EPI == 5) {
         const int live_last = (int)(Cout - (int64_t)(slices - 1) * 32);
         if (live_last <= 16 && half_slice_enabled()) {
             full = slices - 1;
@@ -732,6 +760,26 @@ int advstep_resconv_pool2_forward_f32(const float *x1, const float *x2, const fl
     const int64_t K = ceil_div(K1 + K2, 8) * 8;
     return launch_wino<4, 0, true>(x1, nullptr, U, bias, nullptr, nullptr, y, sel, N, K, H, W, rows, (int)ceil_div(rows, 32),
                                    as_stream(stream), GenArgs{x2, (int)K1, (int)(K1 + K2), 1.0f});
+}
+
+int advstep_resconv_pooled_grad_f32(const float *gy, const uint8_t *sel, const float *U, const float *h, float slope, float *g,
+                                    int64_t N, int64_t K, int64_t rows, int64_t H, int64_t W, advstep_stream_t stream) {
+    WINO_REQUIRE(N >= 0 && H >= 0 && W >= 0 && advstep_resconv_supported(K, 0, rows));
+    if (N == 0 || H == 0 || W == 0) return ADVSTEP_OK;
+    WINO_REQUIRE(g);
+    if (H / 2 == 0 || W / 2 == 0)
+        return hipMemsetAsync(g, 0, (size_t)N * rows * H * W * sizeof(float), as_stream(stream)) == hipSuccess ? ADVSTEP_OK
+                                                                                                                : ADVSTEP_ELAUNCH;
+    WINO_REQUIRE(gy && sel && U);
+    WINO_REQUIRE((uint64_t)N * K * (H / 2) * (W / 2) < (1ull << 29) && (uint64_t)N * rows * H * W * 4 < (1ull << 33) &&
+                 (uint64_t)N * ((H + 1) / 2) * ((W + 1) / 2) < (1ull << 31));
+    const int64_t Kp = ceil_div(K, 8) * 8;
+    const GenArgs ga{nullptr, (int)K, (int)K, slope};
+    if (h)
+        return launch_wino<5, 2, true>(gy, sel, U, nullptr, h, nullptr, g, nullptr, N, Kp, H, W, rows, (int)ceil_div(rows, 32),
+                                       as_stream(stream), ga);
+    return launch_wino<0, 2, true>(gy, sel, U, nullptr, nullptr, nullptr, g, nullptr, N, Kp, H, W, rows, (int)ceil_div(rows, 32),
+                                   as_stream(stream), ga);
 }
 
 }  // extern "C"

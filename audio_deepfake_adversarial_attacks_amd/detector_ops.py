@@ -275,6 +275,27 @@ def resconv_pool2(x1: torch.Tensor, x2: Optional[torch.Tensor], U: torch.Tensor,
     return y, sel
 
 
+def resconv_pooled_grad(gy: torch.Tensor, sel: torch.Tensor, U: torch.Tensor, rows: int, H: int, W: int,
+                        h: Optional[torch.Tensor] = None, slope: float = 1.0) -> torch.Tensor:
+    """conv3x3(unpool(gy, sel)) [* leaky_relu'(h)] with U prepared with transpose=True: the input gradient of a convolution whose
+    output went through MaxPool2d(2), straight from the pooled gradient (N, K, H//2, W//2) — no autograd (building block)."""
+    _require(gy, "gy")
+    N, K = gy.shape[0], gy.shape[1]
+    if tuple(gy.shape[2:]) != (H // 2, W // 2) or sel.numel() < gy.numel() or sel.dtype != torch.uint8:
+        raise ValueError("gy / sel do not match a 2x2 pooling of an (H, W) plane")
+    if h is not None:
+        _require(h, "h")
+        if tuple(h.shape) != (N, rows, H, W):
+            raise ValueError("h must have the output's shape")
+    g = torch.empty((N, rows, H, W), dtype=gy.dtype, device=gy.device)
+    with _Launch("resconv_pooled_grad", gy.device):
+        st = _lib.load().advstep_resconv_pooled_grad_f32(gy.data_ptr(), sel.data_ptr(), U.data_ptr(),
+                                                         None if h is None else h.data_ptr(), float(slope), g.data_ptr(), N, K, rows,
+                                                         H, W, _stream(gy.device))
+    _lib.check(st, "advstep_resconv_pooled_grad_f32")
+    return g
+
+
 class ResBlockPlan:
     """Everything `res_block` needs from one `Residual_block2D` with frozen parameters: folded per-channel constants and
     the transformed weights of its convolutions.  Built by `res_block_plan`, cached on the module until a parameter changes."""
@@ -299,7 +320,6 @@ class ResBlockPlan:
             # input gradients: d h1 from d h2; d x from d(conv1 out) [+ d h2 through the downsample]
             self.U2T = resconv_prepare(w2, transpose=True)
             self.U1T = resconv_prepare(w1, wd, kscale=self.scale, transpose=True)
-            self.ones, self.zeros = torch.ones_like(self.scale), torch.zeros_like(self.scale)
 
 
 def res_block_supported(conv1, conv2, down) -> bool:
@@ -352,17 +372,12 @@ class _ResBlock(torch.autograd.Function):
         N, _, H, W = x.shape
         gy = gy.contiguous()
         lib = _lib.load()
-        g_h2 = torch.empty((N, p.cout, H, W), dtype=gy.dtype, device=gy.device)
+        # d(conv1 out) / bn2 scale = conv2^T(unpool(gy)) * lrelu'(h1): unpooling in the operand load, lrelu' in the epilogue
+        g_pre = resconv_pooled_grad(gy, sel, p.U2T, p.cout, H, W, h1, p.slope)
+        g_h2 = torch.empty((N, p.cout, H, W), dtype=gy.dtype, device=gy.device)       # the identity path's gradient
         with _Launch("maxpool2_backward", gy.device):
             st = lib.advstep_maxpool2_backward_f32(gy.data_ptr(), sel.data_ptr(), g_h2.data_ptr(), N, p.cout, H, W, _stream(gy.device))
         _lib.check(st, "advstep_maxpool2_backward_f32")
-        g_h1 = resconv(g_h2, None, p.U2T, p.cout)
-        g_pre = torch.empty_like(g_h1)                 # d(conv1 out) / scale = d h1 * lrelu'(h1)
-        with _Launch("affine_act_backward", gy.device):
-            st = lib.advstep_affine_act_backward_f32(g_h1.data_ptr(), h1.data_ptr(), p.ones.data_ptr(), p.zeros.data_ptr(), None,
-                                                     g_pre.data_ptr(), N, p.cout, H * W, MODE_AFFINE_LRELU, p.slope,
-                                                     _stream(gy.device))
-        _lib.check(st, "advstep_affine_act_backward_f32")
         gx = resconv(g_pre, g_h2 if p.downsample else None, p.U1T, p.cin)
         if not p.downsample:
             gx += g_h2

@@ -87,6 +87,14 @@ int advstep_resconv_pool2_forward_f32(const float *x1, const float *x2, const fl
                                       uint8_t *sel, int64_t N, int64_t K1, int64_t K2, int64_t rows, int64_t H, int64_t W,
                                       advstep_stream_t stream);
 
+/* g (N, rows, H, W) = conv3x3(unpool(gy, sel)) [* (h > 0 ? 1 : slope)]: the input gradient of a convolution whose OUTPUT went
+ * through MaxPool2d(2), from the pooled gradient gy (N, K, H/2, W/2) and the selection bytes — the full-resolution
+ * d(conv out) is expanded inside the operand load and never written — with U prepared with transpose 1; h (N, rows, H, W),
+ * when given, is the LeakyReLU output that fed the convolution (its sign is its input's sign): the activation's backward
+ * in the epilogue (specrnet.py:80-81 on the way back). */
+int advstep_resconv_pooled_grad_f32(const float *gy, const uint8_t *sel, const float *U, const float *h, float slope, float *g,
+                                    int64_t N, int64_t K, int64_t rows, int64_t H, int64_t W, advstep_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -121,6 +121,38 @@ def test_resconv_pool2_matches_maxpool_of_the_convolution(D, cuda, shape):
     assert (picked - y.double()).abs().max().item() <= tol
 
 
+@pytest.mark.parametrize("shape", [(2, 20, 20, 16, 24), (3, 64, 64, 20, 101), (2, 64, 64, 5, 25), (1, 20, 20, 7, 9), (2, 12, 40, 2, 2),
+                                   (1, 8, 3, 1, 6), (2, 4, 2, 6, 8)])
+@pytest.mark.parametrize("with_h", [False, True])
+def test_pooled_gradient_source_equals_the_dense_path(D, cuda, shape, with_h):
+    """advstep_resconv_pooled_grad_f32 expands the pooled gradient inside the operand load and applies LeakyReLU's backward in
+    the epilogue: the same numbers in the same order as unpooling (advstep_maxpool2_backward_f32), the dense convolution and
+    the elementwise backward pass — bit for bit."""
+    N, K, R, H, W = shape
+    full = rnd((N, K, H, W), 1, cuda)
+    U = D.resconv_prepare(rnd((K, R, 3, 3), 2, cuda, 0.2), transpose=True)
+    h = rnd((N, R, H, W), 3, cuda) if with_h else None
+    if h is not None:
+        h[0, 0, 0, 0] = 0.0                      # leaky_relu_backward at exactly 0 takes the slope
+    if H // 2 == 0 or W // 2 == 0:
+        gy = torch.zeros((N, K, H // 2, W // 2), device=cuda)
+        sel = torch.zeros(1, dtype=torch.uint8, device=cuda)
+        assert not D.resconv_pooled_grad(gy, sel, U, R, H, W, h, 0.3).any()
+        return
+    _, sel = D._add_maxpool2_raw(full, None, None)
+    gy = rnd((N, K, H // 2, W // 2), 4, cuda)
+    got = D.resconv_pooled_grad(gy, sel, U, R, H, W, h, 0.3)
+    dense = torch.empty_like(full)
+    from audio_deepfake_adversarial_attacks_amd import _lib
+    from audio_deepfake_adversarial_attacks_amd.hip_ops import _stream
+    _lib.check(_lib.load().advstep_maxpool2_backward_f32(gy.data_ptr(), sel.data_ptr(), dense.data_ptr(), N, K, H, W, _stream(cuda)),
+               "advstep_maxpool2_backward_f32")
+    ref = D.resconv(dense, None, U, R)
+    if h is not None:
+        ref = ref * torch.where(h > 0, 1.0, 0.3).to(ref.dtype)
+    assert torch.equal(got, ref)
+
+
 def make_block(cin, cout, first, cuda, seed):
     from audio_deepfake_adversarial_attacks_amd.models.specrnet import Residual_block2D
     torch.manual_seed(seed)
