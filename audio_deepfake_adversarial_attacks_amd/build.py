@@ -11,7 +11,8 @@ ROOT = PKG.parent
 SOURCES = [PKG / "csrc" / "advstep.hip", PKG / "csrc" / "lcnn_mfm.hip", PKG / "csrc" / "lcnn_conv0.hip",
            PKG / "csrc" / "lcnn_conv1x1.hip", PKG / "csrc" / "lcnn_lstm.hip", PKG / "csrc" / "lcnn_wino.hip",
            PKG / "csrc" / "lfcc.hip", PKG / "csrc" / "lfcc_stft.hip", PKG / "csrc" / "fab.hip",
-           PKG / "csrc" / "wave_prep.hip", PKG / "csrc" / "specrnet_gru.hip", PKG / "csrc" / "detector_elem.hip"]
+           PKG / "csrc" / "wave_prep.hip", PKG / "csrc" / "specrnet_gru.hip", PKG / "csrc" / "detector_elem.hip",
+           PKG / "csrc" / "detector_conv.hip"]
 HEADERS = [ROOT / "include" / "advstep.h", ROOT / "include" / "advstep_lcnn.h", ROOT / "include" / "advstep_frontend.h",
            ROOT / "include" / "advstep_fab.h", ROOT / "include" / "advstep_dataset.h", ROOT / "include" / "advstep_detector.h"]
 LIB = PKG / "libadvstep.so"

@@ -296,6 +296,45 @@ def resconv_pooled_grad(gy: torch.Tensor, sel: torch.Tensor, U: torch.Tensor, ro
     return g
 
 
+def conv3x3_fewin_supported(channels: int) -> bool:
+    return bool(_lib.load().advstep_conv3x3_fewin_supported(channels))
+
+
+def conv3x3_fewin(x: torch.Tensor, w: torch.Tensor, shift: Optional[torch.Tensor], slope: float) -> torch.Tensor:
+    """leaky_relu(conv3x3(x, w, pad 1) + shift[co], slope) for 1-2 input channels (vector-ALU kernel) — no autograd."""
+    _require(x, "x"), _require(w, "w")
+    N, Cin, H, W = x.shape
+    Cout = w.shape[0]
+    y = torch.empty((N, Cout, H, W), dtype=x.dtype, device=x.device)
+    with _Launch("conv3x3_fewin_forward", x.device):
+        st = _lib.load().advstep_conv3x3_fewin_forward_f32(x.data_ptr(), w.data_ptr(), None if shift is None else shift.data_ptr(),
+                                                           float(slope), y.data_ptr(), N, Cin, Cout, H, W, _stream(x.device))
+    _lib.check(st, "advstep_conv3x3_fewin_forward_f32")
+    return y
+
+
+def conv3x3_fewout_grad(g1: torch.Tensor, w3: torch.Tensor, gp: Optional[torch.Tensor] = None, sel: Optional[torch.Tensor] = None,
+                        wd: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Input gradient (1-2 channels) of conv3x3(x, w3 (K, rows, 3, 3)) for d(out) = g1, plus that of the 1x1 convolution wd (K, rows)
+    whose d(out) is the unpooled (gp, sel) — no autograd."""
+    _require(g1, "g1"), _require(w3, "w3")
+    N, K, H, W = g1.shape
+    rows = w3.shape[1]
+    if gp is not None:
+        _require(gp, "gp"), _require(wd, "wd")
+        if tuple(gp.shape) != (N, K, H // 2, W // 2) or sel.numel() < gp.numel() or tuple(wd.shape) != (K, rows):
+            raise ValueError("gp / sel / wd do not match")
+        if gp.numel() == 0:                    # nothing was pooled (H or W < 2): the identity path carries no gradient
+            gp = None
+    gx = torch.empty((N, rows, H, W), dtype=g1.dtype, device=g1.device)
+    with _Launch("conv3x3_fewout_grad", g1.device):
+        st = _lib.load().advstep_conv3x3_fewout_grad_f32(g1.data_ptr(), w3.data_ptr(), None if gp is None else gp.data_ptr(),
+                                                         None if gp is None else sel.data_ptr(), None if gp is None else wd.data_ptr(),
+                                                         gx.data_ptr(), N, K, rows, H, W, _stream(g1.device))
+    _lib.check(st, "advstep_conv3x3_fewout_grad_f32")
+    return gx
+
+
 class ResBlockPlan:
     """Everything `res_block` needs from one `Residual_block2D` with frozen parameters: folded per-channel constants and
     the transformed weights of its convolutions.  Built by `res_block_plan`, cached on the module until a parameter changes."""
@@ -314,12 +353,17 @@ class ResBlockPlan:
             if down is not None and down.bias is not None:
                 bias = down.bias.detach() if bias is None else bias + down.bias.detach()
             self.bias = None if bias is None else bias.contiguous()
+            # 1-2 input channels (the spectrogram end): conv1 and the d x convolution on the vector ALUs, bn2's scale inside
+            # the weights; otherwise everything on the matrix cores
+            self.fewin = self.downsample and conv3x3_fewin_supported(self.cin)
             # forward: conv1 (+ bn2 scale on its rows), conv2 [+ downsample as centre taps over x]
-            self.U1 = resconv_prepare(w1, rscale=self.scale)
+            self.w1_scaled = (w1 * self.scale.view(-1, 1, 1, 1)).contiguous() if self.fewin else None
+            self.wd = wd
+            self.U1 = None if self.fewin else resconv_prepare(w1, rscale=self.scale)
             self.U2 = resconv_prepare(w2, wd)
             # input gradients: d h1 from d h2; d x from d(conv1 out) [+ d h2 through the downsample]
             self.U2T = resconv_prepare(w2, transpose=True)
-            self.U1T = resconv_prepare(w1, wd, kscale=self.scale, transpose=True)
+            self.U1T = None if self.fewin else resconv_prepare(w1, wd, kscale=self.scale, transpose=True)
 
 
 def res_block_supported(conv1, conv2, down) -> bool:
@@ -356,7 +400,10 @@ class _ResBlock(torch.autograd.Function):
     def forward(ctx, x, plan):
         _require(x, "x")
         p = plan
-        h1 = resconv(x, None, p.U1, p.cout, p.shift, p.slope)
+        if p.fewin:
+            h1 = conv3x3_fewin(x, p.w1_scaled, p.shift, p.slope)
+        else:
+            h1 = resconv(x, None, p.U1, p.cout, p.shift, p.slope)
         if p.downsample:
             y, sel = resconv_pool2(h1, x, p.U2, p.cout, p.bias)
         else:
@@ -374,6 +421,8 @@ class _ResBlock(torch.autograd.Function):
         lib = _lib.load()
         # d(conv1 out) / bn2 scale = conv2^T(unpool(gy)) * lrelu'(h1): unpooling in the operand load, lrelu' in the epilogue
         g_pre = resconv_pooled_grad(gy, sel, p.U2T, p.cout, H, W, h1, p.slope)
+        if p.fewin:
+            return conv3x3_fewout_grad(g_pre, p.w1_scaled, gy, sel, p.wd), None
         g_h2 = torch.empty((N, p.cout, H, W), dtype=gy.dtype, device=gy.device)       # the identity path's gradient
         with _Launch("maxpool2_backward", gy.device):
             st = lib.advstep_maxpool2_backward_f32(gy.data_ptr(), sel.data_ptr(), g_h2.data_ptr(), N, p.cout, H, W, _stream(gy.device))

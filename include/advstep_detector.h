@@ -95,6 +95,21 @@ int advstep_resconv_pool2_forward_f32(const float *x1, const float *x2, const fl
 int advstep_resconv_pooled_grad_f32(const float *gy, const uint8_t *sel, const float *U, const float *h, float slope, float *g,
                                     int64_t N, int64_t K, int64_t rows, int64_t H, int64_t W, advstep_stream_t stream);
 
+/* ---- the spectrogram end of SpecRNet's first block: 3x3 convolutions with 1-2 channels on one side (csrc/detector_conv.hip) --
+ * Vector-ALU kernels (a matrix tile would be mostly padding), thread = one 2x2 block of positions.
+ * forward:  y (N, Cout, H, W) = leaky_relu(conv3x3(x (N, Cin, H, W), w (Cout, Cin, 3, 3), pad 1) + shift[co], slope), Cin in {1, 2};
+ *           a folded BatchNorm scale is expected INSIDE w (specrnet.py:76-81: conv1 -> bn2 -> lrelu of block0).
+ * grad:     gx (N, rows, H, W), rows in {1, 2}: the input gradient of conv3x3(x, w3 (K, rows, 3, 3)) given d(out) = g1 (N, K, H, W),
+ *           plus — when gp / sel / wd are given — the input gradient of the 1x1 convolution wd (K, rows) whose d(out) is the
+ *           unpooled gradient of MaxPool2d(2) in compact form (gp (N, K, H/2, W/2), sel as advstep_add_maxpool2_forward_f32 writes
+ *           it): `conv_downsample`'s share of d x (specrnet.py:83-90 on the way back).  Every sample < 2 GiB per tensor. */
+int advstep_conv3x3_fewin_supported(int64_t channels);
+int advstep_conv3x3_fewin_forward_f32(const float *x, const float *w, const float *shift, float slope, float *y, int64_t N,
+                                      int64_t Cin, int64_t Cout, int64_t H, int64_t W, advstep_stream_t stream);
+int advstep_conv3x3_fewout_grad_f32(const float *g1, const float *w3, const float *gp, const uint8_t *sel, const float *wd,
+                                    float *gx, int64_t N, int64_t K, int64_t rows, int64_t H, int64_t W,
+                                    advstep_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -153,6 +153,39 @@ def test_pooled_gradient_source_equals_the_dense_path(D, cuda, shape, with_h):
     assert torch.equal(got, ref)
 
 
+@pytest.mark.parametrize("shape", [(2, 2, 20, 16, 24), (2, 1, 20, 7, 9), (1, 2, 5, 1, 1), (2, 2, 20, 80, 404), (3, 1, 3, 2, 3), (1, 2, 7, 5, 4)])
+def test_few_input_channel_convolution_matches_aten(D, cuda, shape):
+    N, Cin, Cout, H, W = shape
+    x, w, shift = rnd((N, Cin, H, W), 1, cuda), rnd((Cout, Cin, 3, 3), 2, cuda, 0.3), rnd((Cout,), 3, cuda)
+    y = D.conv3x3_fewin(x, w, shift, 0.3)
+    ref = F.leaky_relu(F.conv2d(x.double(), w.double(), shift.double(), 1, 1), 0.3)
+    assert (y.double() - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()      # direct fp32 sums of 9-18 terms
+    y1 = D.conv3x3_fewin(x, w, None, 1.0)
+    ref1 = F.conv2d(x.double(), w.double(), None, 1, 1)
+    assert (y1.double() - ref1).abs().max().item() <= 2e-6 * ref1.abs().max().item()
+
+
+@pytest.mark.parametrize("shape", [(2, 20, 2, 16, 24), (2, 20, 1, 7, 9), (1, 5, 2, 1, 1), (2, 20, 2, 80, 404), (3, 3, 1, 2, 3), (1, 7, 2, 5, 4)])
+@pytest.mark.parametrize("pooled", [False, True])
+def test_few_output_row_gradient_matches_autograd(D, cuda, shape, pooled):
+    """gx = d/dx [ sum(g1 * conv3x3(x, w3)) + sum(unpool(gp, sel) * conv1x1(x, wd)) ]."""
+    N, K, R, H, W = shape
+    g1, w3 = rnd((N, K, H, W), 1, cuda), rnd((K, R, 3, 3), 2, cuda, 0.3)
+    x = torch.zeros((N, R, H, W), dtype=torch.float64, device=cuda, requires_grad=True)
+    out = (F.conv2d(x, w3.double(), None, 1, 1) * g1.double()).sum()
+    gp = sel = wd = None
+    if pooled:
+        full = rnd((N, K, H, W), 3, cuda)
+        gp, wd = rnd((N, K, H // 2, W // 2), 4, cuda), rnd((K, R), 5, cuda)
+        _, sel = D._add_maxpool2_raw(full, None, None)
+        if gp.numel():
+            dense = torch.autograd.grad(F.max_pool2d(full.requires_grad_(True), 2), full, gp)[0]
+            out = out + (F.conv2d(x, wd.double()[:, :, None, None]) * dense.double()).sum()
+    (ref,) = torch.autograd.grad(out, x)
+    gx = D.conv3x3_fewout_grad(g1, w3, gp, sel, wd)
+    assert (gx.double() - ref).abs().max().item() <= 4e-6 * max(ref.abs().max().item(), 1e-30)   # sums of up to 9 K + K terms
+
+
 def make_block(cin, cout, first, cuda, seed):
     from audio_deepfake_adversarial_attacks_amd.models.specrnet import Residual_block2D
     torch.manual_seed(seed)
@@ -171,7 +204,7 @@ def make_block(cin, cout, first, cuda, seed):
 
 
 @pytest.mark.parametrize("cin,cout,first,hw", [(2, 20, True, (16, 24)), (20, 64, False, (20, 101)), (64, 64, False, (5, 25)),
-                                               (2, 20, True, (80, 404))])
+                                               (2, 20, True, (80, 404)), (1, 20, True, (9, 13)), (4, 20, True, (8, 12))])
 def test_residual_block_matches_plain_modules(D, cuda, monkeypatch, parity_record, cin, cout, first, hw):
     """Residual_block2D with frozen parameters: the matrix-core block (ADVSTEP_SPECRNET_CONV=1) against the plain torch modules
     in float64 — output and input gradient.  A pooling winner at a near tie may go the other way, which moves single
