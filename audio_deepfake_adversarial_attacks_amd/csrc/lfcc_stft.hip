@@ -414,6 +414,7 @@ __global__ __launch_bounds__(kThreads) void stft_bands_backward_kernel(const flo
 // ---- mel-spec frontend (src/frontends.py:53-79): STFT -> MelScale on the real and imaginary parts -> |.|, angle ----------
 // out (B, 2, M, NF): plane 0 the magnitude, plane 1 the phase of  Y[m] = sum_k fb[k, m] X[k].
 constexpr int kMelMax = 80;
+constexpr int kMelMaxSpan = 48;     // longest run of bins under one band the kernels take (80 HTK bands over 257 bins: 16)
 
 struct LdsMel {
     Lds c;
@@ -421,25 +422,51 @@ struct LdsMel {
     float stage[2][kMelMax][kFramesPerBlockFwd + 1];         // (plane, band, frame) tile of the output / its gradient
 };
 
-__device__ __forceinline__ void mel_bands(const Lds &L, int wave, int lane, const int32_t *__restrict__ fb_start,
-                                          const float *__restrict__ fb_w, int span, int M, float2 *y) {
-    for (int m = lane; m < M; m += 64) {
-        const int f0 = fb_start[m];
-        float re = 0.0f, im = 0.0f;
-        for (int j = 0; j < span; ++j) {
-            const int k = f0 + j;
-            if (k < kBins) {
-                const float wj = fb_w[m * span + j];
+// A lane owns bands `lane` and `lane + 64` (M <= 80) and keeps their taps in registers: the filterbank is the same for every
+// frame a wave transforms, and a per-tap table load in the band loop (one dependent L1 round trip per tap, 2 x span per
+// frame) was most of the mel kernels' time.  Taps past the band's run, past `span` or past the last bin are 0 with a clamped
+// bin index: `fma(0, X[k], acc)` leaves acc unchanged.
+template <int CAP>
+struct MelTaps {
+    float w[2][CAP];
+    int f0[2];
+};
+
+template <int CAP>
+__device__ __forceinline__ void load_mel_taps(MelTaps<CAP> &t, int lane, const int32_t *__restrict__ fb_start,
+                                              const float *__restrict__ fb_w, int span, int M) {
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int m = lane + 64 * pass;
+        const bool live = m < M;
+        const int f0 = live ? fb_start[m] : 0;
+        t.f0[pass] = f0;
+#pragma unroll
+        for (int j = 0; j < CAP; ++j) t.w[pass][j] = (live && j < span && f0 + j < kBins) ? fb_w[m * span + j] : 0.0f;
+    }
+}
+
+template <int CAP>
+__device__ __forceinline__ void mel_bands(const Lds &L, int wave, int lane, const MelTaps<CAP> &t, int M, float2 *y) {
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int m = lane + 64 * pass;
+        if (m < M) {
+            float re = 0.0f, im = 0.0f;
+#pragma unroll
+            for (int j = 0; j < CAP; ++j) {
+                const int k = t.f0[pass] + j < kBins ? t.f0[pass] + j : kBins - 1;
                 const float2 z = L.xs_of(wave)[k];
-                re = fmaf(wj, z.x, re);
-                im = fmaf(wj, z.y, im);
+                re = fmaf(t.w[pass][j], z.x, re);
+                im = fmaf(t.w[pass][j], z.y, im);
             }
+            y[m] = make_float2(re, im);
         }
-        y[m] = make_float2(re, im);
     }
 }
 
 // grid (ceil(NF / 16), B)
+template <int CAP>
 __global__ __launch_bounds__(kThreads) void stft_mel_kernel(const float *__restrict__ x, const float *__restrict__ w,
                                                             const int32_t *__restrict__ fb_start,
                                                             const float *__restrict__ fb_w, int span,
@@ -452,11 +479,13 @@ __global__ __launch_bounds__(kThreads) void stft_mel_kernel(const float *__restr
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t b = blockIdx.y;
     const int f_base = blockIdx.x * kFramesPerBlockFwd;
+    MelTaps<CAP> taps;
+    load_mel_taps(taps, lane, fb_start, fb_w, span, M);
     for (int r = 0; r < kFramesPerBlockFwd / kWavesPerBlock; ++r) {
         const int fl = r * kWavesPerBlock + wave, f = f_base + fl;
         if (f >= NF) break;                       // wave-uniform
         frame_spectrum(x + b * T, w, T, f, hop, L, wave, lane);
-        mel_bands(L, wave, lane, fb_start, fb_w, span, M, S.y[wave]);
+        mel_bands(L, wave, lane, taps, M, S.y[wave]);
         wave_lds_sync();
         for (int m = lane; m < M; m += 64) {
             const float2 v = S.y[wave][m];
@@ -482,6 +511,9 @@ struct LdsMelBwd {
 };
 
 // grid (ceil(NF / 4), B).  dout (B, 2, M, NF) -> dx (B, T), dx zeroed by the host entry point.
+// SPT >= span_t: a lane owns bins lane + 64 p (p < 5) and keeps their transposed-filterbank taps in registers as well, loaded
+// before the transform so the table's latency hides behind it.
+template <int CAP, int SPT>
 __global__ __launch_bounds__(kThreads) void stft_mel_backward_kernel(const float *__restrict__ x, const float *__restrict__ w,
                                                                      const float *__restrict__ dout,
                                                                      const int32_t *__restrict__ fb_start,
@@ -503,11 +535,24 @@ __global__ __launch_bounds__(kThreads) void stft_mel_backward_kernel(const float
     }
     __syncthreads();
     const float *xb = x + b * T;
+    MelTaps<CAP> taps;
+    load_mel_taps(taps, lane, fb_start, fb_w, span, M);
+    constexpr int kBinPasses = (kBins + 63) / 64;
+    float tw_t[kBinPasses][SPT];
+    int m0_t[kBinPasses];
+#pragma unroll
+    for (int p = 0; p < kBinPasses; ++p) {
+        const int k = lane + 64 * p;
+        const bool in = k < kBins;
+        m0_t[p] = in ? fbt_start[k] : 0;
+#pragma unroll
+        for (int j = 0; j < SPT; ++j) tw_t[p][j] = (in && j < span_t && m0_t[p] + j < M) ? fbt_w[k * span_t + j] : 0.0f;
+    }
     for (int r = 0; r < kFramesPerBlockBwd / kWavesPerBlock; ++r) {
         const int fl = r * kWavesPerBlock + wave, f = f_base + fl;
         const bool live = f < NF;
         frame_spectrum(xb, w, T, live ? f : NF - 1, hop, L, wave, lane);
-        mel_bands(L, wave, lane, fb_start, fb_w, span, M, S.y[wave]);
+        mel_bands(L, wave, lane, taps, M, S.y[wave]);
         wave_lds_sync();
         // d(|Y|, angle Y) -> (dL/dRe Y, dL/dIm Y): torch's abs / angle backward, 0 at Y = 0
         for (int m = lane; m < M; m += 64) {
@@ -524,18 +569,20 @@ __global__ __launch_bounds__(kThreads) void stft_mel_backward_kernel(const float
         }
         wave_lds_sync();
         // dX[k] = sum_j fbt_w[k, j] dY[fbt_start[k] + j]
-        for (int k = lane; k < kBins; k += 64) {
-            const int m0 = fbt_start[k];
-            float re = 0.0f, im = 0.0f;
-            for (int j = 0; j < span_t; ++j) {
-                const int m = m0 + j;
-                if (m < M) {
-                    const float wj = fbt_w[k * span_t + j];
-                    re = fmaf(wj, S.y[wave][m].x, re);
-                    im = fmaf(wj, S.y[wave][m].y, im);
+#pragma unroll
+        for (int p = 0; p < kBinPasses; ++p) {
+            const int k = lane + 64 * p;
+            if (k < kBins) {
+                float re = 0.0f, im = 0.0f;
+#pragma unroll
+                for (int j = 0; j < SPT; ++j) {
+                    const int m = m0_t[p] + j < M ? m0_t[p] + j : M - 1;      // past the run: weight 0
+                    const float2 gy = S.y[wave][m];
+                    re = fmaf(tw_t[p][j], gy.x, re);
+                    im = fmaf(tw_t[p][j], gy.y, im);
                 }
+                L.xs_of(wave)[k] = make_float2(re, im);
             }
-            L.xs_of(wave)[k] = make_float2(re, im);
         }
         wave_lds_sync();
         spectrum_grad_to_frame<false>(L, wave, lane, w, S.dframe[fl], live);
@@ -619,15 +666,18 @@ int advstep_stft_mel_f32(const float *x, const float *window, const int32_t *fb_
                          advstep_stream_t stream) {
     STFT_REQUIRE(B >= 0 && NF >= 0 && M >= 0 && span >= 1);
     if (B == 0 || NF == 0 || M == 0) return ADVSTEP_OK;
-    STFT_REQUIRE(x && window && fb_start && fb_w && out && B <= kMaxGridY && M <= kMelMax);
+    STFT_REQUIRE(x && window && fb_start && fb_w && out && B <= kMaxGridY && M <= kMelMax && span <= kMelMaxSpan);
     STFT_REQUIRE(advstep_stft_bands_supported(nfft, hop, T) && NF == 1 + T / hop);
     hipStream_t st = as_stream(stream);
     ensure_twiddles(st);
     const size_t lds = sizeof(LdsMel);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(stft_mel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds);
-    hipLaunchKernelGGL(stft_mel_kernel, dim3((unsigned)ceil_div(NF, kFramesPerBlockFwd), (unsigned)B), dim3(kThreads), lds, st,
-                       x, window, fb_start, fb_w, (int)span, out, (int)T, (int)NF, (int)hop, (int)M);
+    auto go = [&](auto kernel) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kernel, dim3((unsigned)ceil_div(NF, kFramesPerBlockFwd), (unsigned)B), dim3(kThreads), lds, st, x,
+                           window, fb_start, fb_w, (int)span, out, (int)T, (int)NF, (int)hop, (int)M);
+    };
+    if (span <= 16) go(stft_mel_kernel<16>);
+    else go(stft_mel_kernel<kMelMaxSpan>);
     return status_after_launch();
 }
 
@@ -637,18 +687,23 @@ int advstep_stft_mel_backward_f32(const float *x, const float *window, const flo
                                   int64_t M, advstep_stream_t stream) {
     STFT_REQUIRE(B >= 0 && NF >= 0 && M >= 0 && span >= 1 && span_t >= 1);
     if (B == 0 || T == 0) return ADVSTEP_OK;
-    STFT_REQUIRE(x && window && dout && fb_start && fb_w && fbt_start && fbt_w && dx && B <= kMaxGridY && M <= kMelMax);
+    STFT_REQUIRE(x && window && dout && fb_start && fb_w && fbt_start && fbt_w && dx && B <= kMaxGridY && M <= kMelMax &&
+                 span <= kMelMaxSpan && span_t <= kMaxSpanT);
     STFT_REQUIRE(advstep_stft_bands_supported(nfft, hop, T) && NF == 1 + T / hop);
     STFT_REQUIRE(kFramesPerBlockBwd * hop >= kNfft - hop);
     hipStream_t st = as_stream(stream);
     ensure_twiddles(st);
     if (hipMemsetAsync(dx, 0, (size_t)B * T * sizeof(float), st) != hipSuccess) return ADVSTEP_ELAUNCH;
     const size_t lds = sizeof(LdsMelBwd);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(stft_mel_backward_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(stft_mel_backward_kernel, dim3((unsigned)ceil_div(NF, kFramesPerBlockBwd), (unsigned)B), dim3(kThreads),
-                       lds, st, x, window, dout, fb_start, fb_w, (int)span, fbt_start, fbt_w, (int)span_t, dx, (int)T, (int)NF,
-                       (int)hop, (int)M);
+    auto go = [&](auto kernel) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kernel, dim3((unsigned)ceil_div(NF, kFramesPerBlockBwd), (unsigned)B), dim3(kThreads), lds, st, x,
+                           window, dout, fb_start, fb_w, (int)span, fbt_start, fbt_w, (int)span_t, dx, (int)T, (int)NF, (int)hop,
+                           (int)M);
+    };
+    if (span <= 16 && span_t <= 2) go(stft_mel_backward_kernel<16, 2>);
+    else if (span_t <= 2) go(stft_mel_backward_kernel<kMelMaxSpan, 2>);
+    else go(stft_mel_backward_kernel<kMelMaxSpan, kMaxSpanT>);
     return status_after_launch();
 }
 

@@ -289,8 +289,8 @@ class _MelSpecFromWaveform(torch.autograd.Function):
         return dx, None, None, None
 
 
-def mel_spec_supported(nfft: int, hop: int, T: int, n_mels: int) -> bool:
-    return bool(_lib.load().advstep_stft_bands_supported(nfft, hop, T)) and n_mels <= 80
+def mel_spec_supported(nfft: int, hop: int, T: int, n_mels: int, span: int = 1, span_t: int = 1) -> bool:
+    return bool(_lib.load().advstep_stft_bands_supported(nfft, hop, T)) and n_mels <= 80 and span <= 48 and span_t <= 8
 
 
 def mel_spec_from_waveform(x: torch.Tensor, window_nfft: torch.Tensor, hop: int, tables: FilterbankTables) -> torch.Tensor:

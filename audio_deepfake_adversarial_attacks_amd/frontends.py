@@ -263,9 +263,10 @@ class MelSpecFrontend(nn.Module):
     def forward(self, audio: torch.Tensor) -> torch.Tensor:
         if audio.is_cuda and audio.dim() == 2 and audio.dtype == torch.float32 and _fused_mel_enabled():
             from . import frontend_ops
-            if frontend_ops.mel_spec_supported(N_FFT, self.hop_length, audio.shape[1], self.mel_scale.fb.shape[1]):
+            tables, window = self._fused_state(audio.device)
+            if frontend_ops.mel_spec_supported(N_FFT, self.hop_length, audio.shape[1], self.mel_scale.fb.shape[1], tables.span,
+                                               tables.span_t):
                 # framing + FFT + complex mel projection + magnitude / phase in one kernel each way
-                tables, window = self._fused_state(audio.device)
                 return frontend_ops.mel_spec_from_waveform(audio, window, self.hop_length, tables)
         stft = torch.stft(audio, n_fft=N_FFT, return_complex=True, hop_length=self.hop_length,
                           win_length=self.win_length,

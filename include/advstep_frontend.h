@@ -95,7 +95,7 @@ int advstep_stft_bands_backward_f32(const float *x, const float *window, const f
 /* ---- mel-spec frontend (src/frontends.py:53-79) around the same in-LDS FFT --------------------------------------------
  * torch.stft (window 512 = the rectangular 400-sample window centred / zero-padded) -> MelScale applied to the real and
  * the imaginary part -> magnitude and phase:  out (B, 2, M, NF), plane 0 = |Y|, plane 1 = angle(Y),
- * Y[m] = sum_j fb_w[m, j] X[fb_start[m] + j].  M <= 80. */
+ * Y[m] = sum_j fb_w[m, j] X[fb_start[m] + j].  M <= 80, span <= 48 (a lane keeps its bands' taps in registers). */
 int advstep_stft_mel_f32(const float *x, const float *window, const int32_t *fb_start, const float *fb_w, int64_t span,
                          float *out, int64_t B, int64_t T, int64_t NF, int64_t hop, int64_t nfft, int64_t M,
                          advstep_stream_t stream);

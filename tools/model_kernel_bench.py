@@ -179,6 +179,19 @@ def main():
     timeit("stft_bands_backward (fbank^T+FFT+iFFT+OLA)", lambda: lib.advstep_stft_bands_backward_f32(
         wav.data_ptr(), win.data_ptr(), dband.data_ptr(), tables.fbt_start.data_ptr(), tables.fbt_w.data_ptr(), tables.span_t,
         dxx.data_ptr(), B, Tn, NF, 160, 512, M, st), bytes_moved=4.0 * (2 * wav.numel() + dband.numel()))
+    # mel-spec frontend of SpecRNet: STFT -> complex mel projection -> magnitude / phase, and back
+    mel = frontends.MelSpecFrontend().to(dev)
+    mt, mwin = mel._fused_state(torch.device(dev))
+    Mm = mel.mel_scale.fb.shape[1]
+    mout = torch.empty(B, 2, Mm, NF, device=dev)
+    dmel = torch.randn(B, 2, Mm, NF, device=dev)
+    timeit("stft_mel (framing+FFT+mel+abs/angle)", lambda: lib.advstep_stft_mel_f32(
+        wav.data_ptr(), mwin.data_ptr(), mt.fb_start.data_ptr(), mt.fb_w.data_ptr(), mt.span, mout.data_ptr(), B, Tn, NF, 160, 512,
+        Mm, st), bytes_moved=4.0 * (wav.numel() + mout.numel()))
+    timeit("stft_mel_backward", lambda: lib.advstep_stft_mel_backward_f32(
+        wav.data_ptr(), mwin.data_ptr(), dmel.data_ptr(), mt.fb_start.data_ptr(), mt.fb_w.data_ptr(), mt.span, mt.fbt_start.data_ptr(),
+        mt.fbt_w.data_ptr(), mt.span_t, dxx.data_ptr(), B, Tn, NF, 160, 512, Mm, st),
+        bytes_moved=4.0 * (2 * wav.numel() + dmel.numel()))
     if a.json:
         Path(a.json).write_text(json.dumps({"batch": B, "kernels": res}, indent=1))
 
