@@ -46,6 +46,12 @@ def _gemm_conv1d_enabled() -> bool:
     return os.environ.get("ADVSTEP_RAWNET3_GEMM_CONV", "1") != "0"
 
 
+def _inplace_conv1d_enabled() -> bool:
+    """ADVSTEP_RAWNET3_INPLACE_CONV=0 keeps the autograd formulation over a padded copy (A/B measurements); default on."""
+    import os
+    return os.environ.get("ADVSTEP_RAWNET3_INPLACE_CONV", "1") != "0"
+
+
 def _fused_elem_enabled() -> bool:
     import os
     return os.environ.get("ADVSTEP_RAWNET3_ELEM", "1") != "0"
@@ -77,18 +83,70 @@ def _add_pool(a: torch.Tensor, b, pool: nn.MaxPool1d) -> torch.Tensor:
     return pool(a if b is None else a + b)
 
 
+def _tap_ranges(k: int, d: int, T: int):
+    """(tap j, output range, input range) of a "same" dilated convolution: y[t] += W_j x[t + (j - k//2) d] where both exist."""
+    for j in range(k):
+        o = (j - k // 2) * d
+        if abs(o) >= T:
+            continue
+        yield (j, slice(0, T), slice(0, T)) if o == 0 else ((j, slice(-o, T), slice(0, T + o)) if o < 0 else
+                                                            (j, slice(0, T - o), slice(o, T)))
+
+
+class _SameConv1dFrozen(torch.autograd.Function):
+    """The dilated "same" Conv1d as k GEMMs that accumulate IN PLACE into sub-ranges of one output buffer — no zero-padded
+    copy of the input — and the same for its input gradient (the transposed taps into sub-ranges of one gradient buffer).
+    Differentiable w.r.t. the input only: built for the attack loop, where the weights are frozen.  Through autograd the
+    shifted views of a padded input cost, per convolution and direction, a pad / slice copy plus (backward) three zero-filled
+    full-size buffers, three slice copies and two adds around the three GEMMs: 10 ms of an 81 ms iteration at B = 64."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, d):
+        B, _, T = x.shape
+        k = weight.shape[-1]
+        y = None
+        for j, ys, xs in sorted(_tap_ranges(k, d, T), key=lambda r: r[0] != k // 2):      # the full-range (centre) tap first
+            wj = weight[:, :, j].unsqueeze(0).expand(B, -1, -1)
+            if y is None:
+                y = torch.bmm(wj, x[:, :, xs]) if bias is None else torch.baddbmm(bias.view(1, -1, 1), wj, x[:, :, xs])
+            else:
+                y[:, :, ys].baddbmm_(wj, x[:, :, xs])
+        ctx.save_for_backward(weight)
+        ctx.d = d
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (weight,) = ctx.saved_tensors
+        B, _, T = g.shape
+        k, d = weight.shape[-1], ctx.d
+        gx = None
+        for j, ys, xs in sorted(_tap_ranges(k, d, T), key=lambda r: r[0] != k // 2):
+            wjt = weight[:, :, j].t().unsqueeze(0).expand(B, -1, -1)
+            if gx is None:
+                gx = torch.bmm(wjt, g[:, :, ys])
+            else:
+                gx[:, :, xs].baddbmm_(wjt, g[:, :, ys])
+        return gx, None, None, None
+
+
 def _same_conv1d(x: torch.Tensor, conv: nn.Conv1d, with_bias: bool = True) -> torch.Tensor:
     """`conv(x)` for the dilated "same" Conv1d(width, width, 3, dilation=d, padding=d) of the Res2Net branches.
 
     On a HIP device MIOpen (no tuned solver for these 128-channel dilated 1-D convolutions) runs them with its NAIVE
     reference kernel — 5.9 ms each, 22 per forward: 130 ms of a 190 ms RawNet3 iteration at B = 64.  The same arithmetic
-    as k GEMMs over shifted views of the padded input, W[:, :, j] (Cout x Cin) . x[:, :, t + j d], goes to rocBLAS /
-    hipBLASLt instead (autograd included).  CPU tensors and any other geometry take the module itself."""
+    as k GEMMs over shifted ranges, W[:, :, j] (Cout x Cin) . x[:, :, t + (j - k//2) d], goes to rocBLAS / hipBLASLt instead:
+    with frozen parameters (an attack is running) through `_SameConv1dFrozen` (in-place accumulation, no padded copy,
+    hand-written input gradient), otherwise as baddbmm over views of the padded input with autograd.  CPU tensors and any
+    other geometry take the module itself."""
     k, d = conv.kernel_size[0], conv.dilation[0]
     bias = conv.bias if with_bias else None
     if not (x.is_cuda and _gemm_conv1d_enabled() and conv.stride == (1,) and conv.groups == 1 and k % 2 == 1 and k > 1
             and conv.padding == ((k // 2) * d,) and conv.padding_mode == "zeros"):
         return F.conv1d(x, conv.weight, bias, conv.stride, conv.padding, conv.dilation, conv.groups)
+    frozen = not (torch.is_grad_enabled() and (conv.weight.requires_grad or (bias is not None and bias.requires_grad)))
+    if frozen and x.dtype == torch.float32 and x.shape[-1] > (k // 2) * d and _inplace_conv1d_enabled():
+        return _SameConv1dFrozen.apply(x, conv.weight.detach(), None if bias is None else bias.detach(), d)
     T = x.shape[-1]
     xp = torch.nn.functional.pad(x, ((k // 2) * d, (k // 2) * d))
     B = x.shape[0]

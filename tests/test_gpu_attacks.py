@@ -288,3 +288,47 @@ def test_rawnet3_gemm_convolutions_match_miopen(cuda, monkeypatch):
     z1, g1 = run(True)
     assert (z0 - z1).abs().max().item() <= 1e-4 * max(z0.abs().max().item(), 1.0)
     assert (g0 - g1).norm().item() <= 1e-3 * g0.norm().item()
+
+
+def test_rawnet3_inplace_gemm_convolution_with_frozen_weights(cuda, monkeypatch):
+    """With frozen parameters the dilated convolutions accumulate their taps in place into sub-ranges of one buffer and
+    have a hand-written input gradient (models/rawnet3.py:_SameConv1dFrozen): the operator against F.conv1d (strided
+    input view included), and the whole detector against the autograd formulation and against MIOpen."""
+    import torch.nn.functional as F
+    from audio_deepfake_adversarial_attacks_amd.models import rawnet3 as R
+    from audio_deepfake_adversarial_attacks_amd.models.models import get_model
+    gen = torch.Generator().manual_seed(5)
+    for C, k, d, T in [(128, 3, 2, 6435), (128, 3, 4, 429), (16, 5, 3, 50), (8, 3, 4, 5)]:
+        w = (torch.randn(C, C, k, generator=gen) * 0.05).to(cuda)
+        b = torch.randn(C, generator=gen).to(cuda)
+        big = torch.randn(2, 2 * C, T, generator=gen).to(cuda)
+        xv = big[:, C:].detach().requires_grad_(True)                      # a channel slice: batch stride 2 C T
+        y = R._SameConv1dFrozen.apply(xv, w, b, d)
+        ref_in = big[:, C:].detach().double().requires_grad_(True)
+        ref = F.conv1d(ref_in, w.double(), b.double(), 1, (k // 2) * d, d)
+        g = torch.randn(y.shape, generator=gen).to(cuda)
+        (gx,) = torch.autograd.grad(y, xv, g)
+        (gref,) = torch.autograd.grad(ref, ref_in, g.double())
+        assert (y.double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+        assert (gx.double() - gref).abs().max().item() <= 2e-5 * gref.abs().max().item()
+
+    torch.manual_seed(2)
+    model = get_model("rawnet3", {}, str(cuda)).to(cuda).eval()
+    for p in model.parameters():
+        p.requires_grad_(False)
+    x = (torch.randn(2, 64_600, generator=torch.Generator().manual_seed(3)) * 0.05).to(cuda)
+
+    def run(gemm, inplace):
+        monkeypatch.setenv("ADVSTEP_RAWNET3_GEMM_CONV", "1" if gemm else "0")
+        monkeypatch.setenv("ADVSTEP_RAWNET3_INPLACE_CONV", "1" if inplace else "0")
+        a = x.clone().requires_grad_(True)
+        z = model(a)
+        (gr,) = torch.autograd.grad(z.sum(), a)
+        return z.detach(), gr
+
+    z_mi, g_mi = run(False, False)
+    z_ag, g_ag = run(True, False)
+    z_ip, g_ip = run(True, True)
+    for z, gr in ((z_ag, g_ag), (z_ip, g_ip)):
+        assert (z_mi - z).abs().max().item() <= 1e-4 * max(z_mi.abs().max().item(), 1.0)
+        assert (g_mi - gr).norm().item() <= 1e-3 * g_mi.norm().item()
