@@ -73,6 +73,25 @@ def resconv(B):
               flush=True)
 
 
+def direct(B):
+    """block0's 2-channel ends on the vector ALUs (csrc/detector_conv.hip)."""
+    from audio_deepfake_adversarial_attacks_amd import detector_ops as D
+    dev, H, W = "cuda", 80, 404
+    x = torch.randn(B, 2, H, W, device=dev)
+    w = torch.randn(20, 2, 3, 3, device=dev) * 0.1
+    shift = torch.randn(20, device=dev)
+    t = timed(lambda: D.conv3x3_fewin(x, w, shift, 0.3))
+    print(f"direct  block0 conv1 (2 -> 20) + shift + lrelu                {t:7.1f} us ({(2 + 20) * B * H * W * 4 / t / 1e3:6.0f} GB/s)", flush=True)
+    g1 = torch.randn(B, 20, H, W, device=dev)
+    full = torch.randn(B, 20, H, W, device=dev)
+    gp = torch.randn(B, 20, H // 2, W // 2, device=dev)
+    _, sel = D._add_maxpool2_raw(full, None, None)
+    wd = torch.randn(20, 2, device=dev)
+    t = timed(lambda: D.conv3x3_fewout_grad(g1, w, gp, sel, wd))
+    print(f"direct  block0 conv1^T + down^T (20 + pooled 20 -> 2)          {t:7.1f} us ({(20 + 5.25 + 2) * B * H * W * 4 / t / 1e3:6.0f} GB/s)", flush=True)
+
+
 if __name__ == "__main__":
     main()
     resconv(int(sys.argv[1]) if len(sys.argv) > 1 else 128)
+    direct(int(sys.argv[1]) if len(sys.argv) > 1 else 128)
