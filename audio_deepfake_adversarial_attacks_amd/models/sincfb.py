@@ -60,6 +60,42 @@ class ParamSincFB(nn.Module):
         return torch.cat([self._band_pass(low, high, odd=False), self._band_pass(low, high, odd=True)], dim=0)
 
 
+def _gemm_encoder_enabled() -> bool:
+    """ADVSTEP_RAWNET3_SINC_GEMM=0 keeps F.conv1d for the encoder on HIP devices (A/B measurements); default on."""
+    import os
+    return os.environ.get("ADVSTEP_RAWNET3_SINC_GEMM", "1") != "0"
+
+
+class _StridedCorrelationFrozen(torch.autograd.Function):
+    """conv1d(x (B, 1, T), w (F, 1, K), stride) as ONE batched GEMM over an explicit (B, K, frames) patch matrix, and its input
+    gradient as the transposed GEMM + `fold`.  Input gradient only (the filterbank is frozen while an attack runs).
+
+    Why: MIOpen runs this one-input-channel, 251-tap, stride-10 convolution sample by sample — im2col + a 256 x 251 x 6435 GEMM
+    per utterance forward, GEMM + col2im per utterance backward: 256 launches and 5.4 ms of a 72 ms RawNet3 iteration at B = 64.
+    Batched, the same arithmetic is a 413 MB patch copy + one 53-GFLOP GEMM each way."""
+
+    @staticmethod
+    def forward(ctx, x, w, stride):
+        B, _, T = x.shape
+        nf, _, K = w.shape
+        cols = x[:, 0].unfold(-1, K, stride).transpose(1, 2).contiguous()          # (B, K, frames)
+        ctx.save_for_backward(w)
+        ctx.meta = (T, K, stride)
+        return torch.matmul(w[:, 0], cols)                                        # (F, K) @ (B, K, frames) -> (B, F, frames)
+
+    @staticmethod
+    def backward(ctx, g):
+        (w,) = ctx.saved_tensors
+        T, K, stride = ctx.meta
+        gcols = torch.matmul(w[:, 0].t(), g)                                      # (B, K, frames)
+        frames = g.shape[-1]
+        span = (frames - 1) * stride + K                                          # samples the frames cover (<= T)
+        gx = F.fold(gcols, output_size=(1, span), kernel_size=(1, K), stride=(1, stride)).view(g.shape[0], 1, span)
+        if span < T:
+            gx = F.pad(gx, (0, T - span))
+        return gx, None, None
+
+
 class Encoder(nn.Module):
     """(B, T) or (B, 1, T) -> (B, n_filters, frames): strided correlation with the filterbank, no padding."""
 
@@ -67,7 +103,22 @@ class Encoder(nn.Module):
         super().__init__()
         self.filterbank = filterbank
 
+    def _frozen_filters(self):
+        """The filterbank evaluated once per parameter version (≈ 40 small kernels per call otherwise)."""
+        fb = self.filterbank
+        tensors = [fb.low_hz_, fb.band_hz_, fb.window_, fb.n_]
+        key = tuple((t.data_ptr(), t._version) for t in tensors)
+        if getattr(self, "_filters_key", None) != key:
+            with torch.no_grad():
+                self._filters_key, self._filters_val = key, fb.filters().contiguous()
+        return self._filters_val
+
     def forward(self, waveform):
         if waveform.ndim == 2:
             waveform = waveform.unsqueeze(1)
-        return F.conv1d(waveform, self.filterbank.filters(), stride=self.filterbank.stride, padding=0)
+        fb = self.filterbank
+        frozen = not (torch.is_grad_enabled() and (fb.low_hz_.requires_grad or fb.band_hz_.requires_grad))
+        if (frozen and waveform.is_cuda and waveform.dtype == torch.float32 and waveform.shape[1] == 1
+                and waveform.shape[-1] >= fb.kernel_size and _gemm_encoder_enabled()):
+            return _StridedCorrelationFrozen.apply(waveform, self._frozen_filters(), fb.stride)
+        return F.conv1d(waveform, fb.filters(), stride=fb.stride, padding=0)

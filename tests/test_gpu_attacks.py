@@ -318,17 +318,62 @@ def test_rawnet3_inplace_gemm_convolution_with_frozen_weights(cuda, monkeypatch)
         p.requires_grad_(False)
     x = (torch.randn(2, 64_600, generator=torch.Generator().manual_seed(3)) * 0.05).to(cuda)
 
-    def run(gemm, inplace):
+    def run(gemm, inplace, encoder_default=False, elem="1"):
         monkeypatch.setenv("ADVSTEP_RAWNET3_GEMM_CONV", "1" if gemm else "0")
         monkeypatch.setenv("ADVSTEP_RAWNET3_INPLACE_CONV", "1" if inplace else "0")
+        monkeypatch.setenv("ADVSTEP_RAWNET3_SINC_GEMM", "1" if encoder_default else "0")
+        monkeypatch.setenv("ADVSTEP_RAWNET3_PREEMPH", "1" if encoder_default else "0")
+        monkeypatch.setenv("ADVSTEP_RAWNET3_ELEM", elem)
         a = x.clone().requires_grad_(True)
         z = model(a)
         (gr,) = torch.autograd.grad(z.sum(), a)
         return z.detach(), gr
 
-    z_mi, g_mi = run(False, False)
-    z_ag, g_ag = run(True, False)
-    z_ip, g_ip = run(True, True)
-    for z, gr in ((z_ag, g_ag), (z_ip, g_ip)):
+    z_mi, g_mi = run(False, False, elem="0")                 # MIOpen convolutions, plain torch modules
+    # same pre-emphasis and encoder kernels (bit-identical encoder output): the detector body's variants, compared tightly
+    for z, gr in (run(True, False), run(True, True)):
         assert (z_mi - z).abs().max().item() <= 1e-4 * max(z_mi.abs().max().item(), 1.0)
         assert (g_mi - gr).norm().item() <= 1e-3 * g_mi.norm().item()
+    # the default: pre-emphasis as elementwise arithmetic and the sinc encoder as one batched GEMM each way.  Their outputs
+    # differ from MIOpen's in the last bits, and the waveform gradient passes through d log(|y| + 1e-6) / dy = 1 / (|y| + 1e-6)
+    # of the encoder output y: where y is at rounding level that factor is up to 1e6 and follows y's last bits (for ANY two
+    # convolution implementations), and those entries dominate the gradient's norm.  So: logits tightly, the gradient by a
+    # robust statistic; the two operators themselves are pinned against float64 in the next test.
+    z, gr = run(True, True, encoder_default=True)
+    assert (z_mi - z).abs().max().item() <= 1e-4 * max(z_mi.abs().max().item(), 1.0)
+    rel = (g_mi - gr).abs() / g_mi.abs().clamp_min(1e-12)
+    assert rel.median().item() <= 0.05
+
+
+def test_sinc_encoder_as_batched_gemm_and_elementwise_preemphasis(cuda, monkeypatch):
+    """models/sincfb.py:_StridedCorrelationFrozen against F.conv1d (values and input gradient, odd sizes included), and
+    RawNet3's two-tap PreEmphasis as elementwise arithmetic against its convolution."""
+    import torch.nn.functional as F
+    from audio_deepfake_adversarial_attacks_amd.models import rawnet3 as R
+    from audio_deepfake_adversarial_attacks_amd.models import sincfb
+    gen = torch.Generator().manual_seed(9)
+    for B, T, nf, K, st in [(3, 64_600, 256, 251, 10), (2, 251, 4, 251, 10), (2, 1_003, 6, 31, 7), (1, 5_000, 16, 251, 10)]:
+        x = torch.randn(B, 1, T, generator=gen).to(cuda).requires_grad_(True)
+        w = (torch.randn(nf, 1, K, generator=gen) * 0.1).to(cuda)
+        y = sincfb._StridedCorrelationFrozen.apply(x, w, st)
+        xr = x.detach().double().requires_grad_(True)
+        ref = F.conv1d(xr, w.double(), stride=st)
+        g = torch.randn(y.shape, generator=gen).to(cuda)
+        (gx,) = torch.autograd.grad(y, x, g)
+        (gref,) = torch.autograd.grad(ref, xr, g.double())
+        assert y.shape == ref.shape
+        assert (y.double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+        assert (gx.double() - gref).abs().max().item() <= 2e-5 * gref.abs().max().item()
+    pe = R.PreEmphasis().to(cuda)
+    x = torch.randn(4, 64_600, generator=gen).to(cuda)
+    monkeypatch.setenv("ADVSTEP_RAWNET3_PREEMPH", "0")
+    a = x.clone().requires_grad_(True)
+    y0 = pe(a)
+    (g0,) = torch.autograd.grad(y0.sum() + (y0 * y0).sum(), a)
+    monkeypatch.setenv("ADVSTEP_RAWNET3_PREEMPH", "1")
+    b = x.clone().requires_grad_(True)
+    y1 = pe(b)
+    (g1,) = torch.autograd.grad(y1.sum() + (y1 * y1).sum(), b)
+    assert y1.shape == y0.shape
+    assert (y0 - y1).abs().max().item() <= 1e-6 * y0.abs().max().item()
+    assert (g0 - g1).abs().max().item() <= 1e-5 * g0.abs().max().item()
