@@ -129,6 +129,110 @@ int launch_affine(const float *gy, const float *x, const float *scale, const flo
     return status_after_launch();
 }
 
+// ---- one link of RawNet3's Res2Net chain (src/models/rawnet3.py:244-258) ------------------------------------------------
+// forward : y = relu(h + pre[c]) * scale[c] + shift[c]  (the branch's `bn(relu(conv(.)))`), written into its channel slice of
+//           the concatenated tensor (batch stride y_bs), and z = y + other  — the NEXT branch's input `sp + spx[i + 1]`
+//           (other = the next group, a channel slice with batch stride o_bs) — in the same pass.
+// backward: gx = (h + pre <= 0) ? 0 : (g1 + g2) * scale  where g1 is the slice of d(concatenated) (batch stride g1_bs) and
+//           g2 the gradient arriving from the next branch's input (batch stride g2_bs); either extra operand may be absent.
+// h, z and gx are contiguous (N, C, P).  Plane (n, c) of a strided operand starts at n * bs + c * P; with every batch stride a
+// multiple of 4 and 16-byte aligned bases all operands of a plane share one alignment phase ((c * P) & 3), so the scalar head /
+// float4 body / scalar tail split of affine_act_kernel applies (VEC); otherwise element by element.
+template <bool BWD, bool VEC>
+__global__ __launch_bounds__(kBlock) void res2net_link_kernel(const float *__restrict__ h, const float *__restrict__ a,
+                                                              int64_t a_bs, const float *__restrict__ b, int64_t b_bs,
+                                                              const float *__restrict__ scale, const float *__restrict__ shift,
+                                                              const float *__restrict__ pre, float *__restrict__ o1,
+                                                              int64_t o1_bs, float *__restrict__ o2, int64_t C, int64_t P) {
+    // FWD: a = other (may be null), b unused; o1 = y (strided), o2 = z (contiguous, null when a is null)
+    // BWD: a = g1 (strided), b = g2 (may be null); o1 = gx (contiguous: o1_bs = C * P), o2 unused
+    const int64_t nc = blockIdx.x, n = nc / C;
+    const int c = (int)(nc - n * C);
+    const float s = scale[c], t = shift[c], pr = pre ? pre[c] : 0.0f;
+    const float *hp = h + nc * P;
+    const float *ap = a ? a + n * a_bs + (int64_t)c * P : nullptr;
+    const float *bp = (BWD && b) ? b + n * b_bs + (int64_t)c * P : nullptr;
+    float *o1p = o1 + n * o1_bs + (int64_t)c * P;
+    float *o2p = (!BWD && o2) ? o2 + nc * P : nullptr;
+    auto one = [&](int64_t i) {
+        if (BWD) {
+            const float g = ap[i] + (bp ? bp[i] : 0.0f);
+            o1p[i] = act_bwd<1>(g, hp[i], s, t, pr, 0.0f);
+        } else {
+            const float y = act_fwd<1>(hp[i], s, t, pr, 0.0f);
+            o1p[i] = y;
+            if (o2p) o2p[i] = y + ap[i];
+        }
+    };
+    if (VEC) {
+        int64_t head = (4 - (((int64_t)c * P) & 3)) & 3;
+        if (head > P) head = P;
+        const int64_t G = (P - head) / 4, tail0 = head + 4 * G;
+        const int64_t g0 = (int64_t)blockIdx.y * (kBlock * kVecPerThread) + threadIdx.x;
+        float4 hv[kVecPerThread], av[kVecPerThread], bv[kVecPerThread];
+#pragma unroll
+        for (int k = 0; k < kVecPerThread; ++k) {
+            const int64_t g = g0 + (int64_t)k * kBlock;
+            if (g < G) {
+                hv[k] = reinterpret_cast<const float4 *>(hp + head)[g];
+                av[k] = ap ? reinterpret_cast<const float4 *>(ap + head)[g] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                bv[k] = bp ? reinterpret_cast<const float4 *>(bp + head)[g] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kVecPerThread; ++k) {
+            const int64_t g = g0 + (int64_t)k * kBlock;
+            if (g < G) {
+                float4 r;
+                if (BWD) {
+                    r.x = act_bwd<1>(av[k].x + bv[k].x, hv[k].x, s, t, pr, 0.0f);
+                    r.y = act_bwd<1>(av[k].y + bv[k].y, hv[k].y, s, t, pr, 0.0f);
+                    r.z = act_bwd<1>(av[k].z + bv[k].z, hv[k].z, s, t, pr, 0.0f);
+                    r.w = act_bwd<1>(av[k].w + bv[k].w, hv[k].w, s, t, pr, 0.0f);
+                    reinterpret_cast<float4 *>(o1p + head)[g] = r;
+                } else {
+                    r.x = act_fwd<1>(hv[k].x, s, t, pr, 0.0f);
+                    r.y = act_fwd<1>(hv[k].y, s, t, pr, 0.0f);
+                    r.z = act_fwd<1>(hv[k].z, s, t, pr, 0.0f);
+                    r.w = act_fwd<1>(hv[k].w, s, t, pr, 0.0f);
+                    reinterpret_cast<float4 *>(o1p + head)[g] = r;
+                    if (o2p)
+                        reinterpret_cast<float4 *>(o2p + head)[g] =
+                            make_float4(r.x + av[k].x, r.y + av[k].y, r.z + av[k].z, r.w + av[k].w);
+                }
+            }
+        }
+        if (blockIdx.y == 0 && threadIdx.x < 8) {
+            const int64_t i = threadIdx.x < 4 ? (int64_t)threadIdx.x : tail0 + threadIdx.x - 4;
+            if (threadIdx.x < 4 ? i < head : i < P) one(i);
+        }
+    } else {
+        const int64_t i0 = ((int64_t)blockIdx.y * (kBlock * kVecPerThread) + threadIdx.x) * 4;
+#pragma unroll
+        for (int k = 0; k < kVecPerThread; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int64_t i = i0 + (int64_t)k * kBlock * 4 + e;
+                if (i < P) one(i);
+            }
+    }
+}
+
+template <bool BWD>
+int launch_link(const float *h, const float *a, int64_t a_bs, const float *b, int64_t b_bs, const float *scale, const float *shift,
+                const float *pre, float *o1, int64_t o1_bs, float *o2, int64_t N, int64_t C, int64_t P, hipStream_t st) {
+    const int64_t tiles = ceil_div(ceil_div(P, 4), kBlock * kVecPerThread);
+    if (N * C > 0x7fffffffLL || tiles > 65535) return ADVSTEP_EINVAL;
+    const bool vec = aligned16(h) && aligned16(o1) && (!a || (aligned16(a) && a_bs % 4 == 0)) && (!b || (aligned16(b) && b_bs % 4 == 0)) &&
+                     o1_bs % 4 == 0 && (!o2 || aligned16(o2)) && (C * P) % 4 == 0;
+    const dim3 grid((unsigned)(N * C), (unsigned)tiles), block(kBlock);
+    if (vec)
+        hipLaunchKernelGGL((res2net_link_kernel<BWD, true>), grid, block, 0, st, h, a, a_bs, b, b_bs, scale, shift, pre, o1, o1_bs, o2, C, P);
+    else
+        hipLaunchKernelGGL((res2net_link_kernel<BWD, false>), grid, block, 0, st, h, a, a_bs, b, b_bs, scale, shift, pre, o1, o1_bs, o2, C, P);
+    return status_after_launch();
+}
+
 // ---- 2x2 max pooling family: thread = 2 horizontally adjacent pooled outputs -------------------------------------------
 // at::native::max_pool_forward_nchw: scan the window row-major, take val when (val > max) || isnan(val); start max = -inf.
 __device__ __forceinline__ float pool4(float v00, float v01, float v10, float v11, int &code) {
@@ -293,6 +397,24 @@ int advstep_affine_act_backward_f32(const float *gy, const float *x, const float
                                     const float *pre, float *gx, int64_t N, int64_t C, int64_t P, int mode, float slope,
                                     advstep_stream_t stream) {
     return launch_affine<true>(gy, x, scale, shift, pre, gx, N, C, P, mode, slope, as_stream(stream));
+}
+
+int advstep_res2net_link_forward_f32(const float *h, const float *scale, const float *shift, const float *pre, float *y,
+                                     int64_t y_bs, const float *other, int64_t other_bs, float *z, int64_t N, int64_t C, int64_t P,
+                                     advstep_stream_t stream) {
+    if (N < 0 || C < 0 || P < 0 || y_bs < C * P || (other && other_bs < C * P)) return ADVSTEP_EINVAL;
+    if (N * C * P == 0) return ADVSTEP_OK;
+    if (!h || !scale || !shift || !y || ((other != nullptr) != (z != nullptr))) return ADVSTEP_EINVAL;
+    return launch_link<false>(h, other, other_bs, nullptr, 0, scale, shift, pre, y, y_bs, z, N, C, P, as_stream(stream));
+}
+
+int advstep_res2net_link_backward_f32(const float *g1, int64_t g1_bs, const float *g2, int64_t g2_bs, const float *h,
+                                      const float *scale, const float *shift, const float *pre, float *gx, int64_t N, int64_t C,
+                                      int64_t P, advstep_stream_t stream) {
+    if (N < 0 || C < 0 || P < 0 || g1_bs < C * P || (g2 && g2_bs < C * P)) return ADVSTEP_EINVAL;
+    if (N * C * P == 0) return ADVSTEP_OK;
+    if (!g1 || !h || !scale || !shift || !gx) return ADVSTEP_EINVAL;
+    return launch_link<true>(h, g1, g1_bs, g2, g2_bs, scale, shift, pre, gx, C * P, nullptr, N, C, P, as_stream(stream));
 }
 
 int advstep_add_maxpool2_forward_f32(const float *a, const float *b, const float *bias, float *y, uint8_t *sel, int64_t N,

@@ -124,6 +124,50 @@ def add_maxpool2(a: torch.Tensor, b: Optional[torch.Tensor] = None, bias: Option
     return _AddMaxPool2.apply(a.contiguous(), None if b is None else b.contiguous(), bias)
 
 
+def _plane_view(t: torch.Tensor, name: str) -> int:
+    """Batch stride (elements) of a (N, C, P) float32 HIP tensor whose (c, p) planes are dense: a contiguous tensor or a
+    channel slice of one."""
+    _require_strided(t, name)
+    if t.dim() != 3 or t.stride(2) != 1 or t.stride(1) != t.shape[2] or t.stride(0) < t.shape[1] * t.shape[2]:
+        raise ValueError(f"{name}: expected a (N, C, P) tensor or a channel slice of one, got strides {t.stride()}")
+    return t.stride(0)
+
+
+def _require_strided(t: torch.Tensor, name: str) -> None:
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32):
+        raise _lib.AdvstepError(f"{name}: needs a float32 tensor on a HIP device (no CPU fallback)")
+
+
+def res2net_link_forward(h: torch.Tensor, scale, shift, pre, y: torch.Tensor, other: Optional[torch.Tensor],
+                         z: Optional[torch.Tensor]) -> None:
+    """y[...] = relu(h + pre[c]) * scale[c] + shift[c] (y: a channel slice of the concatenated tensor); z = y + other when
+    `other` (the next group, a channel slice) is given.  In place on y / z — no autograd (building block)."""
+    _require(h, "h")
+    N, C, P = h.shape
+    y_bs = _plane_view(y, "y")
+    o_bs = _plane_view(other, "other") if other is not None else 0
+    if z is not None:
+        _require(z, "z")
+    st = _lib.load().advstep_res2net_link_forward_f32(h.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                                      None if pre is None else pre.data_ptr(), y.data_ptr(), y_bs,
+                                                      None if other is None else other.data_ptr(), o_bs,
+                                                      None if z is None else z.data_ptr(), N, C, P, _stream(h.device))
+    _lib.check(st, "advstep_res2net_link_forward_f32")
+
+
+def res2net_link_backward(g1: torch.Tensor, g2: Optional[torch.Tensor], h: torch.Tensor, scale, shift, pre) -> torch.Tensor:
+    """(h + pre <= 0) ? 0 : (g1 + g2) * scale  -> contiguous (N, C, P); g1 / g2 may be channel slices; g2 optional."""
+    _require(h, "h")
+    N, C, P = h.shape
+    gx = torch.empty_like(h)
+    st = _lib.load().advstep_res2net_link_backward_f32(g1.data_ptr(), _plane_view(g1, "g1"), None if g2 is None else g2.data_ptr(),
+                                                       _plane_view(g2, "g2") if g2 is not None else 0, h.data_ptr(),
+                                                       scale.data_ptr(), shift.data_ptr(), None if pre is None else pre.data_ptr(),
+                                                       gx.data_ptr(), N, C, P, _stream(h.device))
+    _lib.check(st, "advstep_res2net_link_backward_f32")
+    return gx
+
+
 class _AddMaxPool1d(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b, k):

@@ -64,6 +64,12 @@ def _inplace_conv1d_enabled() -> bool:
     return os.environ.get("ADVSTEP_RAWNET3_INPLACE_CONV", "1") != "0"
 
 
+def _chain_enabled() -> bool:
+    """ADVSTEP_RAWNET3_CHAIN=0 runs the Res2Net branches as separate torch ops (A/B measurements); default on."""
+    import os
+    return os.environ.get("ADVSTEP_RAWNET3_CHAIN", "1") != "0"
+
+
 def _fused_elem_enabled() -> bool:
     import os
     return os.environ.get("ADVSTEP_RAWNET3_ELEM", "1") != "0"
@@ -105,6 +111,28 @@ def _tap_ranges(k: int, d: int, T: int):
                                                             (j, slice(0, T - o), slice(o, T)))
 
 
+def _dilated_gemm(x, weight, bias, d: int, transpose: bool = False, out=None):
+    """The dilated "same" convolution (transpose=False) or its input gradient (transpose=True) as k GEMMs accumulating in
+    place into sub-ranges of ONE buffer — `out` (any (B, C, T) view with unit last stride, e.g. a channel slice) or a new tensor.
+    x may be a channel slice too.  No autograd."""
+    B, _, T = x.shape
+    k = weight.shape[-1]
+    y = None
+    for j, ys, xs in sorted(_tap_ranges(k, d, T), key=lambda r: r[0] != k // 2):      # the full-range (centre) tap first
+        if transpose:
+            ys, xs = xs, ys                                                          # tap j moves gradient from y-range to x-range
+        wj = (weight[:, :, j].t() if transpose else weight[:, :, j]).unsqueeze(0).expand(B, -1, -1)
+        if y is None:
+            if bias is not None:
+                y = torch.baddbmm(bias.view(1, -1, 1), wj, x[:, :, xs], out=out) if out is not None else \
+                    torch.baddbmm(bias.view(1, -1, 1), wj, x[:, :, xs])
+            else:
+                y = torch.bmm(wj, x[:, :, xs], out=out) if out is not None else torch.bmm(wj, x[:, :, xs])
+        else:
+            y[:, :, ys].baddbmm_(wj, x[:, :, xs])
+    return y
+
+
 class _SameConv1dFrozen(torch.autograd.Function):
     """The dilated "same" Conv1d as k GEMMs that accumulate IN PLACE into sub-ranges of one output buffer — no zero-padded
     copy of the input — and the same for its input gradient (the transposed taps into sub-ranges of one gradient buffer).
@@ -114,32 +142,58 @@ class _SameConv1dFrozen(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, d):
-        B, _, T = x.shape
-        k = weight.shape[-1]
-        y = None
-        for j, ys, xs in sorted(_tap_ranges(k, d, T), key=lambda r: r[0] != k // 2):      # the full-range (centre) tap first
-            wj = weight[:, :, j].unsqueeze(0).expand(B, -1, -1)
-            if y is None:
-                y = torch.bmm(wj, x[:, :, xs]) if bias is None else torch.baddbmm(bias.view(1, -1, 1), wj, x[:, :, xs])
-            else:
-                y[:, :, ys].baddbmm_(wj, x[:, :, xs])
         ctx.save_for_backward(weight)
         ctx.d = d
-        return y
+        return _dilated_gemm(x, weight, bias, d)
 
     @staticmethod
     def backward(ctx, g):
         (weight,) = ctx.saved_tensors
-        B, _, T = g.shape
-        k, d = weight.shape[-1], ctx.d
-        gx = None
-        for j, ys, xs in sorted(_tap_ranges(k, d, T), key=lambda r: r[0] != k // 2):
-            wjt = weight[:, :, j].t().unsqueeze(0).expand(B, -1, -1)
-            if gx is None:
-                gx = torch.bmm(wjt, g[:, :, ys])
-            else:
-                gx[:, :, xs].baddbmm_(wjt, g[:, :, ys])
-        return gx, None, None, None
+        return _dilated_gemm(g, weight, None, ctx.d, transpose=True), None, None, None
+
+
+class _Res2NetChain(torch.autograd.Function):
+    """The hierarchical branches of a Bottle2neck (src/models/rawnet3.py:244-258) on the (B, scale * width, T) tensor that leaves
+    conv1 / bn1:   sp_0 = spx[0],  sp_i = piece_{i-1} + spx[i],  piece_i = bns[i](relu(convs[i](sp_i))),
+    out = cat(piece_0 .. piece_{nums-1}, spx[nums])   — input gradient only (parameters frozen).
+    Per branch: the convolution's k GEMMs (`_dilated_gemm`) and ONE elementwise pass each way (`advstep_res2net_link_*`): the
+    activation is written straight into its slice of the concatenated tensor together with the next branch's input, and on
+    the way back the two gradients of a piece are summed inside the activation's backward while the branch's input gradient
+    lands in its slice of d(input) — no `torch.cat`, no strided adds, no gradient-accumulation adds."""
+
+    @staticmethod
+    def forward(ctx, out, plan):
+        from .. import detector_ops as D
+        B, _, T = out.shape
+        w, nums = plan["width"], plan["nums"]
+        cat = torch.empty_like(out)
+        hs, inp = [], out[:, :w]
+        for i in range(nums):
+            h = _dilated_gemm(inp, plan["weight"][i], None, plan["d"])
+            nxt = out[:, (i + 1) * w:(i + 2) * w] if i + 1 < nums else None
+            z = torch.empty((B, w, T), dtype=out.dtype, device=out.device) if nxt is not None else None
+            D.res2net_link_forward(h, plan["scale"][i], plan["shift"][i], plan["bias"][i], cat[:, i * w:(i + 1) * w], nxt, z)
+            hs.append(h)
+            inp = z
+        cat[:, nums * w:].copy_(out[:, nums * w:])
+        ctx.save_for_backward(*hs)
+        ctx.plan = plan
+        return cat
+
+    @staticmethod
+    def backward(ctx, g):
+        from .. import detector_ops as D
+        plan, hs = ctx.plan, ctx.saved_tensors
+        w, nums = plan["width"], plan["nums"]
+        g = g.contiguous()
+        gout = torch.empty_like(g)
+        carry = None
+        for i in reversed(range(nums)):
+            gh = D.res2net_link_backward(g[:, i * w:(i + 1) * w], carry, hs[i], plan["scale"][i], plan["shift"][i], plan["bias"][i])
+            carry = gout[:, i * w:(i + 1) * w]
+            _dilated_gemm(gh, plan["weight"][i], None, plan["d"], transpose=True, out=carry)
+        gout[:, nums * w:].copy_(g[:, nums * w:])
+        return gout, None
 
 
 def _same_conv1d(x: torch.Tensor, conv: nn.Conv1d, with_bias: bool = True) -> torch.Tensor:
@@ -199,6 +253,10 @@ class Bottle2neck(nn.Module):
         residual = self.residual(x)
         out = _conv_relu_bn(x, self.conv1, self.bn1)
 
+        plan = self._chain_plan(out)
+        if plan is not None:
+            out = _Res2NetChain.apply(out.contiguous(), plan)
+            return self._tail(out, residual)
         groups = torch.split(out, self.width, 1)
         pieces, carry = [], None
         for i in range(self.nums):
@@ -208,12 +266,43 @@ class Bottle2neck(nn.Module):
         pieces.append(groups[self.nums])
         out = torch.cat(pieces, 1)
 
+        return self._tail(out, residual)
+
+    def _tail(self, out, residual):
         out = _conv_relu_bn(out, self.conv3, self.bn3)
         if self.mp:
             out = _add_pool(out, residual, self.mp)        # `out += residual` -> MaxPool1d, one pass on a HIP tensor
         else:
             out = out + residual
         return self.afms(out)
+
+    def _chain_plan(self, out):
+        """Frozen, foldable parameters on a HIP tensor: the per-branch constants `_Res2NetChain` needs, cached until a
+        parameter changes; None = run the branches as torch ops."""
+        if not (out.is_cuda and out.dtype == torch.float32 and _fused_elem_enabled() and _gemm_conv1d_enabled()
+                and _inplace_conv1d_enabled() and _chain_enabled()):
+            return None
+        from .. import detector_ops as D
+        convs, bns = list(self.convs), list(self.bns)
+        params = [p for m in convs + bns for p in m.parameters()]
+        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            return None
+        c0 = convs[0]
+        k, d = c0.kernel_size[0], c0.dilation[0]
+        same = all(c.kernel_size == (k,) and c.dilation == (d,) and c.stride == (1,) and c.groups == 1 and c.padding == ((k // 2) * d,)
+                   and c.padding_mode == "zeros" and c.in_channels == c.out_channels == self.width for c in convs)
+        if not (same and k % 2 == 1 and k > 1 and out.shape[-1] > (k // 2) * d and all(D.foldable_bn(b) for b in bns)):
+            return None
+        tensors = params + [b for m in bns for b in m.buffers()]
+        key = tuple((t.data_ptr(), t._version) for t in tensors)
+        if getattr(self, "_chain_key", None) != key:
+            affine = [D.bn_eval_affine(b) for b in bns]
+            self._chain_key = key
+            self._chain_val = {"width": self.width, "nums": self.nums, "d": d,
+                               "weight": [c.weight.detach() for c in convs],
+                               "bias": [None if c.bias is None else c.bias.detach() for c in convs],
+                               "scale": [a[0] for a in affine], "shift": [a[1] for a in affine]}
+        return self._chain_val
 
 
 class RawNet3(nn.Module):

@@ -30,6 +30,23 @@ int advstep_affine_act_backward_f32(const float *gy, const float *x, const float
                                     const float *pre, float *gx, int64_t N, int64_t C, int64_t P, int mode, float slope,
                                     advstep_stream_t stream);
 
+/* ---- one link of RawNet3's Res2Net chain (src/models/rawnet3.py:244-258: `sp = sp + spx[i]; sp = bns[i](relu(convs[i](sp)))`,
+ * `out = cat(out, sp)`) -----------------------------------------------------------------------------------------------------
+ * forward:  y = relu(h + pre[c]) * scale[c] + shift[c] written straight into the branch's channel slice of the concatenated
+ *           tensor (plane (n, c) of y at n * y_bs + c * P), and, when `other` (the next group: plane at n * other_bs + c * P) is
+ *           given, z (N, C, P) = y + other — the next branch's input — in the same pass.  h (N, C, P) = the branch convolution's
+ *           output without its bias (pre = that bias, may be NULL).
+ * backward: gx (N, C, P) = (h + pre <= 0) ? 0 : (g1 + g2) * scale, g1 = the slice of d(concatenated tensor) (batch stride g1_bs),
+ *           g2 = the gradient coming back from the next branch's input (batch stride g2_bs), NULL for the last branch.
+ * Batch strides are in elements and >= C * P.  Replaces, per branch, a strided add, the activation pass, a share of `torch.cat`
+ * and (backward) autograd's gradient-accumulation add. */
+int advstep_res2net_link_forward_f32(const float *h, const float *scale, const float *shift, const float *pre, float *y,
+                                     int64_t y_bs, const float *other, int64_t other_bs, float *z, int64_t N, int64_t C, int64_t P,
+                                     advstep_stream_t stream);
+int advstep_res2net_link_backward_f32(const float *g1, int64_t g1_bs, const float *g2, int64_t g2_bs, const float *h,
+                                      const float *scale, const float *shift, const float *pre, float *gx, int64_t N, int64_t C,
+                                      int64_t P, advstep_stream_t stream);
+
 /* ---- residual add + MaxPool2d(2) --------------------------------------------------------------------------------------
  * y (N, C, H/2, W/2) = MaxPool2d(2)(a + b + bias[c]), sel = one byte per pooled output (bit 1 = dh, bit 0 = dw of the
  * winner; ATen's scan order and NaN rule).  SpecRNet: `mp(out + identity)` (src/models/specrnet.py:83-90) with the two

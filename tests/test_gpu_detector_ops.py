@@ -177,3 +177,64 @@ def test_detectors_with_fused_elementwise_passes_agree_with_plain_modules(cuda, 
     assert fig["grad_rel_l2"] <= 5e-3, fig
     for p in model.parameters():
         p.requires_grad_(True)
+
+
+@pytest.mark.parametrize("N,C,P,Ct", [(2, 128, 6435, 1024), (3, 4, 429, 12), (1, 8, 17, 8), (2, 4, 1287, 12), (2, 3, 5, 7)])
+def test_res2net_link_kernels_match_the_torch_chain(D, cuda, N, C, P, Ct):
+    """advstep_res2net_link_{forward,backward}_f32 on channel slices of (N, Ct, P) tensors against
+    `y = bn(relu(h + bias)); z = y + next_group` and `relu_affine`'s backward of (g1 + g2): same arithmetic, bit for bit;
+    nothing outside the slices is written.  (Ct = 7, P = 5: batch strides not a multiple of 4 -> the element-wise path.)"""
+    h = rnd((N, C, P), 1, cuda)
+    scale, shift, pre = rnd((C,), 2, cuda), rnd((C,), 3, cuda), rnd((C,), 4, cuda)
+    h[0, 0, 0] = -pre[0]                                        # relu at exactly 0
+    lo = C if Ct >= 3 * C else 0                                # the slice under test
+    groups = rnd((N, Ct, P), 5, cuda)
+    other = groups[:, Ct - C:]
+    cat = torch.full((N, Ct, P), 7.0, device=cuda)
+    z = torch.empty((N, C, P), device=cuda)
+    D.res2net_link_forward(h, scale, shift, pre, cat[:, lo:lo + C], other, z)
+    y_ref = torch.relu(h + pre.view(1, -1, 1)) * scale.view(1, -1, 1) + shift.view(1, -1, 1)
+    assert torch.equal(cat[:, lo:lo + C], y_ref) and torch.equal(z, y_ref + other)
+    untouched = torch.ones(Ct, dtype=torch.bool, device=cuda)
+    untouched[lo:lo + C] = False
+    assert (cat[:, untouched] == 7.0).all()
+    cat2 = torch.full((N, Ct, P), 7.0, device=cuda)
+    D.res2net_link_forward(h, scale, shift, None, cat2[:, lo:lo + C], None, None)                 # last branch, no bias
+    assert torch.equal(cat2[:, lo:lo + C], torch.relu(h) * scale.view(1, -1, 1) + shift.view(1, -1, 1))
+
+    g_cat, g_in = rnd((N, Ct, P), 6, cuda), rnd((N, Ct, P), 7, cuda)
+    g1, g2 = g_cat[:, lo:lo + C], g_in[:, Ct - C:]
+    gx = D.res2net_link_backward(g1, g2, h, scale, shift, pre)
+    ref = torch.where((h + pre.view(1, -1, 1)) <= 0, torch.zeros_like(h), (g1 + g2) * scale.view(1, -1, 1))
+    assert torch.equal(gx, ref)
+    gx1 = D.res2net_link_backward(g1, None, h, scale, shift, pre)
+    assert torch.equal(gx1, torch.where((h + pre.view(1, -1, 1)) <= 0, torch.zeros_like(h), (g1 + 0.0) * scale.view(1, -1, 1)))
+    with pytest.raises(ValueError):
+        D.res2net_link_backward(g_cat.transpose(1, 2)[:, :C], None, h, scale, shift, pre)
+
+
+def test_rawnet3_res2net_chain_equals_the_separate_ops(cuda, monkeypatch, parity_record):
+    """Whole RawNet3, frozen: the branches of every Bottle2neck through `_Res2NetChain` (ADVSTEP_RAWNET3_CHAIN=1) against the
+    same kernels launched as separate torch ops with autograd in between.  Same GEMMs and the same elementwise arithmetic:
+    logits and the waveform gradient agree to float rounding (the order of the two-term gradient sums is the same)."""
+    from audio_deepfake_adversarial_attacks_amd.models.models import get_model
+    torch.manual_seed(3)
+    model = attack_mode_frozen(get_model("rawnet3", {}, str(cuda)).to(cuda))
+    x = (torch.randn(2, 64_600, generator=torch.Generator().manual_seed(5)) * 0.05).to(cuda)
+
+    def run(on):
+        monkeypatch.setenv("ADVSTEP_RAWNET3_CHAIN", "1" if on else "0")
+        a = x.clone().requires_grad_(True)
+        z = model(a)
+        (gr,) = torch.autograd.grad(z.sum(), a)
+        return z.detach(), gr
+
+    z0, g0 = run(False)
+    z1, g1 = run(True)
+    assert model.layer1._chain_val["nums"] == 7
+    fig = {"logit_max_abs": (z0 - z1).abs().max().item(), "grad_rel_l2": ((g0 - g1).norm() / g0.norm()).item()}
+    parity_record["rawnet3_res2net_chain_vs_separate_ops"] = fig
+    assert fig["logit_max_abs"] <= 1e-6 * max(z0.abs().max().item(), 1.0), fig
+    assert fig["grad_rel_l2"] <= 1e-5, fig
+    for p in model.parameters():
+        p.requires_grad_(True)
