@@ -116,12 +116,14 @@ def _dilated_gemm(x, weight, bias, d: int, transpose: bool = False, out=None):
     place into sub-ranges of ONE buffer — `out` (any (B, C, T) view with unit last stride, e.g. a channel slice) or a new tensor.
     x may be a channel slice too.  No autograd."""
     B, _, T = x.shape
-    k = weight.shape[-1]
+    taps = weight if isinstance(weight, (list, tuple)) else None      # per-tap (Cout, Cin) matrices, already contiguous
+    k = len(taps) if taps is not None else weight.shape[-1]
     y = None
     for j, ys, xs in sorted(_tap_ranges(k, d, T), key=lambda r: r[0] != k // 2):      # the full-range (centre) tap first
         if transpose:
             ys, xs = xs, ys                                                          # tap j moves gradient from y-range to x-range
-        wj = (weight[:, :, j].t() if transpose else weight[:, :, j]).unsqueeze(0).expand(B, -1, -1)
+        wj = taps[j] if taps is not None else weight[:, :, j]                        # (a (Cout, Cin, k) slice has no unit stride:
+        wj = (wj.t() if transpose else wj).unsqueeze(0).expand(B, -1, -1)            #  bmm copies it, B times, on every call)
         if y is None:
             if bias is not None:
                 y = torch.baddbmm(bias.view(1, -1, 1), wj, x[:, :, xs], out=out) if out is not None else \
@@ -225,6 +227,31 @@ def _same_conv1d(x: torch.Tensor, conv: nn.Conv1d, with_bias: bool = True) -> to
     return out
 
 
+class _PointwiseConv1dFrozen(torch.autograd.Function):
+    """Conv1d(kernel 1) as one batched GEMM each way, input gradient only.  For `layer4` (3072 -> 1536 channels over 429 frames)
+    MIOpen picks a composable-kernel backward-data solver that needs four layout transposes around it (2.8 ms at B = 64)."""
+
+    @staticmethod
+    def forward(ctx, x, w2, bias):
+        ctx.save_for_backward(w2)
+        B = x.shape[0]
+        wb = w2.unsqueeze(0).expand(B, -1, -1)
+        return torch.bmm(wb, x) if bias is None else torch.baddbmm(bias.view(1, -1, 1), wb, x)
+
+    @staticmethod
+    def backward(ctx, g):
+        (w2,) = ctx.saved_tensors
+        return torch.bmm(w2.t().unsqueeze(0).expand(g.shape[0], -1, -1), g), None, None
+
+
+def _pointwise_conv1d(x: torch.Tensor, conv: nn.Conv1d) -> torch.Tensor:
+    frozen = not (torch.is_grad_enabled() and (conv.weight.requires_grad or (conv.bias is not None and conv.bias.requires_grad)))
+    if (frozen and x.is_cuda and x.dtype == torch.float32 and conv.kernel_size == (1,) and conv.stride == (1,)
+            and conv.padding == (0,) and conv.groups == 1 and _gemm_conv1d_enabled() and _inplace_conv1d_enabled()):
+        return _PointwiseConv1dFrozen.apply(x, conv.weight.detach()[:, :, 0], None if conv.bias is None else conv.bias.detach())
+    return conv(x)
+
+
 class Bottle2neck(nn.Module):
     """Res2Net bottleneck over time with hierarchical dilated convs (rawnet3.py:185-274)."""
 
@@ -299,7 +326,7 @@ class Bottle2neck(nn.Module):
             affine = [D.bn_eval_affine(b) for b in bns]
             self._chain_key = key
             self._chain_val = {"width": self.width, "nums": self.nums, "d": d,
-                               "weight": [c.weight.detach() for c in convs],
+                               "weight": [[c.weight.detach()[:, :, j].contiguous() for j in range(k)] for c in convs],
                                "bias": [None if c.bias is None else c.bias.detach() for c in convs],
                                "scale": [a[0] for a in affine], "shift": [a[1] for a in affine]}
         return self._chain_val
@@ -359,7 +386,7 @@ class RawNet3(nn.Module):
         x2 = self.layer2(x1)
         x1p = _add_pool(x1, None, self.mp3)      # the reference evaluates mp3(x1) twice (:96, :102): same values, once here
         x3 = self.layer3(x1p + x2) if self.summed else self.layer3(x2)
-        x = self.relu(self.layer4(torch.cat((x1p, x2, x3), dim=1)))
+        x = self.relu(_pointwise_conv1d(torch.cat((x1p, x2, x3), dim=1), self.layer4))
 
         t = x.size()[-1]
         if self.context:
