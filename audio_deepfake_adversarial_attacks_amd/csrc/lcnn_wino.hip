@@ -268,16 +268,28 @@ __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restri
         // as lane masks, and an invalid tap gets an out-of-range offset (reads 0) when the load is issued
         const uint32_t lane_base = (((uint32_t)(n * KA + g)) * plane + (uint32_t)((2 * th - 1) * W + (2 * tw - 1))) * 4u;
         const uint32_t lane_base2 = (((uint32_t)(n * KB + g)) * plane + (uint32_t)((2 * th - 1) * W + (2 * tw - 1))) * 4u;
-        bool ok[4][4];
+        // SRC 0: a patch row is [column 2 tw - 1 | columns 2 tw, 2 tw + 1 | column 2 tw + 2].  The middle pair is ONE 8-byte load
+        // (the 16 lanes of a lane row hold consecutive tiles: 128 contiguous bytes); the outer columns are the neighbouring
+        // tiles' pairs and come from the neighbouring LANES (DPP row shift) — only the first / last lane of a lane row loads its
+        // outer column itself (one dword load per patch row with 2 of 16 lanes active).  8 load instructions per k-step instead of
+        // 16 with lanes 8 bytes apart: the patch loads, not the matrix pipe, were what a quarter of these kernels' time went to
+        // (halving them — wrong results, timing only — made the L6 / L13 kernels 9-25 % faster).
+        bool row_ok[4], ok_l[4], ok_r[4], ok_2[4], ok_e[4];      // lane masks (scalar registers)
+        uint32_t pair_off[4], edge_off[4];                       // byte offsets from the lane base (GEN) / the tensor base
         uint32_t cell[3][3];     // SRC 1: element offsets of the 3x3 pooled cells around the tile (0x20000000 = outside)
         if (SRC == 0) {
 #pragma unroll
-            for (int p = 0; p < 4; ++p)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int hh = 2 * th - 1 + p, ww = 2 * tw - 1 + q;
-                    ok[p][q] = valid && hh >= 0 && hh < H && ww >= 0 && ww < W;
-                }
+            for (int p = 0; p < 4; ++p) {
+                const int hh = 2 * th - 1 + p;
+                row_ok[p] = valid && hh >= 0 && hh < H;
+                ok_l[p] = row_ok[p] && tw > 0;                   // column 2 tw - 1 exists
+                ok_2[p] = row_ok[p] && 2 * tw + 1 < W;           // second element of the pair exists (odd W: not in the last tile)
+                ok_r[p] = row_ok[p] && 2 * tw + 2 < W;           // column 2 tw + 2 exists
+                ok_e[p] = (nl == 0 && ok_l[p]) || (nl == 15 && ok_r[p]);
+                const uint32_t rel_pair = (uint32_t)((p * W + 1) * 4), rel_edge = (uint32_t)((p * W + (nl == 0 ? 0 : 3)) * 4);
+                pair_off[p] = GEN ? rel_pair : (row_ok[p] ? lane_base + rel_pair : 0x80000000u);
+                edge_off[p] = GEN ? rel_edge : (ok_e[p] ? lane_base + rel_edge : 0x80000000u);
+            }
         } else {
 #pragma unroll
             for (int i = 0; i < 3; ++i)
@@ -292,31 +304,30 @@ __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restri
 
         // a patch in flight: SRC 0 the 16 taps; SRC 1 the 9 pooled gradients + their 9 selection bytes
         struct Patch {
-            float v[SRC == 0 ? 16 : 9];
+            float v[SRC == 0 ? 12 : 9];          // SRC 0: per patch row the pair (2 p, 2 p + 1), then the 4 edge values (8 + p)
             uint32_t code[SRC == 0 ? 1 : 9];
+        };
+        auto load_row = [&](Patch &dst, int p, __amdgpu_buffer_rsrc_t r, uint32_t po, uint32_t eo, uint32_t soff) {
+            const f32x2 pr = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, po, soff, 0));
+            dst.v[2 * p] = pr.x;
+            dst.v[2 * p + 1] = pr.y;
+            dst.v[8 + p] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, eo, soff, 0));
         };
         auto load_patch = [&](Patch &dst, int s) {
             if (SRC == 0 && GEN) {
                 const bool first = 4 * s < ga.K1;                          // wave-uniform: this k-step reads x (else x2)
                 const uint32_t soff = (uint32_t)(first ? 4 * s : 4 * s - ga.K1) * plane * 4u;
-                const uint32_t base = 4 * s + g < ga.Kreal ? (first ? lane_base : lane_base2) : 0x80000000u;
+                const bool lane_ok = 4 * s + g < ga.Kreal;                // padded reduction channels read 0
+                const uint32_t base = first ? lane_base : lane_base2;
                 const __amdgpu_buffer_rsrc_t r = first ? xr : xr2;
 #pragma unroll
                 for (int p = 0; p < 4; ++p)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const uint32_t vo = ok[p][q] ? base + (uint32_t)((p * W + q) * 4) : 0x80000000u;
-                        dst.v[p * 4 + q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, vo, soff, 0));
-                    }
+                    load_row(dst, p, r, (row_ok[p] && lane_ok) ? base + pair_off[p] : 0x80000000u,
+                             (ok_e[p] && lane_ok) ? base + edge_off[p] : 0x80000000u, soff);
             } else if (SRC == 0) {
                 const uint32_t soff = (uint32_t)(4 * s) * plane * 4u;
 #pragma unroll
-                for (int p = 0; p < 4; ++p)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const uint32_t vo = ok[p][q] ? lane_base + (uint32_t)((p * W + q) * 4) : 0x80000000u;
-                        dst.v[p * 4 + q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, vo, soff, 0));
-                    }
+                for (int p = 0; p < 4; ++p) load_row(dst, p, xr, pair_off[p], edge_off[p], soff);
             } else {
                 const int k0 = 4 * s, c0 = SRC == 1 && k0 >= Cs ? k0 - Cs : k0;      // wave-uniform: channel of lane group 0
                 const uint32_t soff = (uint32_t)c0 * cplane;
@@ -333,9 +344,18 @@ __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restri
         auto taps = [&](const Patch &src, int s, float (&d)[4][4]) {
             if (SRC == 0) {
 #pragma unroll
-                for (int p = 0; p < 4; ++p)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) d[p][q] = src.v[p * 4 + q];
+                for (int p = 0; p < 4; ++p) {
+                    const float a = src.v[2 * p], b = src.v[2 * p + 1], e = src.v[8 + p];
+                    // row_shr:1 / row_shl:1 inside the 16-lane row; a lane without a source (the row's first / last) keeps `e`
+                    const float left = __builtin_bit_cast(
+                        float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, e), __builtin_bit_cast(int, b), 0x111, 0xf, 0xf, false));
+                    const float right = __builtin_bit_cast(
+                        float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, e), __builtin_bit_cast(int, a), 0x101, 0xf, 0xf, false));
+                    d[p][0] = ok_l[p] ? left : 0.0f;
+                    d[p][1] = a;
+                    d[p][2] = ok_2[p] ? b : 0.0f;
+                    d[p][3] = ok_r[p] ? right : 0.0f;
+                }
             } else {
                 const uint32_t half_bit = SRC == 1 && 4 * s >= Cs ? 4u : 0u;         // wave-uniform
 #pragma unroll
