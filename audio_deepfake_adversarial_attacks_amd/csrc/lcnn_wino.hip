@@ -213,6 +213,7 @@ struct GenArgs {
     const float *x2;
     int K1, Kreal;
     float slope;
+    int xcd;          // 1: workgroups b, b + 8, b + 16, ... (one XCD, one L2) take the slices of the same tile ranges
 };
 
 template <int EPI, bool STREAM, int SRC, int NT = 2, bool GEN = false>
@@ -226,7 +227,13 @@ __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restri
     static_assert(NT == 2 || EPI == 0 || EPI == 3 || EPI == 5, "one accumulator tile only for the plain-store epilogues");
     static_assert(!GEN || SRC != 1, "the general reduction reads dense tensors or a plain pooled gradient");
     extern __shared__ __attribute__((aligned(16))) float u_s[];
-    const int slice = slice0 + blockIdx.x % slices, range = blockIdx.x / slices;
+    int slice_i = blockIdx.x % slices, range = blockIdx.x / slices;
+    if (ga.xcd) {
+        const int x = blockIdx.x & 7, w = blockIdx.x >> 3;
+        slice_i = w % slices;
+        range = x * (ranges >> 3) + w / slices;
+    }
+    const int slice = slice0 + slice_i;
     const int chunks = (K + kChunkCin - 1) / kChunkCin, steps = K / 4;
     const float *Usl = U + (int64_t)slice * chunks * kChunkFloats;
     auto copy_chunk = [&](int chunk, int buf) {
@@ -604,7 +611,7 @@ inline bool half_slice_enabled() {
 template <int EPI, int SRC, bool GEN = false>
 int launch_wino(const float *x, const uint8_t *xsel, const float *U, const float *bias, const float *bn_mean,
                 const float *bn_invstd, float *y, uint8_t *idx, int64_t N, int64_t K, int64_t H, int64_t W, int64_t Cout,
-                int slices, hipStream_t st, GenArgs ga = GenArgs{nullptr, 0, 0, 1.0f}) {
+                int slices, hipStream_t st, GenArgs ga = GenArgs{nullptr, 0, 0, 1.0f, 0}) {
     const int cus = 256;
     const int chunks = (int)ceil_div(K, kChunkCin);
     const bool stream = chunks > kMaxResident;
@@ -614,6 +621,15 @@ int launch_wino(const float *x, const uint8_t *xsel, const float *U, const float
         int ranges = cus / n_slices;
         if ((int64_t)ranges * kWaves > groups) ranges = (int)ceil_div(groups, kWaves);
         if (ranges < 1) ranges = 1;
+        // the slices of one tile range read the same input tiles at the same time: put them on ONE XCD (workgroups b, b + 8, ...
+        // share an L2) so two of three reads hit it — 1-3 % on the multi-slice layers even where 32 CUs per XCD do not divide
+        // into whole ranges (3 slices: 240 workgroups).  ADVSTEP_WINO_XCD=0 (read per call): round-robin slices (A/B).
+        const char *e = getenv("ADVSTEP_WINO_XCD");
+        ga.xcd = 0;
+        if (!(e && e[0] == '0') && n_slices > 1 && ranges >= 16) {
+            ranges &= ~7;
+            ga.xcd = 1;
+        }
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kernel, dim3((unsigned)(n_slices * ranges)), dim3(kThreads), lds, st, x, xsel, U, bias, bn_mean, bn_invstd,
                            y, idx, (int)N, (int)K, (int)H, (int)W, (int)Cout, n_slices, ranges, slice0, ga);
@@ -767,7 +783,7 @@ int advstep_resconv_forward_f32(const float *x1, const float *x2, const float *U
     if (const int st = resconv_check(x1, x2, U, y, N, K1, K2, rows, H, W)) return st;
     const int64_t K = ceil_div(K1 + K2, 8) * 8;
     return launch_wino<3, 0, true>(x1, nullptr, U, shift, nullptr, nullptr, y, nullptr, N, K, H, W, rows, (int)ceil_div(rows, 32),
-                                   as_stream(stream), GenArgs{x2, (int)K1, (int)(K1 + K2), slope});
+                                   as_stream(stream), GenArgs{x2, (int)K1, (int)(K1 + K2), slope, 0});
 }
 
 int advstep_resconv_pool2_forward_f32(const float *x1, const float *x2, const float *U, const float *bias, float *y,
@@ -779,7 +795,7 @@ int advstep_resconv_pool2_forward_f32(const float *x1, const float *x2, const fl
     if (const int st = resconv_check(x1, x2, U, y, N, K1, K2, rows, H, W)) return st;
     const int64_t K = ceil_div(K1 + K2, 8) * 8;
     return launch_wino<4, 0, true>(x1, nullptr, U, bias, nullptr, nullptr, y, sel, N, K, H, W, rows, (int)ceil_div(rows, 32),
-                                   as_stream(stream), GenArgs{x2, (int)K1, (int)(K1 + K2), 1.0f});
+                                   as_stream(stream), GenArgs{x2, (int)K1, (int)(K1 + K2), 1.0f, 0});
 }
 
 int advstep_resconv_pooled_grad_f32(const float *gy, const uint8_t *sel, const float *U, const float *h, float slope, float *g,
@@ -794,7 +810,7 @@ int advstep_resconv_pooled_grad_f32(const float *gy, const uint8_t *sel, const f
     WINO_REQUIRE((uint64_t)N * K * (H / 2) * (W / 2) < (1ull << 29) && (uint64_t)N * rows * H * W * 4 < (1ull << 33) &&
                  (uint64_t)N * ((H + 1) / 2) * ((W + 1) / 2) < (1ull << 31));
     const int64_t Kp = ceil_div(K, 8) * 8;
-    const GenArgs ga{nullptr, (int)K, (int)K, slope};
+    const GenArgs ga{nullptr, (int)K, (int)K, slope, 0};
     if (h)
         return launch_wino<5, 2, true>(gy, sel, U, nullptr, h, nullptr, g, nullptr, N, Kp, H, W, rows, (int)ceil_div(rows, 32),
                                        as_stream(stream), ga);
