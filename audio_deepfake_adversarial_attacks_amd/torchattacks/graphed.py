@@ -65,7 +65,10 @@ class _Captured:
             two_iterations()
         torch.cuda.current_stream(dev).wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # thread-local capture mode: with N > 1 ranks the RCCL watchdog thread (event queries), and in the CLI the DataLoader's
+        # pinning thread, make HIP calls of their own while this thread captures; in the default "global" mode any such call
+        # invalidates the capture
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             two_iterations()
 
     def run(self, adv, images, labels, target, pairs: int) -> torch.Tensor:
