@@ -379,6 +379,68 @@ __global__ __launch_bounds__(kBlock) void pool1d_backward_kernel(const float *__
         for (int64_t i = Lo * k; i < L; ++i) g[nc * L + i] = 0.0f;
 }
 
+// ---- the tail of a RawNet3 Bottle2neck in one pass each way (src/models/rawnet3.py:262-269) -----------------------------------
+//     out = bn3(relu(conv3(.)));  out += residual;  out = MaxPool1d(k)(out)
+// forward : y = pool_k(relu(h + pre[c]) * scale[c] + shift[c] + res), sel;  the activated tensor is never written.
+// backward: g = unpool(gy, sel);  g_res = g;  g_h = (h + pre <= 0) ? 0 : g * scale   (the activation mask is recomputed from h).
+// A workgroup owns kTailOut pooled outputs of one (n, c) row: their kTailOut * k inputs are read with consecutive lanes on
+// consecutive elements and meet in LDS (window stride k = 3 or 5 is coprime to the 32 banks); the thread-per-window kernels
+// above read lanes 4 k bytes apart (2.8 TB/s on these 1.7 GB tensors).
+constexpr int kTailOut = 448;
+
+__global__ __launch_bounds__(kBlock) void tail_pool1d_forward_kernel(const float *__restrict__ h, const float *__restrict__ res,
+                                                                     const float *__restrict__ scale, const float *__restrict__ shift,
+                                                                     const float *__restrict__ pre, float *__restrict__ y,
+                                                                     uint8_t *__restrict__ sel, int64_t C, int64_t L, int64_t Lo, int k) {
+    __shared__ float v_s[kTailOut * 8];
+    const int64_t nc = blockIdx.x;
+    const int c = (int)(nc % C);
+    const float s = scale[c], t = shift[c], pr = pre ? pre[c] : 0.0f;
+    const int64_t j0 = (int64_t)blockIdx.y * kTailOut;
+    const int outs = (int)((Lo - j0) < kTailOut ? (Lo - j0) : kTailOut), ins = outs * k;
+    const float *hp = h + nc * L + j0 * k, *rp = res + nc * L + j0 * k;
+    for (int i = threadIdx.x; i < ins; i += kBlock) v_s[i] = act_fwd<1>(hp[i], s, t, pr, 0.0f) + rp[i];
+    __syncthreads();
+    for (int j = threadIdx.x; j < outs; j += kBlock) {
+        float best = -INFINITY;
+        int code = 0;
+        for (int e = 0; e < k; ++e) {
+            const float v = v_s[j * k + e];
+            if (v > best || v != v) { best = v; code = e; }
+        }
+        y[nc * Lo + j0 + j] = best;
+        sel[nc * Lo + j0 + j] = (uint8_t)code;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void tail_pool1d_backward_kernel(const float *__restrict__ gy, const uint8_t *__restrict__ sel,
+                                                                      const float *__restrict__ h, const float *__restrict__ scale,
+                                                                      const float *__restrict__ pre, float *__restrict__ g_h,
+                                                                      float *__restrict__ g_res, int64_t C, int64_t L, int64_t Lo,
+                                                                      int k) {
+    __shared__ float g_s[kTailOut];
+    __shared__ uint8_t c_s[kTailOut];
+    const int64_t nc = blockIdx.x;
+    const int c = (int)(nc % C);
+    const float s = scale[c], pr = pre ? pre[c] : 0.0f;
+    const int64_t j0 = (int64_t)blockIdx.y * kTailOut;
+    const bool last = j0 + kTailOut >= Lo;
+    const int outs = (int)(last ? (Lo - j0) : kTailOut);
+    const int ins = last ? (int)(L - j0 * k) : outs * k;          // the last tile also owns the dropped tail (gradient 0)
+    for (int j = threadIdx.x; j < outs; j += kBlock) {
+        g_s[j] = gy[nc * Lo + j0 + j];
+        c_s[j] = sel[nc * Lo + j0 + j];
+    }
+    __syncthreads();
+    const int64_t base = nc * L + j0 * k;
+    for (int i = threadIdx.x; i < ins; i += kBlock) {
+        const int j = i / k, e = i - j * k;
+        const float g = (j < outs && (int)c_s[j] == e) ? g_s[j] : 0.0f;
+        g_res[base + i] = g;
+        g_h[base + i] = act_bwd<1>(g, h[base + i], s, 0.0f, pr, 0.0f);
+    }
+}
+
 inline bool pool_dims_ok(int64_t N, int64_t C, int64_t H, int64_t W) {
     // planes on grid.x, tiles of a plane on grid.y (<= 65535 workgroups of 256 threads per plane)
     return N >= 0 && C >= 0 && H >= 0 && W >= 0 && N * C <= 0x7fffffffLL && H * ((W + 3) / 4) <= 65535LL * kBlock;
@@ -451,6 +513,34 @@ int advstep_maxpool1d_backward_f32(const float *gy, const uint8_t *sel, float *g
     if (!gy || !sel) return ADVSTEP_EINVAL;
     const dim3 grid((unsigned)(N * C), (unsigned)ceil_div(Lo, kBlock)), block(kBlock);
     hipLaunchKernelGGL(pool1d_backward_kernel, grid, block, 0, as_stream(stream), gy, sel, g, L, Lo, (int)k);
+    return status_after_launch();
+}
+
+int advstep_tail_pool1d_forward_f32(const float *h, const float *res, const float *scale, const float *shift, const float *pre,
+                                    float *y, uint8_t *sel, int64_t N, int64_t C, int64_t L, int64_t k, advstep_stream_t stream) {
+    if (N < 0 || C < 0 || L < 0 || k < 2 || k > 8 || N * C > 0x7fffffffLL) return ADVSTEP_EINVAL;
+    const int64_t Lo = L / k;
+    if (N * C * Lo == 0) return ADVSTEP_OK;
+    if (!h || !res || !scale || !shift || !y || !sel || ceil_div(Lo, kTailOut) > 65535) return ADVSTEP_EINVAL;
+    const dim3 grid((unsigned)(N * C), (unsigned)ceil_div(Lo, kTailOut)), block(kBlock);
+    hipLaunchKernelGGL(tail_pool1d_forward_kernel, grid, block, 0, as_stream(stream), h, res, scale, shift, pre, y, sel, C, L, Lo, (int)k);
+    return status_after_launch();
+}
+
+int advstep_tail_pool1d_backward_f32(const float *gy, const uint8_t *sel, const float *h, const float *scale, const float *pre,
+                                     float *g_h, float *g_res, int64_t N, int64_t C, int64_t L, int64_t k, advstep_stream_t stream) {
+    if (N < 0 || C < 0 || L < 0 || k < 2 || k > 8 || N * C > 0x7fffffffLL) return ADVSTEP_EINVAL;
+    if (N * C * L == 0) return ADVSTEP_OK;
+    const int64_t Lo = L / k;
+    if (!g_h || !g_res || ceil_div(Lo, kTailOut) > 65535) return ADVSTEP_EINVAL;
+    if (Lo == 0) {
+        const size_t bytes = (size_t)(N * C * L) * sizeof(float);
+        return (hipMemsetAsync(g_h, 0, bytes, as_stream(stream)) == hipSuccess && hipMemsetAsync(g_res, 0, bytes, as_stream(stream)) == hipSuccess)
+                   ? ADVSTEP_OK : ADVSTEP_ELAUNCH;
+    }
+    if (!gy || !sel || !h || !scale) return ADVSTEP_EINVAL;
+    const dim3 grid((unsigned)(N * C), (unsigned)ceil_div(Lo, kTailOut)), block(kBlock);
+    hipLaunchKernelGGL(tail_pool1d_backward_kernel, grid, block, 0, as_stream(stream), gy, sel, h, scale, pre, g_h, g_res, C, L, Lo, (int)k);
     return status_after_launch();
 }
 

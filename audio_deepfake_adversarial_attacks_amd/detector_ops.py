@@ -207,6 +207,45 @@ def add_maxpool1d(a: torch.Tensor, b: Optional[torch.Tensor], k: int) -> torch.T
     return _AddMaxPool1d.apply(a.contiguous(), None if b is None else b.contiguous(), int(k))
 
 
+class _TailPool1d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, res, scale, shift, pre, k):
+        _require(h, "h"), _require(res, "res")
+        if h.dim() != 3 or res.shape != h.shape:
+            raise ValueError("h and res must be (N, C, L) tensors of the same shape")
+        N, C, L = h.shape
+        y = torch.empty((N, C, L // k), dtype=h.dtype, device=h.device)
+        sel = torch.empty(max(y.numel(), 1), dtype=torch.uint8, device=h.device)
+        with _Launch("tail_pool1d_forward", h.device):
+            st = _lib.load().advstep_tail_pool1d_forward_f32(h.data_ptr(), res.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                                             None if pre is None else pre.data_ptr(), y.data_ptr(), sel.data_ptr(),
+                                                             N, C, L, k, _stream(h.device))
+        _lib.check(st, "advstep_tail_pool1d_forward_f32")
+        ctx.save_for_backward(h, sel, scale, *([pre] if pre is not None else []))
+        ctx.k = k
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        h, sel, scale, *pre = ctx.saved_tensors
+        N, C, L = h.shape
+        gy = gy.contiguous()
+        g_h, g_res = torch.empty_like(h), torch.empty_like(h)
+        with _Launch("tail_pool1d_backward", h.device):
+            st = _lib.load().advstep_tail_pool1d_backward_f32(gy.data_ptr(), sel.data_ptr(), h.data_ptr(), scale.data_ptr(),
+                                                              pre[0].data_ptr() if pre else None, g_h.data_ptr(), g_res.data_ptr(),
+                                                              N, C, L, ctx.k, _stream(h.device))
+        _lib.check(st, "advstep_tail_pool1d_backward_f32")
+        return g_h, g_res, None, None, None, None
+
+
+def tail_pool1d(h: torch.Tensor, res: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, pre: Optional[torch.Tensor],
+                k: int) -> torch.Tensor:
+    """MaxPool1d(k)(relu(h + pre[c]) * scale[c] + shift[c] + res) over (N, C, L), kernel = stride = k in 2..8; differentiable in h
+    and res (per-channel constants are constants)."""
+    return _TailPool1d.apply(h.contiguous(), res.contiguous(), scale, shift, pre, int(k))
+
+
 def maxpool1d_supported(pool) -> bool:
     """nn.MaxPool1d with kernel = stride in 2..8, no padding / dilation / ceil mode / indices."""
     k = pool.kernel_size if isinstance(pool.kernel_size, int) else pool.kernel_size[0]

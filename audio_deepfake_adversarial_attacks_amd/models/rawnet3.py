@@ -70,6 +70,12 @@ def _chain_enabled() -> bool:
     return os.environ.get("ADVSTEP_RAWNET3_CHAIN", "1") != "0"
 
 
+def _tail_enabled() -> bool:
+    """ADVSTEP_RAWNET3_TAIL=0 keeps activation and `+= residual` / MaxPool1d as two passes (A/B measurements); default on."""
+    import os
+    return os.environ.get("ADVSTEP_RAWNET3_TAIL", "1") != "0"
+
+
 def _fused_elem_enabled() -> bool:
     import os
     return os.environ.get("ADVSTEP_RAWNET3_ELEM", "1") != "0"
@@ -296,6 +302,21 @@ class Bottle2neck(nn.Module):
         return self._tail(out, residual)
 
     def _tail(self, out, residual):
+        if (self.mp and out.is_cuda and out.dtype == torch.float32 and _fused_elem_enabled() and _tail_enabled()
+                and isinstance(residual, torch.Tensor)):
+            from .. import detector_ops as D
+            conv, bn = self.conv3, self.bn3
+            frozen = not (torch.is_grad_enabled() and (conv.weight.requires_grad or (conv.bias is not None and conv.bias.requires_grad)
+                                                       or any(p.requires_grad for p in bn.parameters())))
+            if frozen and D.foldable_bn(bn) and D.maxpool1d_supported(self.mp):
+                # conv3 -> relu -> bn3 -> `+= residual` -> MaxPool1d: the convolution without its bias, everything else one pass
+                scale, shift = D.bn_eval_affine(bn)
+                h = _same_conv1d(out, conv, with_bias=False)
+                if h.shape == residual.shape:
+                    k = self.mp.kernel_size if isinstance(self.mp.kernel_size, int) else self.mp.kernel_size[0]
+                    return self.afms(D.tail_pool1d(h, residual, scale, shift, conv.bias.detach() if conv.bias is not None else None, k))
+                return self.afms(_add_pool(D.relu_affine(h, scale, shift, conv.bias.detach() if conv.bias is not None else None),
+                                           residual, self.mp))
         out = _conv_relu_bn(out, self.conv3, self.bn3)
         if self.mp:
             out = _add_pool(out, residual, self.mp)        # `out += residual` -> MaxPool1d, one pass on a HIP tensor

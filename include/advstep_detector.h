@@ -67,6 +67,17 @@ int advstep_add_maxpool1d_forward_f32(const float *a, const float *b, float *y, 
 int advstep_maxpool1d_backward_f32(const float *gy, const uint8_t *sel, float *g, int64_t N, int64_t C, int64_t L, int64_t k,
                                    advstep_stream_t stream);
 
+/* ---- the tail of a RawNet3 Bottle2neck (src/models/rawnet3.py:262-269: `bn3(relu(conv3(.)))`, `out += residual`, `mp(out)`) ----
+ * forward:  y (N, C, L/k) = MaxPool1d(k)(relu(h + pre[c]) * scale[c] + shift[c] + res), sel as advstep_add_maxpool1d_forward_f32;
+ *           h = conv3's output without its bias (pre = that bias or NULL), res = the residual branch; 2 <= k <= 8.
+ * backward: g_res (N, C, L) = unpool(gy, sel) (dropped tail 0) and g_h = (h + pre <= 0) ? 0 : g_res * scale in the same pass.
+ * Same arithmetic as advstep_affine_act_*(mode 1) followed by advstep_add_maxpool1d_* — the activated tensor is never written,
+ * and the windows are gathered through LDS so that global accesses are contiguous. */
+int advstep_tail_pool1d_forward_f32(const float *h, const float *res, const float *scale, const float *shift, const float *pre,
+                                    float *y, uint8_t *sel, int64_t N, int64_t C, int64_t L, int64_t k, advstep_stream_t stream);
+int advstep_tail_pool1d_backward_f32(const float *gy, const uint8_t *sel, const float *h, const float *scale, const float *pre,
+                                     float *g_h, float *g_res, int64_t N, int64_t C, int64_t L, int64_t k, advstep_stream_t stream);
+
 /* ---- channel gate + MaxPool2d(2) --------------------------------------------------------------------------------------
  * y = MaxPool2d(2)(x * gate[n, c] + gate[n, c]) (src/models/specrnet.py:145-149 followed by `self.pool`, :163-172).
  * Backward: gx = gate * scatter(gy); ggate_partial (N * C, blocks) holds per-workgroup partial sums of

@@ -238,3 +238,30 @@ def test_rawnet3_res2net_chain_equals_the_separate_ops(cuda, monkeypatch, parity
     assert fig["grad_rel_l2"] <= 1e-5, fig
     for p in model.parameters():
         p.requires_grad_(True)
+
+
+@pytest.mark.parametrize("shape,k", [((2, 16, 6435), 5), ((3, 7, 1287), 3), ((1, 2, 17), 5), ((2, 3, 4), 5), ((2, 4, 30), 2), ((1, 3, 2700), 3)])
+def test_tail_pool1d_equals_activation_then_add_maxpool1d(D, cuda, shape, k):
+    """advstep_tail_pool1d_* = relu_affine followed by add_maxpool1d, in one pass each way: bit for bit, values, winners and both
+    gradients (several tiles per row, a dropped tail, rows shorter than a window)."""
+    N, C, L = shape
+    h, res = rnd(shape, 1, cuda), rnd(shape, 2, cuda)
+    scale, shift, pre = rnd((C,), 3, cuda), rnd((C,), 4, cuda), rnd((C,), 5, cuda)
+    h[0, 0, :min(L, 3)] = -pre[0]                                   # relu at exactly 0; ties inside a window
+    res[0, 0, :min(L, 3)] = 0.25
+
+    def run(fused, with_pre):
+        a, b = h.clone().requires_grad_(True), res.clone().requires_grad_(True)
+        p = pre if with_pre else None
+        y = D.tail_pool1d(a, b, scale, shift, p, k) if fused else D.add_maxpool1d(D.relu_affine(a, scale, shift, p), b, k)
+        if y.numel() == 0:
+            return y.detach(), torch.zeros_like(a), torch.zeros_like(b)
+        gy = rnd(tuple(y.shape), 6, cuda)
+        ga, gb = torch.autograd.grad(y, (a, b), gy)
+        return y.detach(), ga, gb
+
+    for with_pre in (True, False):
+        y0, ga0, gb0 = run(False, with_pre)
+        y1, ga1, gb1 = run(True, with_pre)
+        assert y1.shape == (N, C, L // k)
+        assert torch.equal(y0, y1) and torch.equal(ga0, ga1) and torch.equal(gb0, gb1)
