@@ -441,6 +441,59 @@ __global__ __launch_bounds__(kBlock) void tail_pool1d_backward_kernel(const floa
     }
 }
 
+// ---- RawNet3's feature normalisation (src/models/rawnet3.py:80-85): x = log(|y| + eps);  x = x - mean_t(x) -----------------------
+// One workgroup per (n, c) row of L <= kRowCap frames, the row in registers: forward reads y once and writes x once (ATen: abs,
+// add, log, mean, sub = 5 passes); backward  g_y = (g - mean_t(g)) / (|y| + eps) * sign(y)  likewise (ATen: 9 kernels).
+constexpr int kRowPerThread = 32, kRowCap = kBlock * kRowPerThread;
+
+__device__ __forceinline__ float block_sum(float v, float *red_s) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();                       // red_s may still be read from a previous call
+    if (lane == 0) red_s[wave] = v;
+    __syncthreads();
+    float t = 0.0f;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; ++w) t += red_s[w];      // same order in every thread
+    return t;
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(kBlock) void log_meannorm_kernel(const float *__restrict__ g, const float *__restrict__ y, float eps,
+                                                              float *__restrict__ out, int64_t L) {
+    __shared__ float red_s[kBlock / 64];
+    const int64_t row = blockIdx.x;
+    const float *yp = y + row * L;
+    const float *gp = BWD ? g + row * L : nullptr;
+    float *op = out + row * L;
+    float v[kRowPerThread];
+    float part = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kRowPerThread; ++k) {
+        const int64_t i = threadIdx.x + (int64_t)k * kBlock;
+        v[k] = 0.0f;
+        if (i < L) {
+            v[k] = BWD ? gp[i] : logf(fabsf(yp[i]) + eps);
+            part += v[k];
+        }
+    }
+    const float mean = block_sum(part, red_s) / (float)L;
+#pragma unroll
+    for (int k = 0; k < kRowPerThread; ++k) {
+        const int64_t i = threadIdx.x + (int64_t)k * kBlock;
+        if (i < L) {
+            if (BWD) {
+                const float yv = yp[i];
+                const float sg = yv > 0.0f ? 1.0f : (yv < 0.0f ? -1.0f : (yv == 0.0f ? 0.0f : yv));      // torch.sign; NaN stays NaN
+                op[i] = (v[k] - mean) / (fabsf(yv) + eps) * sg;
+            } else {
+                op[i] = v[k] - mean;
+            }
+        }
+    }
+}
+
 inline bool pool_dims_ok(int64_t N, int64_t C, int64_t H, int64_t W) {
     // planes on grid.x, tiles of a plane on grid.y (<= 65535 workgroups of 256 threads per plane)
     return N >= 0 && C >= 0 && H >= 0 && W >= 0 && N * C <= 0x7fffffffLL && H * ((W + 3) / 4) <= 65535LL * kBlock;
@@ -513,6 +566,26 @@ int advstep_maxpool1d_backward_f32(const float *gy, const uint8_t *sel, float *g
     if (!gy || !sel) return ADVSTEP_EINVAL;
     const dim3 grid((unsigned)(N * C), (unsigned)ceil_div(Lo, kBlock)), block(kBlock);
     hipLaunchKernelGGL(pool1d_backward_kernel, grid, block, 0, as_stream(stream), gy, sel, g, L, Lo, (int)k);
+    return status_after_launch();
+}
+
+int advstep_log_meannorm_max_length(void) { return kRowCap; }
+
+int advstep_log_meannorm_forward_f32(const float *y, float eps, float *x, int64_t rows, int64_t L, advstep_stream_t stream) {
+    if (rows < 0 || L < 0 || L > kRowCap || rows > 0x7fffffffLL) return ADVSTEP_EINVAL;
+    if (rows * L == 0) return ADVSTEP_OK;
+    if (!y || !x) return ADVSTEP_EINVAL;
+    hipLaunchKernelGGL(log_meannorm_kernel<false>, dim3((unsigned)rows), dim3(kBlock), 0, as_stream(stream), (const float *)nullptr, y, eps,
+                       x, L);
+    return status_after_launch();
+}
+
+int advstep_log_meannorm_backward_f32(const float *gx, const float *y, float eps, float *gy, int64_t rows, int64_t L,
+                                      advstep_stream_t stream) {
+    if (rows < 0 || L < 0 || L > kRowCap || rows > 0x7fffffffLL) return ADVSTEP_EINVAL;
+    if (rows * L == 0) return ADVSTEP_OK;
+    if (!gx || !y || !gy) return ADVSTEP_EINVAL;
+    hipLaunchKernelGGL(log_meannorm_kernel<true>, dim3((unsigned)rows), dim3(kBlock), 0, as_stream(stream), gx, y, eps, gy, L);
     return status_after_launch();
 }
 

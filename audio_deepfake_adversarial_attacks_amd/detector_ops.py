@@ -207,6 +207,42 @@ def add_maxpool1d(a: torch.Tensor, b: Optional[torch.Tensor], k: int) -> torch.T
     return _AddMaxPool1d.apply(a.contiguous(), None if b is None else b.contiguous(), int(k))
 
 
+class _LogMeanNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, eps):
+        _require(y, "y")
+        L = y.shape[-1]
+        x = torch.empty_like(y)
+        with _Launch("log_meannorm_forward", y.device):
+            st = _lib.load().advstep_log_meannorm_forward_f32(y.data_ptr(), eps, x.data_ptr(), y.numel() // max(L, 1), L,
+                                                              _stream(y.device))
+        _lib.check(st, "advstep_log_meannorm_forward_f32")
+        ctx.save_for_backward(y)
+        ctx.eps = eps
+        return x
+
+    @staticmethod
+    def backward(ctx, gx):
+        (y,) = ctx.saved_tensors
+        L = y.shape[-1]
+        gx = gx.contiguous()
+        gy = torch.empty_like(y)
+        with _Launch("log_meannorm_backward", y.device):
+            st = _lib.load().advstep_log_meannorm_backward_f32(gx.data_ptr(), y.data_ptr(), ctx.eps, gy.data_ptr(),
+                                                               y.numel() // max(L, 1), L, _stream(y.device))
+        _lib.check(st, "advstep_log_meannorm_backward_f32")
+        return gy, None
+
+
+def log_meannorm_supported(L: int) -> bool:
+    return 0 < L <= _lib.load().advstep_log_meannorm_max_length()
+
+
+def log_meannorm(y: torch.Tensor, eps: float = 1e-6) -> torch.Tensor:
+    """log(|y| + eps) minus its mean over the last dimension, one pass each way (rows of at most 8192 elements)."""
+    return _LogMeanNorm.apply(y.contiguous(), float(eps))
+
+
 class _TailPool1d(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h, res, scale, shift, pre, k):

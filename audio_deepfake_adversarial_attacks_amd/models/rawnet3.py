@@ -393,10 +393,20 @@ class RawNet3(nn.Module):
 
     def forward(self, x):
         """x: (B, samples)   (rawnet3.py:73-137)."""
-        x = torch.abs(self.conv1(self.preprocess(x)))
-        if self.log_sinc:
-            x = torch.log(x + 1e-6)
-        if self.norm_sinc == "mean":
+        x = self.conv1(self.preprocess(x))
+        fused_norm = False
+        if self.log_sinc and self.norm_sinc == "mean" and x.is_cuda and x.dtype == torch.float32 and _fused_elem_enabled():
+            from .. import detector_ops as D
+            if D.log_meannorm_supported(x.shape[-1]):
+                x = D.log_meannorm(x, 1e-6)               # abs, + 1e-6, log, mean, subtract: one pass each way
+                fused_norm = True
+        if not fused_norm:
+            x = torch.abs(x)
+            if self.log_sinc:
+                x = torch.log(x + 1e-6)
+        if fused_norm:
+            pass
+        elif self.norm_sinc == "mean":
             x = x - torch.mean(x, dim=-1, keepdim=True)
         elif self.norm_sinc == "mean_std":
             m = torch.mean(x, dim=-1, keepdim=True)

@@ -67,6 +67,16 @@ int advstep_add_maxpool1d_forward_f32(const float *a, const float *b, float *y, 
 int advstep_maxpool1d_backward_f32(const float *gy, const uint8_t *sel, float *g, int64_t N, int64_t C, int64_t L, int64_t k,
                                    advstep_stream_t stream);
 
+/* ---- RawNet3's feature normalisation after the sinc encoder (src/models/rawnet3.py:80-85, log_sinc + norm_sinc == "mean") ------
+ * forward:  x (rows, L) = log(|y| + eps) - mean over L of the same      (rows = N * C; L <= advstep_log_meannorm_max_length())
+ * backward: gy = (gx - mean_L(gx)) / (|y| + eps) * sign(y)               (torch's abs / log / mean gradients; sign(0) = 0)
+ * One read and one write of the 0.4 GB feature map each way instead of 5 / 9 ATen passes; the row sum is taken in a fixed
+ * order (deterministic; differs from ATen's reduction order in the last bits). */
+int advstep_log_meannorm_max_length(void);
+int advstep_log_meannorm_forward_f32(const float *y, float eps, float *x, int64_t rows, int64_t L, advstep_stream_t stream);
+int advstep_log_meannorm_backward_f32(const float *gx, const float *y, float eps, float *gy, int64_t rows, int64_t L,
+                                      advstep_stream_t stream);
+
 /* ---- the tail of a RawNet3 Bottle2neck (src/models/rawnet3.py:262-269: `bn3(relu(conv3(.)))`, `out += residual`, `mp(out)`) ----
  * forward:  y (N, C, L/k) = MaxPool1d(k)(relu(h + pre[c]) * scale[c] + shift[c] + res), sel as advstep_add_maxpool1d_forward_f32;
  *           h = conv3's output without its bias (pre = that bias or NULL), res = the residual branch; 2 <= k <= 8.

@@ -265,3 +265,32 @@ def test_tail_pool1d_equals_activation_then_add_maxpool1d(D, cuda, shape, k):
         y1, ga1, gb1 = run(True, with_pre)
         assert y1.shape == (N, C, L // k)
         assert torch.equal(y0, y1) and torch.equal(ga0, ga1) and torch.equal(gb0, gb1)
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 6435), (3, 5, 429), (1, 2, 1), (2, 3, 8192), (1, 4, 257)])
+def test_log_meannorm_matches_the_aten_chain(D, cuda, shape):
+    """x = log(|y| + 1e-6) - mean_t(.) and its gradient against torch's abs / add / log / mean / sub with autograd (the row sum
+    runs in another order: values to 2e-6 of the row's log range, gradients to 1e-5 relative).  Zeros and a NaN are in the input:
+    sign(0) = 0 and NaN poisons exactly its own row."""
+    y = rnd(shape, 1, cuda)
+    y[0, 0, 0] = 0.0
+    g = rnd(shape, 2, cuda)
+
+    def chain(t):
+        x = torch.log(torch.abs(t) + 1e-6)
+        return x - torch.mean(x, dim=-1, keepdim=True)
+
+    a = y.clone().requires_grad_(True)
+    x0 = chain(a)
+    (g0,) = torch.autograd.grad(x0, a, g)
+    b = y.clone().requires_grad_(True)
+    x1 = D.log_meannorm(b)
+    (g1,) = torch.autograd.grad(x1, b, g)
+    assert (x0 - x1).abs().max().item() <= 2e-6 * max(x0.abs().max().item(), 1.0)
+    assert (g0 - g1).abs().max().item() <= 1e-5 * g0.abs().max().item()
+    if shape[-1] > 1:
+        z = y.clone()
+        z[-1, -1, -1] = float("nan")
+        xn = D.log_meannorm(z)
+        assert torch.isnan(xn[-1, -1]).all() and torch.isfinite(xn.reshape(-1, shape[-1])[:-1]).all()
+    assert not D.log_meannorm_supported(8193) and D.log_meannorm_supported(6435)
