@@ -494,6 +494,36 @@ __global__ __launch_bounds__(kBlock) void log_meannorm_kernel(const float *__res
     }
 }
 
+// ---- RawNet3's AFMS (src/models/rawnet3.py:161-182): y = sigmoid(fc(mean_t x)); out = (x + alpha[c]) * y[n, c] ----------------------
+// Row kernels (one workgroup per (n, c) row of L <= kRowCap frames, the row in registers):
+//   MODE 0  r[row]   = mean_t x                                            (the gate's input; fc and sigmoid stay torch ops on (N, C))
+//   MODE 1  out      = (x + alpha[c]) * y[row]
+//   MODE 2  r[row]   = sum_t g * (x + alpha[c])                            (d out / d y, summed over the row)
+//   MODE 3  out      = g * y[row] + m[row]                                 (d out / d x plus the mean's share m = d mean / L)
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void afms_row_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                          const float *__restrict__ alpha, const float *__restrict__ r0,
+                                                          const float *__restrict__ r1, float *__restrict__ out, int64_t C, int64_t L) {
+    __shared__ float red_s[kBlock / 64];
+    const int64_t row = blockIdx.x;
+    const float *ap = a + row * L;
+    const float *bp = MODE == 2 ? b + row * L : nullptr;
+    const float al = (MODE == 1 || MODE == 2) ? alpha[row % C] : 0.0f;
+    const float s0 = (MODE == 1 || MODE == 3) ? r0[row] : 0.0f, s1 = MODE == 3 ? r1[row] : 0.0f;
+    float part = 0.0f;
+    for (int64_t i = threadIdx.x; i < L; i += kBlock) {
+        const float v = ap[i];
+        if (MODE == 0) part += v;
+        if (MODE == 1) out[row * L + i] = (v + al) * s0;
+        if (MODE == 2) part += v * (bp[i] + al);
+        if (MODE == 3) out[row * L + i] = v * s0 + s1;
+    }
+    if (MODE == 0 || MODE == 2) {
+        const float t = block_sum(part, red_s);
+        if (threadIdx.x == 0) out[row] = MODE == 0 ? t / (float)L : t;
+    }
+}
+
 inline bool pool_dims_ok(int64_t N, int64_t C, int64_t H, int64_t W) {
     // planes on grid.x, tiles of a plane on grid.y (<= 65535 workgroups of 256 threads per plane)
     return N >= 0 && C >= 0 && H >= 0 && W >= 0 && N * C <= 0x7fffffffLL && H * ((W + 3) / 4) <= 65535LL * kBlock;
@@ -566,6 +596,21 @@ int advstep_maxpool1d_backward_f32(const float *gy, const uint8_t *sel, float *g
     if (!gy || !sel) return ADVSTEP_EINVAL;
     const dim3 grid((unsigned)(N * C), (unsigned)ceil_div(Lo, kBlock)), block(kBlock);
     hipLaunchKernelGGL(pool1d_backward_kernel, grid, block, 0, as_stream(stream), gy, sel, g, L, Lo, (int)k);
+    return status_after_launch();
+}
+
+int advstep_afms_row_f32(int mode, const float *a, const float *b, const float *alpha, const float *r0, const float *r1, float *out,
+                         int64_t rows, int64_t C, int64_t L, advstep_stream_t stream) {
+    if (mode < 0 || mode > 3 || rows < 0 || C <= 0 || L < 0 || rows > 0x7fffffffLL) return ADVSTEP_EINVAL;
+    if (rows == 0 || (L == 0 && (mode == 1 || mode == 3))) return ADVSTEP_OK;
+    if (!a || !out || (mode == 2 && !b) || ((mode == 1 || mode == 2) && !alpha) || ((mode == 1 || mode == 3) && !r0) || (mode == 3 && !r1))
+        return ADVSTEP_EINVAL;
+    const dim3 grid((unsigned)rows), block(kBlock);
+    hipStream_t st = as_stream(stream);
+    if (mode == 0) hipLaunchKernelGGL(afms_row_kernel<0>, grid, block, 0, st, a, b, alpha, r0, r1, out, C, L);
+    else if (mode == 1) hipLaunchKernelGGL(afms_row_kernel<1>, grid, block, 0, st, a, b, alpha, r0, r1, out, C, L);
+    else if (mode == 2) hipLaunchKernelGGL(afms_row_kernel<2>, grid, block, 0, st, a, b, alpha, r0, r1, out, C, L);
+    else hipLaunchKernelGGL(afms_row_kernel<3>, grid, block, 0, st, a, b, alpha, r0, r1, out, C, L);
     return status_after_launch();
 }
 

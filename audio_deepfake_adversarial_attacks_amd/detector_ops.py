@@ -207,6 +207,46 @@ def add_maxpool1d(a: torch.Tensor, b: Optional[torch.Tensor], k: int) -> torch.T
     return _AddMaxPool1d.apply(a.contiguous(), None if b is None else b.contiguous(), int(k))
 
 
+def _afms_row(mode: int, a, b, alpha, r0, r1, out, rows: int, C: int, L: int) -> None:
+    ptr = lambda t: None if t is None else t.data_ptr()
+    st = _lib.load().advstep_afms_row_f32(mode, a.data_ptr(), ptr(b), ptr(alpha), ptr(r0), ptr(r1), out.data_ptr(), rows, C, L,
+                                          _stream(a.device))
+    _lib.check(st, "advstep_afms_row_f32")
+
+
+class _Afms(torch.autograd.Function):
+    """(x + alpha[c]) * sigmoid(fc(mean_t x)) — RawNet3's AFMS with frozen parameters; input gradient only."""
+
+    @staticmethod
+    def forward(ctx, x, alpha, weight, bias):
+        _require(x, "x")
+        N, C, L = x.shape
+        mean = torch.empty((N, C), dtype=x.dtype, device=x.device)
+        _afms_row(0, x, None, None, None, None, mean, N * C, C, L)
+        y = torch.sigmoid(torch.addmm(bias, mean, weight.t()) if bias is not None else mean @ weight.t()).contiguous()
+        out = torch.empty_like(x)
+        _afms_row(1, x, None, alpha, y, None, out, N * C, C, L)
+        ctx.save_for_backward(x, alpha, weight, y)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, alpha, weight, y = ctx.saved_tensors
+        N, C, L = x.shape
+        g = g.contiguous()
+        gy = torch.empty((N, C), dtype=x.dtype, device=x.device)
+        _afms_row(2, g, x, alpha, None, None, gy, N * C, C, L)
+        g_mean = ((gy * y * (1.0 - y)) @ weight) / L                  # sigmoid', fc^T, the mean's 1 / L
+        gx = torch.empty_like(x)
+        _afms_row(3, g, None, None, y, g_mean.contiguous(), gx, N * C, C, L)
+        return gx, None, None, None
+
+
+def afms(x: torch.Tensor, alpha: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """RawNet3's AFMS on a (N, C, L) HIP tensor: alpha (C,) or (C, 1), fc weight (C, C) and bias (C,)."""
+    return _Afms.apply(x.contiguous(), alpha.reshape(-1).contiguous(), weight, bias)
+
+
 class _LogMeanNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y, eps):

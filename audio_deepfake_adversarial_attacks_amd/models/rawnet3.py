@@ -42,6 +42,11 @@ class AFMS(nn.Module):
         self.sig = nn.Sigmoid()
 
     def forward(self, x):
+        if x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and _fused_elem_enabled() and _afms_enabled():
+            frozen = not (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()))
+            if frozen:
+                from .. import detector_ops as D
+                return D.afms(x, self.alpha.detach(), self.fc.weight.detach(), None if self.fc.bias is None else self.fc.bias.detach())
         y = F.adaptive_avg_pool1d(x, 1).view(x.size(0), -1)
         y = self.sig(self.fc(y)).view(x.size(0), x.size(1), -1)
         return (x + self.alpha) * y
@@ -68,6 +73,12 @@ def _chain_enabled() -> bool:
     """ADVSTEP_RAWNET3_CHAIN=0 runs the Res2Net branches as separate torch ops (A/B measurements); default on."""
     import os
     return os.environ.get("ADVSTEP_RAWNET3_CHAIN", "1") != "0"
+
+
+def _afms_enabled() -> bool:
+    """ADVSTEP_RAWNET3_AFMS=0 keeps AFMS as torch ops (A/B measurements); default on."""
+    import os
+    return os.environ.get("ADVSTEP_RAWNET3_AFMS", "1") != "0"
 
 
 def _tail_enabled() -> bool:

@@ -77,6 +77,15 @@ int advstep_log_meannorm_forward_f32(const float *y, float eps, float *x, int64_
 int advstep_log_meannorm_backward_f32(const float *gx, const float *y, float eps, float *gy, int64_t rows, int64_t L,
                                       advstep_stream_t stream);
 
+/* ---- RawNet3's AFMS (src/models/rawnet3.py:161-182): y = sigmoid(fc(mean_t x)), out = (x + alpha[c]) * y[n, c] ------------------
+ * Row kernels over (rows = N * C, L) tensors; the (N, C)-sized fc / sigmoid stay with the caller:
+ *   mode 0  out[row] = mean_L a                                  mode 1  out = (a + alpha[c]) * r0[row]
+ *   mode 2  out[row] = sum_L a * (b + alpha[c])   (a = d out, b = x: the gate's gradient)
+ *   mode 3  out = a * r0[row] + r1[row]           (a = d out, r0 = y, r1 = the mean's share of d x)
+ * c = row % C.  Two passes each way over the block's output instead of three / six ATen kernels; row sums in a fixed order. */
+int advstep_afms_row_f32(int mode, const float *a, const float *b, const float *alpha, const float *r0, const float *r1, float *out,
+                         int64_t rows, int64_t C, int64_t L, advstep_stream_t stream);
+
 /* ---- the tail of a RawNet3 Bottle2neck (src/models/rawnet3.py:262-269: `bn3(relu(conv3(.)))`, `out += residual`, `mp(out)`) ----
  * forward:  y (N, C, L/k) = MaxPool1d(k)(relu(h + pre[c]) * scale[c] + shift[c] + res), sel as advstep_add_maxpool1d_forward_f32;
  *           h = conv3's output without its bias (pre = that bias or NULL), res = the residual branch; 2 <= k <= 8.
