@@ -93,6 +93,7 @@ SIGNATURES = {
     "advstep_stft_bands_f32": (ctypes.c_int, [_p, _p, _p, _p, _i64, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _p]),
     "advstep_stft_bands_backward_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _p, _i64, _i64, _i64, _i64, _i64, _i64, _p]),
     "advstep_stft_mel_f32": (ctypes.c_int, [_p, _p, _p, _p, _i64, _p, _i64, _i64, _i64, _i64, _i64, _i64, _p]),
+    "advstep_stft_mel_backward_from_output_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _p, _i64, _i64, _i64, _i64, _i64, _i64, _p]),
     "advstep_stft_mel_backward_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _p, _p, _i64, _p, _i64, _i64, _i64, _i64, _i64,
                                                     _i64, _p]),
     # include/advstep_fab.h

@@ -8,11 +8,10 @@ LFCC) to float rounding, including torchaudio's gradient path through `amax` (fl
 maximum); tests/test_gpu_frontend_ops.py.  HIP tensors only."""
 from __future__ import annotations
 
+import os
 from typing import NamedTuple
 
 import torch
-
-import os
 
 from . import _lib, fft_plans
 from .hip_ops import _Launch, _stream
@@ -270,7 +269,8 @@ class _MelSpecFromWaveform(torch.autograd.Function):
                                                   tables.fb_w.data_ptr(), tables.span, out.data_ptr(), B, T, NF, hop, nfft, M,
                                                   _stream(dev))
         _lib.check(st, "advstep_stft_mel_f32")
-        ctx.save_for_backward(x, window, tables.fb_start, tables.fb_w, tables.fbt_start, tables.fbt_w)
+        ctx.from_output = os.environ.get("ADVSTEP_MEL_BWD_FROM_OUTPUT", "1") != "0"
+        ctx.save_for_backward(out if ctx.from_output else x, window, tables.fb_start, tables.fb_w, tables.fbt_start, tables.fbt_w)
         ctx.meta = (B, T, NF, M, tables.span, tables.span_t, hop, nfft)
         return out
 
@@ -281,6 +281,14 @@ class _MelSpecFromWaveform(torch.autograd.Function):
         dev = gout.device
         go = gout.contiguous()
         dx = torch.empty((B, T), dtype=torch.float32, device=dev)
+        if ctx.from_output:
+            # d x from d out and out alone (Y = |Y| e^{i phase} is all the gradient needs): no spectrum is recomputed
+            with _Launch("stft_mel_backward", dev):
+                st = _lib.load().advstep_stft_mel_backward_from_output_f32(window.data_ptr(), go.data_ptr(), x.data_ptr(),
+                                                                           fbt_start.data_ptr(), fbt_w.data_ptr(), span_t,
+                                                                           dx.data_ptr(), B, T, NF, hop, nfft, M, _stream(dev))
+            _lib.check(st, "advstep_stft_mel_backward_from_output_f32")
+            return dx, None, None, None
         with _Launch("stft_mel_backward", dev):
             st = _lib.load().advstep_stft_mel_backward_f32(x.data_ptr(), window.data_ptr(), go.data_ptr(), fb_start.data_ptr(),
                                                            fb_w.data_ptr(), span, fbt_start.data_ptr(), fbt_w.data_ptr(), span_t,

@@ -107,6 +107,13 @@ int advstep_stft_mel_backward_f32(const float *x, const float *window, const flo
                                   int64_t span_t, float *dx, int64_t B, int64_t T, int64_t NF, int64_t hop, int64_t nfft,
                                   int64_t M, advstep_stream_t stream);
 
+/* The same gradient from the forward OUTPUT instead of the waveform: Y = fb X is linear, so dx needs only dY, and dY needs only
+ * Y = out[:, 0] * exp(i out[:, 1]) — no framing, forward FFT or band projection is recomputed (about 45 % less work).  `out` is
+ * what advstep_stft_mel_f32 wrote for the same x (any rounding of it enters dx at 1e-7 relative). */
+int advstep_stft_mel_backward_from_output_f32(const float *window, const float *dout, const float *out, const int32_t *fbt_start,
+                                              const float *fbt_w, int64_t span_t, float *dx, int64_t B, int64_t T, int64_t NF,
+                                              int64_t hop, int64_t nfft, int64_t M, advstep_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -114,6 +114,29 @@ def test_fused_mel_spec_matches_torch_chain(cuda, monkeypatch, B, T):
     assert torch.equal(y, y2) and torch.equal(g, g2)
 
 
+def test_mel_backward_from_output_equals_backward_from_waveform(cuda, monkeypatch):
+    """The shipped mel-spec gradient reconstructs d Y from the forward OUTPUT (|Y|, phase) and skips the spectrum; the first
+    version recomputed framing + FFT + band projection from the waveform.  Same gradient to 1e-5 relative (the output's
+    rounding enters through cos / sin of the stored phase); exact zeros where |Y| = 0 (silent utterance)."""
+    from audio_deepfake_adversarial_attacks_amd.frontends import MelSpecFrontend
+    fe = MelSpecFrontend().to(cuda)
+    gen = torch.Generator().manual_seed(21)
+    x = (torch.rand(3, 64_600, generator=gen) - 0.5).to(cuda)
+    x[2] = 0.0
+    gy = torch.randn(3, 2, 80, 404, generator=gen).to(cuda)
+
+    def run(from_output):
+        monkeypatch.setenv("ADVSTEP_MEL_BWD_FROM_OUTPUT", "1" if from_output else "0")
+        a = x.clone().requires_grad_(True)
+        (g,) = torch.autograd.grad(fe(a), a, gy)
+        return g
+
+    g0, g1 = run(False), run(True)
+    assert (g0[:2] - g1[:2]).norm().item() <= 1e-5 * g0[:2].norm().item()
+    assert not g0[2].any() and not g1[2].any()
+    assert torch.equal(run(True), g1)
+
+
 def test_fused_mel_spec_with_wide_bands(cuda, monkeypatch):
     """32 mel bands: the widest band covers more than 16 bins, which takes the kernels' second tap-register size."""
     from audio_deepfake_adversarial_attacks_amd import frontend_ops

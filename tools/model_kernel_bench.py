@@ -192,6 +192,9 @@ def main():
         wav.data_ptr(), mwin.data_ptr(), dmel.data_ptr(), mt.fb_start.data_ptr(), mt.fb_w.data_ptr(), mt.span, mt.fbt_start.data_ptr(),
         mt.fbt_w.data_ptr(), mt.span_t, dxx.data_ptr(), B, Tn, NF, 160, 512, Mm, st),
         bytes_moved=4.0 * (2 * wav.numel() + dmel.numel()))
+    timeit("stft_mel_backward_from_output", lambda: lib.advstep_stft_mel_backward_from_output_f32(
+        mwin.data_ptr(), dmel.data_ptr(), mout.data_ptr(), mt.fbt_start.data_ptr(), mt.fbt_w.data_ptr(), mt.span_t, dxx.data_ptr(), B, Tn,
+        NF, 160, 512, Mm, st), bytes_moved=4.0 * (wav.numel() + 2 * dmel.numel()))
     if a.json:
         Path(a.json).write_text(json.dumps({"batch": B, "kernels": res}, indent=1))
 
