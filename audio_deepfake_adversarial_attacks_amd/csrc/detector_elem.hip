@@ -28,11 +28,17 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 // ---- per-channel affine + activation: grid (N * C planes, tiles of 4 x 256 float4 per plane) -------------------------------
 constexpr int kVecPerThread = 4;
 
+constexpr float kSeluAlpha = 1.6732632423543772848170429916717f, kSeluScale = 1.0507009873554804934193349852946f;
+
 template <int MODE>
 __device__ __forceinline__ float act_fwd(float x, float s, float t, float pre, float slope) {
     if (MODE == 0) {
         const float v = x * s + t;
         return v > 0.0f ? v : v * slope;
+    }
+    if (MODE == 2) {                                              // at::selu = elu(x, alpha, scale): exp(v) - 1, not expm1
+        const float v = x * s + t;
+        return v <= 0.0f ? (expf(v) - 1.0f) * (kSeluAlpha * kSeluScale) : v * kSeluScale;
     }
     const float r = x + pre;
     return (r > 0.0f ? r : (r != r ? r : 0.0f)) * s + t;      // at::relu = clamp_min(0): NaN stays NaN
@@ -40,6 +46,10 @@ __device__ __forceinline__ float act_fwd(float x, float s, float t, float pre, f
 template <int MODE>
 __device__ __forceinline__ float act_bwd(float gy, float x, float s, float t, float pre, float slope) {
     if (MODE == 0) return gy * ((x * s + t) > 0.0f ? 1.0f : slope) * s;   // leaky_relu_backward: x > 0 ? g : g * slope
+    if (MODE == 2) {                                                        // elu_backward from the input
+        const float v = x * s + t;
+        return gy * (v <= 0.0f ? (kSeluAlpha * kSeluScale) * expf(v) : kSeluScale) * s;
+    }
     return (x + pre) <= 0.0f ? 0.0f : gy * s;                               // threshold_backward: x <= 0 ? 0 : g (NaN: g)
 }
 
@@ -115,7 +125,7 @@ __global__ __launch_bounds__(kBlock) void affine_act_kernel(const float *__restr
 template <bool BWD>
 int launch_affine(const float *gy, const float *x, const float *scale, const float *shift, const float *pre, float *out,
                   int64_t N, int64_t C, int64_t P, int mode, float slope, hipStream_t st) {
-    if (N < 0 || C < 0 || P < 0 || (mode != 0 && mode != 1)) return ADVSTEP_EINVAL;
+    if (N < 0 || C < 0 || P < 0 || (mode != 0 && mode != 1 && mode != 2)) return ADVSTEP_EINVAL;
     if (N * C * P == 0) return ADVSTEP_OK;
     const int64_t tiles = ceil_div(ceil_div(P, 4), kBlock * kVecPerThread);
     if (!x || !scale || !shift || !out || (BWD && !gy) || N * C > 0x7fffffffLL || tiles > 65535) return ADVSTEP_EINVAL;
@@ -124,7 +134,8 @@ int launch_affine(const float *gy, const float *x, const float *scale, const flo
 #define GO(MODE, VEC)                                                                                                   \
     hipLaunchKernelGGL((affine_act_kernel<MODE, BWD, VEC>), grid, block, 0, st, gy, x, scale, shift, pre, out, C, P, slope)
     if (mode == 0) { if (vec) GO(0, true); else GO(0, false); }
-    else { if (vec) GO(1, true); else GO(1, false); }
+    else if (mode == 1) { if (vec) GO(1, true); else GO(1, false); }
+    else { if (vec) GO(2, true); else GO(2, false); }
 #undef GO
     return status_after_launch();
 }

@@ -12,7 +12,7 @@ import torch
 from . import _lib
 from .hip_ops import _Launch, _require, _stream
 
-MODE_AFFINE_LRELU, MODE_RELU_AFFINE = 0, 1
+MODE_AFFINE_LRELU, MODE_RELU_AFFINE, MODE_AFFINE_SELU = 0, 1, 2
 
 
 def bn_eval_affine(bn: torch.nn.modules.batchnorm._BatchNorm) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -69,6 +69,11 @@ class _AffineAct(torch.autograd.Function):
 def affine_lrelu(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, slope: float) -> torch.Tensor:
     """leaky_relu(x * scale[c] + shift[c], slope) over (N, C, ...)."""
     return _AffineAct.apply(x.contiguous(), scale, shift, None, MODE_AFFINE_LRELU, float(slope))
+
+
+def affine_selu(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor) -> torch.Tensor:
+    """selu(x * scale[c] + shift[c]) over (N, C, ...): an eval-mode BatchNorm followed by SELU, one pass each way."""
+    return _AffineAct.apply(x.contiguous(), scale, shift, None, MODE_AFFINE_SELU, 0.0)
 
 
 def relu_affine(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, pre: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -146,12 +146,22 @@ class BaseSpecRNet(nn.Module):
             return detector_ops.gate_maxpool2(feats, gate)
         return self.pool(self._attend(feats, fc))
 
+    def _bn_selu(self, x, bn):
+        """`self.selu(bn(x))` (specrnet.py:159, 173); eval-mode BatchNorm with frozen parameters on a HIP tensor: one pass."""
+        if x.is_cuda and x.dtype == torch.float32 and _fused_elem_enabled():
+            from .. import detector_ops as D
+            frozen = not (torch.is_grad_enabled() and any(p.requires_grad for p in bn.parameters()))
+            if frozen and D.foldable_bn(bn):
+                scale, shift = D.bn_eval_affine(bn)
+                return D.affine_selu(x, scale, shift)
+        return self.selu(bn(x))
+
     def _compute_embedding(self, x):
-        x = self.selu(self.first_bn(x))
+        x = self._bn_selu(x, self.first_bn)
         x = self._attend_pool(self.block0(x), self.fc_attention0)
         x = self._attend_pool(self.block2(x), self.fc_attention2)
         x = self._attend_pool(self.block4(x), self.fc_attention4)
-        x = self.selu(self.bn_before_gru(x))
+        x = self._bn_selu(x, self.bn_before_gru)
         x = x.squeeze(-2).permute(0, 2, 1)
         x = self._run_gru(x)
         return self.fc2_gru(self.fc1_gru(x[:, -1, :]))

@@ -22,10 +22,12 @@ extern "C" {
  *                                                            (src/models/specrnet.py:76-81: bn2 -> lrelu between conv1, conv2)
  * mode 1  y = relu(x + pre[c]) * scale[c] + shift[c]         RawNet3: Conv1d bias -> ReLU -> BatchNorm1d(eval)
  *                                                            (src/models/rawnet3.py:240-242, 252-254, 262-264)
+ * mode 2  y = selu(x * scale[c] + shift[c])                   SpecRNet: BatchNorm2d(eval) -> SELU (src/models/specrnet.py:159, 173)
  * x, y (N, C, P); scale, shift, pre (C) (pre may be NULL = 0).  One read + one write instead of two or three of each. */
 int advstep_affine_act_forward_f32(const float *x, const float *scale, const float *shift, const float *pre, float *y,
                                    int64_t N, int64_t C, int64_t P, int mode, float slope, advstep_stream_t stream);
-/* gx = gy * d y / d x, recomputed from x (mode 0: slope where x * scale + shift <= 0; mode 1: 0 where x + pre <= 0). */
+/* gx = gy * d y / d x, recomputed from x (mode 0: slope where x * scale + shift <= 0; mode 1: 0 where x + pre <= 0;
+ * mode 2: selu'(x * scale + shift) * scale). */
 int advstep_affine_act_backward_f32(const float *gy, const float *x, const float *scale, const float *shift,
                                     const float *pre, float *gx, int64_t N, int64_t C, int64_t P, int mode, float slope,
                                     advstep_stream_t stream);

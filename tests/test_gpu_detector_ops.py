@@ -46,6 +46,30 @@ def test_affine_lrelu_and_relu_affine_match_aten(D, cuda, shape):
     assert torch.equal(torch.nan_to_num(got, nan=7.0), torch.nan_to_num(torch.relu(x) * scale.view(view) + shift.view(view), nan=7.0))
 
 
+@pytest.mark.parametrize("shape", [(3, 2, 80, 404), (2, 64, 1, 25), (2, 5, 7, 9)])
+def test_affine_selu_matches_batchnorm_then_selu(D, cuda, shape):
+    """selu(bn_eval(x)) in one pass: forward to 2e-6 of the scale (the BatchNorm arithmetic is folded into one multiply-add),
+    input gradient to 1e-5 relative (ATen differentiates the in-place SELU from its result, the kernel from its input)."""
+    C = shape[1]
+    bn = torch.nn.BatchNorm2d(C).to(cuda).eval()
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(1)
+        bn.running_mean.copy_(torch.empty(C).uniform_(-0.5, 0.5, generator=g))
+        bn.running_var.copy_(torch.empty(C).uniform_(0.5, 2.0, generator=g))
+        bn.weight.copy_(torch.empty(C).uniform_(-1.0, 1.5, generator=g))
+        bn.bias.copy_(torch.empty(C).uniform_(-0.5, 0.5, generator=g))
+    x, gy = rnd(shape, 2, cuda, 2.0), rnd(shape, 3, cuda)
+    a = x.clone().requires_grad_(True)
+    y0 = torch.nn.SELU(inplace=True)(bn(a))
+    (g0,) = torch.autograd.grad(y0, a, gy)
+    scale, shift = D.bn_eval_affine(bn)
+    b = x.clone().requires_grad_(True)
+    y1 = D.affine_selu(b, scale, shift)
+    (g1,) = torch.autograd.grad(y1, b, gy)
+    assert (y0 - y1).abs().max().item() <= 2e-6 * y0.abs().max().item()
+    assert (g0 - g1).abs().max().item() <= 1e-5 * g0.abs().max().item()
+
+
 def test_bn_eval_affine_equals_batch_norm(D, cuda):
     bn = torch.nn.BatchNorm2d(6).to(cuda).eval()
     with torch.no_grad():
