@@ -622,12 +622,15 @@ int launch_wino(const float *x, const uint8_t *xsel, const float *U, const float
         if ((int64_t)ranges * kWaves > groups) ranges = (int)ceil_div(groups, kWaves);
         if (ranges < 1) ranges = 1;
         // the slices of one tile range read the same input tiles at the same time: put them on ONE XCD (workgroups b, b + 8, ...
-        // share an L2) so two of three reads hit it — 1-3 % on the multi-slice layers even where 32 CUs per XCD do not divide
-        // into whole ranges (3 slices: 240 workgroups).  ADVSTEP_WINO_XCD=0 (read per call): round-robin slices (A/B).
+        // share an L2) so all but one of the reads hit it: 2-3 % on L13 forward and SpecRNet's block2.
+        // ADVSTEP_WINO_XCD=0 (read per call): round-robin slices (A/B)
         const char *e = getenv("ADVSTEP_WINO_XCD");
         ga.xcd = 0;
-        if (!(e && e[0] == '0') && n_slices > 1 && ranges >= 16) {
-            ranges &= ~7;
+        // — only where rounding the ranges down to a multiple of 8 does not add a pass over the tile groups
+        const int ranges8 = ranges & ~7;
+        if (!(e && e[0] == '0') && n_slices > 1 && ranges8 >= 8 &&
+            ceil_div(groups, (int64_t)ranges8 * kWaves) == ceil_div(groups, (int64_t)ranges * kWaves)) {
+            ranges = ranges8;
             ga.xcd = 1;
         }
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
