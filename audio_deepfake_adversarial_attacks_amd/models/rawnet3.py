@@ -81,6 +81,12 @@ def _afms_enabled() -> bool:
     return os.environ.get("ADVSTEP_RAWNET3_AFMS", "1") != "0"
 
 
+def _context_split_enabled() -> bool:
+    """ADVSTEP_RAWNET3_CONTEXT=0 builds the concatenated context tensor for the attention convolution (A/B); default on."""
+    import os
+    return os.environ.get("ADVSTEP_RAWNET3_CONTEXT", "1") != "0"
+
+
 def _tail_enabled() -> bool:
     """ADVSTEP_RAWNET3_TAIL=0 keeps activation and `+= residual` / MaxPool1d as two passes (A/B measurements); default on."""
     import os
@@ -431,13 +437,31 @@ class RawNet3(nn.Module):
         x = self.relu(_pointwise_conv1d(torch.cat((x1p, x2, x3), dim=1), self.layer4))
 
         t = x.size()[-1]
-        if self.context:
-            mean = torch.mean(x, dim=2, keepdim=True).repeat(1, 1, t)
-            std = torch.sqrt(torch.var(x, dim=2, keepdim=True).clamp(min=1e-4, max=1e4)).repeat(1, 1, t)
-            global_x = torch.cat((x, mean, std), dim=1)
+        first = self.attention[0]
+        if (self.context and x.is_cuda and _context_split_enabled() and isinstance(first, nn.Conv1d) and first.kernel_size == (1,)
+                and first.stride == (1,) and first.padding == (0,) and first.groups == 1 and first.in_channels == 3 * x.shape[1]):
+            # `attention[0](cat(x, mean.repeat(t), std.repeat(t)))` without the repeated / concatenated (B, 4608, t) tensor: a
+            # kernel-1 convolution of time-constant channels is a per-utterance constant,
+            #     W [x; mean; std] = W_x x + (W_mean mean + W_std std + bias) 1^T,
+            # so the GEMM runs over the 1536 real channels only and the two statistics enter as its (B, 128, 1) C operand.
+            # Plain torch ops (autograd, parameter gradients included); the reduction order differs from the module's.
+            C = x.shape[1]
+            mean = torch.mean(x, dim=2)
+            std = torch.sqrt(torch.var(x, dim=2).clamp(min=1e-4, max=1e4))
+            W = first.weight[:, :, 0]
+            const = mean @ W[:, C:2 * C].t() + std @ W[:, 2 * C:].t()
+            if first.bias is not None:
+                const = const + first.bias
+            h = torch.baddbmm(const.unsqueeze(2), W[:, :C].unsqueeze(0).expand(x.shape[0], -1, -1), x)
+            w = self.attention[1:](h)
         else:
-            global_x = x
-        w = self.attention(global_x)
+            if self.context:
+                mean = torch.mean(x, dim=2, keepdim=True).repeat(1, 1, t)
+                std = torch.sqrt(torch.var(x, dim=2, keepdim=True).clamp(min=1e-4, max=1e4)).repeat(1, 1, t)
+                global_x = torch.cat((x, mean, std), dim=1)
+            else:
+                global_x = x
+            w = self.attention(global_x)
 
         mu = torch.sum(x * w, dim=2)
         sg = torch.sqrt((torch.sum((x ** 2) * w, dim=2) - mu ** 2).clamp(min=1e-4, max=1e4))

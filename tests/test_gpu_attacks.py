@@ -377,3 +377,28 @@ def test_sinc_encoder_as_batched_gemm_and_elementwise_preemphasis(cuda, monkeypa
     assert y1.shape == y0.shape
     assert (y0 - y1).abs().max().item() <= 1e-6 * y0.abs().max().item()
     assert (g0 - g1).abs().max().item() <= 1e-5 * g0.abs().max().item()
+
+
+def test_rawnet3_context_attention_without_the_concatenated_tensor(cuda, monkeypatch):
+    """`attention[0](cat(x, mean.repeat, std.repeat))` computed as W_x x + (W_mean mean + W_std std + b) (models/rawnet3.py): same
+    logits and waveform-gradient statistics as with the materialised (B, 4608, t) tensor, parameters requiring grad included
+    (plain torch ops: the parameter gradients must agree too)."""
+    from audio_deepfake_adversarial_attacks_amd.models.models import get_model
+    torch.manual_seed(4)
+    model = get_model("rawnet3", {}, str(cuda)).to(cuda).eval()
+    x = (torch.randn(2, 64_600, generator=torch.Generator().manual_seed(6)) * 0.05).to(cuda)
+
+    def run(split):
+        monkeypatch.setenv("ADVSTEP_RAWNET3_CONTEXT", "1" if split else "0")
+        model.zero_grad(set_to_none=True)
+        a = x.clone().requires_grad_(True)
+        z = model(a)
+        z.sum().backward()
+        return z.detach(), a.grad, model.attention[0].weight.grad.clone(), model.fc6.weight.grad.clone()
+
+    z0, g0, w0, f0 = run(False)
+    z1, g1, w1, f1 = run(True)
+    assert (z0 - z1).abs().max().item() <= 1e-5 * max(z0.abs().max().item(), 1.0)
+    assert (w0 - w1).norm().item() <= 1e-3 * w0.norm().item()       # float32 sums over 27 456 positions in another order
+    assert (f0 - f1).norm().item() <= 1e-3 * f0.norm().item()
+    assert ((g0 - g1).abs() / g0.abs().clamp_min(1e-12)).median().item() <= 1e-3
