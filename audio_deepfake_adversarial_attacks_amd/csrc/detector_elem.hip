@@ -535,6 +535,46 @@ __global__ __launch_bounds__(kBlock) void afms_row_kernel(const float *__restric
     }
 }
 
+// ---- RawNet3's attentive statistics (src/models/rawnet3.py:131-132): mu = sum_t x w,  m2 = sum_t x^2 w  per (n, c) row ---------------
+// One wave per row (L = 429 frames): forward reads x and w once; backward  g_x = g_mu w + 2 g_m2 x w,  g_w = g_mu x + g_m2 x^2.
+constexpr int kRowsPerBlock = kBlock / 64;
+
+__global__ __launch_bounds__(kBlock) void wstats_forward_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                                float *__restrict__ mu, float *__restrict__ m2, int64_t rows, int64_t L) {
+    const int64_t row = (int64_t)blockIdx.x * kRowsPerBlock + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    float a = 0.0f, b = 0.0f;
+    for (int64_t i = lane; i < L; i += 64) {
+        const float xv = x[row * L + i], wv = w[row * L + i];
+        a += xv * wv;
+        b += (xv * xv) * wv;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        a += __shfl_down(a, o, 64);
+        b += __shfl_down(b, o, 64);
+    }
+    if (lane == 0) {
+        mu[row] = a;
+        m2[row] = b;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void wstats_backward_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                                 const float *__restrict__ gmu, const float *__restrict__ gm2,
+                                                                 float *__restrict__ gx, float *__restrict__ gw, int64_t rows, int64_t L) {
+    const int64_t row = (int64_t)blockIdx.x * kRowsPerBlock + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float ga = gmu[row], gb = gm2[row];
+    for (int64_t i = lane; i < L; i += 64) {
+        const float xv = x[row * L + i], wv = w[row * L + i];
+        gx[row * L + i] = ga * wv + (2.0f * gb) * (xv * wv);
+        gw[row * L + i] = ga * xv + gb * (xv * xv);
+    }
+}
+
 inline bool pool_dims_ok(int64_t N, int64_t C, int64_t H, int64_t W) {
     // planes on grid.x, tiles of a plane on grid.y (<= 65535 workgroups of 256 threads per plane)
     return N >= 0 && C >= 0 && H >= 0 && W >= 0 && N * C <= 0x7fffffffLL && H * ((W + 3) / 4) <= 65535LL * kBlock;
@@ -622,6 +662,26 @@ int advstep_afms_row_f32(int mode, const float *a, const float *b, const float *
     else if (mode == 1) hipLaunchKernelGGL(afms_row_kernel<1>, grid, block, 0, st, a, b, alpha, r0, r1, out, C, L);
     else if (mode == 2) hipLaunchKernelGGL(afms_row_kernel<2>, grid, block, 0, st, a, b, alpha, r0, r1, out, C, L);
     else hipLaunchKernelGGL(afms_row_kernel<3>, grid, block, 0, st, a, b, alpha, r0, r1, out, C, L);
+    return status_after_launch();
+}
+
+int advstep_weighted_stats_forward_f32(const float *x, const float *w, float *mu, float *m2, int64_t rows, int64_t L,
+                                       advstep_stream_t stream) {
+    if (rows < 0 || L < 0 || rows > 0x7fffffffLL) return ADVSTEP_EINVAL;
+    if (rows == 0) return ADVSTEP_OK;
+    if (!x || !w || !mu || !m2) return ADVSTEP_EINVAL;
+    hipLaunchKernelGGL(wstats_forward_kernel, dim3((unsigned)ceil_div(rows, kRowsPerBlock)), dim3(kBlock), 0, as_stream(stream), x, w, mu,
+                       m2, rows, L);
+    return status_after_launch();
+}
+
+int advstep_weighted_stats_backward_f32(const float *x, const float *w, const float *gmu, const float *gm2, float *gx, float *gw,
+                                        int64_t rows, int64_t L, advstep_stream_t stream) {
+    if (rows < 0 || L < 0 || rows > 0x7fffffffLL) return ADVSTEP_EINVAL;
+    if (rows * L == 0) return ADVSTEP_OK;
+    if (!x || !w || !gmu || !gm2 || !gx || !gw) return ADVSTEP_EINVAL;
+    hipLaunchKernelGGL(wstats_backward_kernel, dim3((unsigned)ceil_div(rows, kRowsPerBlock)), dim3(kBlock), 0, as_stream(stream), x, w,
+                       gmu, gm2, gx, gw, rows, L);
     return status_after_launch();
 }
 

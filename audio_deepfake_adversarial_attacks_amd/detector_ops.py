@@ -252,6 +252,40 @@ def afms(x: torch.Tensor, alpha: torch.Tensor, weight: torch.Tensor, bias: Optio
     return _Afms.apply(x.contiguous(), alpha.reshape(-1).contiguous(), weight, bias)
 
 
+class _WeightedStats(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w):
+        _require(x, "x"), _require(w, "w")
+        if x.shape != w.shape or x.dim() != 3:
+            raise ValueError("x and w must be (N, C, L) tensors of the same shape")
+        N, C, L = x.shape
+        mu = torch.empty((N, C), dtype=x.dtype, device=x.device)
+        m2 = torch.empty_like(mu)
+        with _Launch("weighted_stats_forward", x.device):
+            st = _lib.load().advstep_weighted_stats_forward_f32(x.data_ptr(), w.data_ptr(), mu.data_ptr(), m2.data_ptr(), N * C, L,
+                                                                _stream(x.device))
+        _lib.check(st, "advstep_weighted_stats_forward_f32")
+        ctx.save_for_backward(x, w)
+        return mu, m2
+
+    @staticmethod
+    def backward(ctx, gmu, gm2):
+        x, w = ctx.saved_tensors
+        N, C, L = x.shape
+        gx, gw = torch.empty_like(x), torch.empty_like(w)
+        with _Launch("weighted_stats_backward", x.device):
+            st = _lib.load().advstep_weighted_stats_backward_f32(x.data_ptr(), w.data_ptr(), gmu.contiguous().data_ptr(),
+                                                                 gm2.contiguous().data_ptr(), gx.data_ptr(), gw.data_ptr(), N * C, L,
+                                                                 _stream(x.device))
+        _lib.check(st, "advstep_weighted_stats_backward_f32")
+        return gx, gw
+
+
+def weighted_stats(x: torch.Tensor, w: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(sum_t x w, sum_t x^2 w) over the last dimension of two (N, C, L) tensors; differentiable in both."""
+    return _WeightedStats.apply(x.contiguous(), w.contiguous())
+
+
 class _LogMeanNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y, eps):

@@ -463,8 +463,12 @@ class RawNet3(nn.Module):
                 global_x = x
             w = self.attention(global_x)
 
-        mu = torch.sum(x * w, dim=2)
-        sg = torch.sqrt((torch.sum((x ** 2) * w, dim=2) - mu ** 2).clamp(min=1e-4, max=1e4))
+        if x.is_cuda and x.dtype == torch.float32 and w.shape == x.shape and _fused_elem_enabled():
+            from .. import detector_ops as D
+            mu, m2 = D.weighted_stats(x, w)                   # both weighted sums in one pass each way
+        else:
+            mu, m2 = torch.sum(x * w, dim=2), torch.sum((x ** 2) * w, dim=2)
+        sg = torch.sqrt((m2 - mu ** 2).clamp(min=1e-4, max=1e4))
         x = self.fc6(self.bn5(torch.cat((mu, sg), 1)))
         return self.bn6(x) if self.out_bn else x
 

@@ -343,3 +343,21 @@ def test_afms_matches_the_torch_module(D, cuda, shape):
         p.requires_grad_(False)
     c = x.clone().requires_grad_(True)
     assert torch.equal(mod(c), y1)                                # frozen module takes the same path
+
+
+@pytest.mark.parametrize("shape", [(2, 1536, 429), (3, 5, 7), (1, 2, 1), (2, 3, 130)])
+def test_weighted_stats_match_the_torch_expressions(D, cuda, shape):
+    """(sum x w, sum x^2 w) and both gradients against torch with autograd; row sums run in another order (2e-6 of the scale),
+    the gradients are elementwise (bit-identical products, one rounding apart at most)."""
+    x, w = rnd(shape, 1, cuda), torch.softmax(rnd(shape, 2, cuda), dim=2)
+    gmu, gm2 = rnd(shape[:2], 3, cuda), rnd(shape[:2], 4, cuda)
+    a, b = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    mu0, m20 = torch.sum(a * b, dim=2), torch.sum((a ** 2) * b, dim=2)
+    ga0, gb0 = torch.autograd.grad((mu0, m20), (a, b), (gmu, gm2))
+    c, d = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    mu1, m21 = D.weighted_stats(c, d)
+    ga1, gb1 = torch.autograd.grad((mu1, m21), (c, d), (gmu, gm2))
+    for r, o in ((mu0, mu1), (m20, m21)):
+        assert (r - o).abs().max().item() <= 2e-6 * max(r.abs().max().item(), 1.0)
+    for r, o in ((ga0, ga1), (gb0, gb1)):
+        assert (r - o).abs().max().item() <= 2e-6 * max(r.abs().max().item(), 1e-30)
