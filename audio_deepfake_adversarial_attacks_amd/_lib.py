@@ -62,6 +62,8 @@ SIGNATURES = {
     "advstep_conv3x3_mfm_backward_f32": (ctypes.c_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _p]),
     "advstep_conv3x3_backward_data_f32": (ctypes.c_int, [_p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p]),
     "advstep_afms_row_f32": (ctypes.c_int, [ctypes.c_int, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _p]),
+    "advstep_gate_maxpool2_backward_gate_f32": (ctypes.c_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _p]),
+    "advstep_gate_maxpool2_backward_input_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p]),
     "advstep_weighted_stats_forward_f32": (ctypes.c_int, [_p, _p, _p, _p, _i64, _i64, _p]),
     "advstep_weighted_stats_backward_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _p]),
     "advstep_log_meannorm_max_length": (ctypes.c_int, []),

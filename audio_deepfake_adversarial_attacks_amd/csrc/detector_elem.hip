@@ -307,11 +307,13 @@ __global__ __launch_bounds__(kBlock) void pool2_forward_kernel(const float *__re
 }
 
 // thread = one input row segment of 4 floats (2 pooled outputs); writes the full-resolution gradient incl. odd tails
+// g == nullptr: only the gate's partial sums (GATE); addc (per plane, may be null): a constant added to EVERY element of the
+// plane — the share of d x that arrives through the gate's `mean_t x` (SpecRNet's attention: detector_ops._AttendPool).
 template <bool GATE>
 __global__ __launch_bounds__(kBlock) void pool2_backward_kernel(const float *__restrict__ gy, const uint8_t *__restrict__ sel,
                                                                 const float *__restrict__ x, const float *__restrict__ gate,
                                                                 float *__restrict__ g, float *__restrict__ partial, int H,
-                                                                int W, int blocks) {
+                                                                int W, int blocks, const float *__restrict__ addc) {
     const int64_t nc = blockIdx.x;
     const int Ho = H >> 1, Wo = W >> 1;
     const int Wq = (W + 3) >> 2;                                  // 4-float segments per input row
@@ -321,7 +323,8 @@ __global__ __launch_bounds__(kBlock) void pool2_backward_kernel(const float *__r
         const int h = (int)(idx / Wq), q = (int)(idx - (int64_t)h * Wq), w0 = 4 * q;
         const int i = h >> 1, dh = h & 1;
         const float gt = GATE ? gate[nc] : 1.0f;
-        float out[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        const float c0 = addc ? addc[nc] : 0.0f;
+        float out[4] = {c0, c0, c0, c0};
         if (i < Ho) {
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
@@ -331,20 +334,22 @@ __global__ __launch_bounds__(kBlock) void pool2_backward_kernel(const float *__r
                     const int code = sel[o];
                     if ((code >> 1) == dh) {
                         const float gv = gy[o];
-                        out[2 * e + (code & 1)] = gv * gt;
-                        if (GATE) acc += gv * (x[(nc * H + h) * W + w0 + 2 * e + (code & 1)] + 1.0f);
+                        out[2 * e + (code & 1)] = gv * gt + c0;
+                        if (GATE && partial) acc += gv * (x[(nc * H + h) * W + w0 + 2 * e + (code & 1)] + 1.0f);
                     }
                 }
             }
         }
-        float *gp = g + (nc * H + h) * W + w0;
-        if (w0 + 3 < W && (W & 3) == 0) *reinterpret_cast<float4 *>(gp) = make_float4(out[0], out[1], out[2], out[3]);
-        else
+        if (g) {
+            float *gp = g + (nc * H + h) * W + w0;
+            if (w0 + 3 < W && (W & 3) == 0) *reinterpret_cast<float4 *>(gp) = make_float4(out[0], out[1], out[2], out[3]);
+            else
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (w0 + e < W) gp[e] = out[e];
+                for (int e = 0; e < 4; ++e)
+                    if (w0 + e < W) gp[e] = out[e];
+        }
     }
-    if (GATE) {
+    if (GATE && partial) {
         // fixed-order workgroup sum: wave butterfly, then the 4 wave sums in index order
         __shared__ float ws[kBlock / 64];
 #pragma unroll
@@ -665,6 +670,30 @@ int advstep_afms_row_f32(int mode, const float *a, const float *b, const float *
     return status_after_launch();
 }
 
+int advstep_gate_maxpool2_backward_gate_f32(const float *gy, const uint8_t *sel, const float *x, float *ggate_partial, int64_t N,
+                                            int64_t C, int64_t H, int64_t W, advstep_stream_t stream) {
+    if (!pool_dims_ok(N, C, H, W)) return ADVSTEP_EINVAL;
+    if (N * C * H * W == 0) return ADVSTEP_OK;
+    if (!ggate_partial || !x || ((H / 2) * (W / 2) > 0 && (!gy || !sel))) return ADVSTEP_EINVAL;
+    const int blocks = (int)advstep_gate_maxpool2_blocks(H, W);
+    const dim3 grid((unsigned)(N * C), (unsigned)blocks), block(kBlock);
+    hipLaunchKernelGGL(pool2_backward_kernel<true>, grid, block, 0, as_stream(stream), gy, sel, x, x, (float *)nullptr, ggate_partial,
+                       (int)H, (int)W, blocks, (const float *)nullptr);
+    return status_after_launch();
+}
+
+int advstep_gate_maxpool2_backward_input_f32(const float *gy, const uint8_t *sel, const float *gate, const float *addc, float *gx,
+                                             int64_t N, int64_t C, int64_t H, int64_t W, advstep_stream_t stream) {
+    if (!pool_dims_ok(N, C, H, W)) return ADVSTEP_EINVAL;
+    if (N * C * H * W == 0) return ADVSTEP_OK;
+    if (!gx || !gate || ((H / 2) * (W / 2) > 0 && (!gy || !sel))) return ADVSTEP_EINVAL;
+    const int blocks = (int)advstep_gate_maxpool2_blocks(H, W);
+    const dim3 grid((unsigned)(N * C), (unsigned)blocks), block(kBlock);
+    hipLaunchKernelGGL(pool2_backward_kernel<true>, grid, block, 0, as_stream(stream), gy, sel, (const float *)nullptr, gate, gx,
+                       (float *)nullptr, (int)H, (int)W, blocks, addc);
+    return status_after_launch();
+}
+
 int advstep_weighted_stats_forward_f32(const float *x, const float *w, float *mu, float *m2, int64_t rows, int64_t L,
                                        advstep_stream_t stream) {
     if (rows < 0 || L < 0 || rows > 0x7fffffffLL) return ADVSTEP_EINVAL;
@@ -740,7 +769,7 @@ int advstep_maxpool2_backward_f32(const float *gy, const uint8_t *sel, float *g,
     if (!g || ((H / 2) * (W / 2) > 0 && (!gy || !sel))) return ADVSTEP_EINVAL;
     const dim3 grid((unsigned)(N * C), (unsigned)ceil_div(H * ((W + 3) / 4), kBlock)), block(kBlock);
     hipLaunchKernelGGL(pool2_backward_kernel<false>, grid, block, 0, as_stream(stream), gy, sel, (const float *)nullptr,
-                       (const float *)nullptr, g, (float *)nullptr, (int)H, (int)W, 0);
+                       (const float *)nullptr, g, (float *)nullptr, (int)H, (int)W, 0, (const float *)nullptr);
     return status_after_launch();
 }
 
@@ -770,7 +799,7 @@ int advstep_gate_maxpool2_backward_f32(const float *gy, const uint8_t *sel, cons
     const int blocks = (int)advstep_gate_maxpool2_blocks(H, W);
     const dim3 grid((unsigned)(N * C), (unsigned)blocks), block(kBlock);
     hipLaunchKernelGGL(pool2_backward_kernel<true>, grid, block, 0, as_stream(stream), gy, sel, x, gate, gx, ggate_partial, (int)H,
-                       (int)W, blocks);
+                       (int)W, blocks, (const float *)nullptr);
     return status_after_launch();
 }
 

@@ -403,6 +403,52 @@ class _GateMaxPool2(torch.autograd.Function):
         return gx, partial.sum(dim=1).view_as(gate)
 
 
+class _AttendPool(torch.autograd.Function):
+    """MaxPool2d(2)(x * g + g), g = sigmoid(fc(mean_hw x)) — SpecRNet's attention + pooling after a block (specrnet.py:145-149,
+    163-172) with a frozen fc; input gradient only.  Backward: the gate's partial sums, sigmoid' and fc^T on (N, C), then ONE
+    pass writes  gate * scatter(gy) + (the mean's share of d x)  — autograd ran the gate-pool backward, materialised the
+    broadcast of the mean's gradient and added the two x-sized tensors."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _require(x, "x")
+        N, C, H, W = x.shape
+        mean = torch.empty((N, C), dtype=x.dtype, device=x.device)
+        _afms_row(0, x, None, None, None, None, mean, N * C, C, H * W)
+        gate = torch.sigmoid(torch.addmm(bias, mean, weight.t()) if bias is not None else mean @ weight.t()).contiguous()
+        y = torch.empty((N, C, H // 2, W // 2), dtype=x.dtype, device=x.device)
+        sel = torch.empty(max(y.numel(), 1), dtype=torch.uint8, device=x.device)
+        st = _lib.load().advstep_gate_maxpool2_forward_f32(x.data_ptr(), gate.data_ptr(), y.data_ptr(), sel.data_ptr(), N, C, H, W,
+                                                           _stream(x.device))
+        _lib.check(st, "advstep_gate_maxpool2_forward_f32")
+        ctx.save_for_backward(x, sel, gate, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, sel, gate, weight = ctx.saved_tensors
+        N, C, H, W = x.shape
+        gy = gy.contiguous()
+        lib = _lib.load()
+        blocks = max(lib.advstep_gate_maxpool2_blocks(H, W), 1)
+        partial = torch.empty((N * C, blocks), dtype=x.dtype, device=x.device)
+        st = lib.advstep_gate_maxpool2_backward_gate_f32(gy.data_ptr(), sel.data_ptr(), x.data_ptr(), partial.data_ptr(), N, C, H, W,
+                                                         _stream(x.device))
+        _lib.check(st, "advstep_gate_maxpool2_backward_gate_f32")
+        ggate = partial.sum(dim=1).view(N, C)
+        g_mean = (((ggate * gate * (1.0 - gate)) @ weight) / float(H * W)).contiguous()
+        gx = torch.empty_like(x)
+        st = lib.advstep_gate_maxpool2_backward_input_f32(gy.data_ptr(), sel.data_ptr(), gate.data_ptr(), g_mean.data_ptr(),
+                                                          gx.data_ptr(), N, C, H, W, _stream(x.device))
+        _lib.check(st, "advstep_gate_maxpool2_backward_input_f32")
+        return gx, None, None
+
+
+def attend_pool(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """MaxPool2d(2)(x * g + g) with g = sigmoid(fc(mean_hw x)) over (N, C, H, W); fc frozen, differentiable in x."""
+    return _AttendPool.apply(x.contiguous(), weight, bias)
+
+
 def gate_maxpool2(x: torch.Tensor, gate: torch.Tensor) -> torch.Tensor:
     """MaxPool2d(2)(x * gate[n, c] + gate[n, c]), gate (N, C) or (N, C, 1, 1); differentiable in x and gate."""
     return _GateMaxPool2.apply(x.contiguous(), gate.contiguous())

@@ -142,6 +142,10 @@ class BaseSpecRNet(nn.Module):
         are one pass (detector_ops.gate_maxpool2: differentiable in the features and in the gate)."""
         if feats.is_cuda and feats.dtype == torch.float32 and _fused_elem_enabled():
             from .. import detector_ops
+            lin = fc[0] if isinstance(fc, nn.Sequential) and len(fc) == 1 else fc
+            if (isinstance(lin, nn.Linear) and feats.dim() == 4
+                    and not (torch.is_grad_enabled() and any(p.requires_grad for p in lin.parameters()))):
+                return detector_ops.attend_pool(feats, lin.weight.detach(), None if lin.bias is None else lin.bias.detach())
             gate = self.sig(fc(self.avgpool(feats).view(feats.size(0), -1)))
             return detector_ops.gate_maxpool2(feats, gate)
         return self.pool(self._attend(feats, fc))

@@ -88,6 +88,14 @@ int advstep_log_meannorm_backward_f32(const float *gx, const float *y, float eps
 int advstep_afms_row_f32(int mode, const float *a, const float *b, const float *alpha, const float *r0, const float *r1, float *out,
                          int64_t rows, int64_t C, int64_t L, advstep_stream_t stream);
 
+/* The same backward in two halves, for a gate that is itself a function of x (SpecRNet: gate = sigmoid(fc(mean x)), specrnet.py:145-149):
+ * first the gate's partial sums alone, then — once the caller has pushed them through sigmoid' and fc^T — gx = gate * scatter(gy) +
+ * addc[n, c], addc = the mean's share of d x (may be NULL).  Replaces the full backward + a broadcast + an add over x-sized tensors. */
+int advstep_gate_maxpool2_backward_gate_f32(const float *gy, const uint8_t *sel, const float *x, float *ggate_partial, int64_t N,
+                                            int64_t C, int64_t H, int64_t W, advstep_stream_t stream);
+int advstep_gate_maxpool2_backward_input_f32(const float *gy, const uint8_t *sel, const float *gate, const float *addc, float *gx,
+                                             int64_t N, int64_t C, int64_t H, int64_t W, advstep_stream_t stream);
+
 /* ---- RawNet3's attentive statistics (src/models/rawnet3.py:131-132: `sum(x * w, dim=2)`, `sum((x ** 2) * w, dim=2)`) ------------
  * forward:  mu[row] = sum_L x w,  m2[row] = sum_L (x x) w   over (rows = N * C, L) tensors x (features) and w (attention weights)
  * backward: gx = gmu[row] w + 2 gm2[row] x w,   gw = gmu[row] x + gm2[row] x x

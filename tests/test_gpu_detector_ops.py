@@ -361,3 +361,23 @@ def test_weighted_stats_match_the_torch_expressions(D, cuda, shape):
         assert (r - o).abs().max().item() <= 2e-6 * max(r.abs().max().item(), 1.0)
     for r, o in ((ga0, ga1), (gb0, gb1)):
         assert (r - o).abs().max().item() <= 2e-6 * max(r.abs().max().item(), 1e-30)
+
+
+@pytest.mark.parametrize("shape", [(2, 20, 40, 202), (3, 5, 7, 9), (2, 64, 10, 50), (1, 3, 2, 12), (1, 4, 5, 25)])
+def test_attend_pool_matches_the_torch_chain(D, cuda, shape):
+    """detector_ops.attend_pool (mean -> fc -> sigmoid -> x * g + g -> MaxPool2d(2), frozen fc) against the torch ops with
+    autograd: pooled values to 2e-6 of the scale, input gradient to 2e-5 relative (the mean and the gate's gradient are row
+    sums in another order)."""
+    N, C, H, W = shape
+    torch.manual_seed(9)
+    fc = torch.nn.Linear(C, C).to(cuda)
+    x, gy = rnd(shape, 1, cuda), rnd((N, C, H // 2, W // 2), 2, cuda)
+    a = x.clone().requires_grad_(True)
+    g0 = torch.sigmoid(fc(a.mean(dim=(2, 3)))).view(N, C, 1, 1)
+    y0 = F.max_pool2d(a * g0 + g0, 2)
+    (ga0,) = torch.autograd.grad(y0, a, gy)
+    b = x.clone().requires_grad_(True)
+    y1 = D.attend_pool(b, fc.weight.detach(), fc.bias.detach())
+    (ga1,) = torch.autograd.grad(y1, b, gy)
+    assert (y0 - y1).abs().max().item() <= 2e-6 * max(y0.abs().max().item(), 1.0)
+    assert (ga0 - ga1).norm().item() <= 2e-5 * ga0.norm().item()
