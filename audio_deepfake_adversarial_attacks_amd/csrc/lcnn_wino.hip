@@ -207,7 +207,7 @@ __global__ void wino_prepare_plain_kernel(const float *__restrict__ w3, const fl
 //     instructions instead of multiplying 16 zero rows.  slice0: first slice of this launch.
 // GEN (SRC 0 only): the reduction runs over the channels of TWO dense tensors, x (K1 channels, K1 % 4 == 0 when x2 is
 //     given) then x2 (Kreal - K1 channels) — a 1x1 convolution of x2 added to the 3x3 convolution of x is the same
-//     reduction with centre-tap-only weights — and Kreal need not fill the last k-steps: K is Kreal rounded up to 8,
+//     reduction with centre-tap-only weights — and Kreal need not fill the last k-step: K is Kreal rounded up to 4 (>= 8),
 //     channels >= Kreal get an out-of-range offset (read 0; their U rows are 0 as well).
 struct GenArgs {
     const float *x2;
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restri
         step(db, 1, a_ptr(1, 0), std::false_type{});
         if (STREAM) copy_chunk(1, 1);   // chunks >= 2 always here; lands while chunk 0's last steps run
 #pragma unroll 1
-        for (int s = 2; s < steps; s += 2) {
+        for (int s = 2; s + 1 < steps; s += 2) {
             if (STREAM && (s & 3) == 0) {
                 __syncthreads();        // chunk s/4 is complete in its buffer; chunk s/4 - 1 is free
                 if (s / 4 + 1 < chunks) copy_chunk(s / 4 + 1, (s / 4 + 1) & 1);
@@ -445,6 +445,13 @@ __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restri
             step(da, s, a_ptr(s, buf), std::false_type{});
             if (s + 2 < steps) load_patch(da, s + 2);
             step(db, s + 1, a_ptr(s + 1, buf), std::false_type{});
+        }
+        if (GEN && (steps & 1)) {
+            // an odd number of k-steps (K a multiple of 4, not of 8 — SpecRNet's 20-channel layers: 5 steps instead of 6): the last
+            // one on its own; its patch was requested by the last pair (or by the prologue when steps == 3)
+            const int s = steps - 1;
+            if (STREAM && (s & 3) == 0) __syncthreads();        // its chunk was copied one pair earlier
+            step(da, s, a_ptr(s, STREAM ? ((s >> 2) & 1) : (s >> 2)), std::false_type{});
         }
 
         // epilogue: Y = A^T M A per (channel, tile)
@@ -784,7 +791,7 @@ int advstep_resconv_forward_f32(const float *x1, const float *x2, const float *U
     WINO_REQUIRE(N >= 0 && H >= 0 && W >= 0 && advstep_resconv_supported(K1, K2, rows));
     if (N == 0 || H == 0 || W == 0) return ADVSTEP_OK;
     if (const int st = resconv_check(x1, x2, U, y, N, K1, K2, rows, H, W)) return st;
-    const int64_t K = ceil_div(K1 + K2, 8) * 8;
+    const int64_t K = (K1 + K2 <= 8) ? 8 : ceil_div(K1 + K2, 4) * 4;      // at least two k-steps; an odd count is fine
     return launch_wino<3, 0, true>(x1, nullptr, U, shift, nullptr, nullptr, y, nullptr, N, K, H, W, rows, (int)ceil_div(rows, 32),
                                    as_stream(stream), GenArgs{x2, (int)K1, (int)(K1 + K2), slope, 0});
 }
@@ -796,7 +803,7 @@ int advstep_resconv_pool2_forward_f32(const float *x1, const float *x2, const fl
     if (N == 0 || H / 2 == 0 || W / 2 == 0) return ADVSTEP_OK;
     WINO_REQUIRE(sel);
     if (const int st = resconv_check(x1, x2, U, y, N, K1, K2, rows, H, W)) return st;
-    const int64_t K = ceil_div(K1 + K2, 8) * 8;
+    const int64_t K = (K1 + K2 <= 8) ? 8 : ceil_div(K1 + K2, 4) * 4;      // at least two k-steps; an odd count is fine
     return launch_wino<4, 0, true>(x1, nullptr, U, bias, nullptr, nullptr, y, sel, N, K, H, W, rows, (int)ceil_div(rows, 32),
                                    as_stream(stream), GenArgs{x2, (int)K1, (int)(K1 + K2), 1.0f, 0});
 }
@@ -812,7 +819,7 @@ int advstep_resconv_pooled_grad_f32(const float *gy, const uint8_t *sel, const f
     WINO_REQUIRE(gy && sel && U);
     WINO_REQUIRE((uint64_t)N * K * (H / 2) * (W / 2) < (1ull << 29) && (uint64_t)N * rows * H * W * 4 < (1ull << 33) &&
                  (uint64_t)N * ((H + 1) / 2) * ((W + 1) / 2) < (1ull << 31));
-    const int64_t Kp = ceil_div(K, 8) * 8;
+    const int64_t Kp = K <= 8 ? 8 : ceil_div(K, 4) * 4;
     const GenArgs ga{nullptr, (int)K, (int)K, slope, 0};
     if (h)
         return launch_wino<5, 2, true>(gy, sel, U, nullptr, h, nullptr, g, nullptr, N, Kp, H, W, rows, (int)ceil_div(rows, 32),
