@@ -61,7 +61,7 @@ def main():
     run("configs[2] SpecRNet+mel, PGDL2-40 eps 0.1 (white box)", "specrnet_melspec", "specrnet_melspec", "PGDL2_40", 128, args.batches)
     run("configs[3] RawNet3 -> LCNN+LFCC, FGSM eps 0.0005", "lcnn", "rawnet3", "FGSM", 64, 2 * args.batches)
     run("configs[3] RawNet3 -> LCNN+LFCC, CW-100 c = 1", "lcnn", "rawnet3", "CW", 64, 5)
-    run("           LCNN+LFCC, FAB (eta 10, 10 steps)", "lcnn", "lcnn", "FAB", 128, args.batches)
+    run("           LCNN+LFCC, FAB (eta 10, 100 steps)", "lcnn", "lcnn", "FAB", 128, args.batches)
 
 
 if __name__ == "__main__":
