@@ -39,7 +39,9 @@ class _AffineAct(torch.autograd.Function):
     def forward(ctx, x, scale, shift, pre, mode, slope):
         _require(x, "x"), _require(scale, "scale"), _require(shift, "shift")
         N, C = x.shape[0], x.shape[1]
-        P = x[0, 0].numel()
+        P = 1
+        for d in x.shape[2:]:
+            P *= d
         if scale.numel() != C or shift.numel() != C or (pre is not None and pre.numel() != C):
             raise ValueError("per-channel constants must have one entry per channel")
         y = torch.empty_like(x)

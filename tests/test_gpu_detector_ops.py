@@ -381,3 +381,23 @@ def test_attend_pool_matches_the_torch_chain(D, cuda, shape):
     (ga1,) = torch.autograd.grad(y1, b, gy)
     assert (y0 - y1).abs().max().item() <= 2e-6 * max(y0.abs().max().item(), 1.0)
     assert (ga0 - ga1).norm().item() <= 2e-5 * ga0.norm().item()
+
+
+def test_round2_detector_ops_accept_empty_batches(D, cuda):
+    """N = 0 (an empty last shard) through every round-2 detector operator: correctly shaped empty outputs, no launch."""
+    e3 = torch.empty((0, 8, 33), device=cuda)
+    c = torch.ones(8, device=cuda)
+    assert D.tail_pool1d(e3, e3, c, c, c, 3).shape == (0, 8, 11)
+    assert D.log_meannorm(e3).shape == (0, 8, 33)
+    mu, m2 = D.weighted_stats(e3, e3)
+    assert mu.shape == (0, 8) and m2.shape == (0, 8)
+    assert D.afms(e3, c, torch.eye(8, device=cuda), c).shape == (0, 8, 33)
+    assert D.affine_selu(e3, c, c).shape == (0, 8, 33)
+    e4 = torch.empty((0, 20, 8, 12), device=cuda)
+    assert D.attend_pool(e4, torch.eye(20, device=cuda), torch.zeros(20, device=cuda)).shape == (0, 20, 4, 6)
+    U = D.resconv_prepare(torch.zeros(20, 20, 3, 3, device=cuda))
+    assert D.resconv(e4, None, U, 20).shape == (0, 20, 8, 12)
+    y, _ = D.resconv_pool2(e4, None, U, 20)
+    assert y.shape == (0, 20, 4, 6)
+    assert D.conv3x3_fewin(torch.empty((0, 2, 8, 12), device=cuda), torch.zeros(20, 2, 3, 3, device=cuda), None, 1.0).shape == (0, 20, 8, 12)
+    assert D.conv3x3_fewout_grad(e4, torch.zeros(20, 2, 3, 3, device=cuda)).shape == (0, 2, 8, 12)
