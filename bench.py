@@ -247,6 +247,15 @@ def main():
         launch_bytes = bytes_per_sample * B * T
         achieved = launch_bytes / (avg_ms * 1e-3) / 1e9
         traffic, provenance = measured_traffic(entry, B)
+        # what an event pair measures with NOTHING between its two records (the command processor's own gap): reported beside
+        # `avg_launch_ms`, not subtracted from it — it is most of the difference to the kernel trace's average duration
+        stream = torch.cuda.current_stream(device)
+        pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(64)]
+        for a, b in pairs:
+            a.record(stream)
+            b.record(stream)
+        torch.cuda.synchronize()
+        empty_ms = sorted(a.elapsed_time(b) for a, b in pairs)[len(pairs) // 2]
         each = [a.elapsed_time(b) for a, b in zip(marks[:-1], marks[1:])]
         k = len(attacks)
         line = {
@@ -284,6 +293,7 @@ def main():
                 "algorithmic_bytes_per_launch": launch_bytes,
                 "avg_launch_ms": avg_ms,
                 "launches_timed": len(step_ms),
+                "empty_event_pair_ms": empty_ms,
             },
             "attack_kernel_ms_per_step": {n: sum(v) / args.steps for n, v in kernel_ms.items() if v},
             "ms_each_step": [round(sum(each[i * k:(i + 1) * k]), 2) for i in range(args.steps)],
