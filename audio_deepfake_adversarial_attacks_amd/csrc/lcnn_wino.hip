@@ -406,6 +406,7 @@ __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restri
             }
             __builtin_amdgcn_sched_barrier(0);
             const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int grp = 0; grp < 8; ++grp) {
                 if (grp + 2 < 8) request(grp + 2);
@@ -418,6 +419,7 @@ __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restri
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            __builtin_amdgcn_s_setprio(0);
         };
         // lane's A address inside a chunk buffer for k-step s: cin_in_chunk = (s & 3) * 4 + g
         auto a_ptr = [&](int s, int buf) { return u_s + buf * kChunkFloats + (((s & 3) * 4 + g) * 16 + nl) * 2; };
