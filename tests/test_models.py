@@ -180,3 +180,63 @@ def test_preemphasis_matches_definition():
     want[:, 1:] = x[:, 1:] - 0.97 * x[:, :-1]
     want[:, 0] = x[:, 0] - 0.97 * x[:, 1]       # reflect padding on the left
     assert torch.allclose(y.squeeze(1), want, atol=1e-6)
+
+
+# ---- round 2: RawNet3's GEMM formulations are plain torch ops, so their arithmetic is pinned on the CPU as well -------------------
+
+def test_rawnet3_dilated_gemm_equals_conv1d_and_its_input_gradient():
+    """models/rawnet3.py:_dilated_gemm (k GEMMs accumulating in place into sub-ranges, `out=` channel slices, transposed taps)
+    against nn.Conv1d with autograd, in float64."""
+    import torch.nn as nn
+    from audio_deepfake_adversarial_attacks_amd.models import rawnet3 as R
+    torch.manual_seed(0)
+    for C, k, d, T in [(8, 3, 2, 40), (8, 3, 4, 9), (4, 5, 3, 30), (4, 3, 4, 5)]:
+        conv = nn.Conv1d(C, C, k, dilation=d, padding=(k // 2) * d).double()
+        big = torch.randn(3, 3 * C, T, dtype=torch.double)
+        x = big[:, C:2 * C].detach().clone().requires_grad_(True)
+        y0 = conv(x)
+        g = torch.randn_like(y0)
+        (g0,) = torch.autograd.grad(y0, x, g)
+        out = torch.zeros(3, 3 * C, T, dtype=torch.double)
+        y1 = R._dilated_gemm(big[:, C:2 * C], conv.weight.detach(), conv.bias.detach(), d, out=out[:, C:2 * C])
+        assert y1.data_ptr() == out[:, C:2 * C].data_ptr() and not out[:, :C].any() and not out[:, 2 * C:].any()
+        assert (y0 - y1).abs().max().item() < 1e-12
+        taps = [conv.weight.detach()[:, :, j].contiguous() for j in range(k)]
+        g1 = R._dilated_gemm(g, taps, None, d, transpose=True)
+        assert (g0 - g1).abs().max().item() < 1e-12
+        x2 = x.detach().clone().requires_grad_(True)
+        y2 = R._SameConv1dFrozen.apply(x2, conv.weight.detach(), conv.bias.detach(), d)
+        (g2,) = torch.autograd.grad(y2, x2, g)
+        assert (y0 - y2).abs().max().item() < 1e-12 and (g0 - g2).abs().max().item() < 1e-12
+
+
+def test_sinc_encoder_gemm_formulation_equals_conv1d():
+    import torch.nn.functional as F
+    from audio_deepfake_adversarial_attacks_amd.models import sincfb
+    torch.manual_seed(1)
+    for B, T, nf, K, st in [(3, 2000, 8, 251, 10), (2, 251, 4, 251, 10), (2, 1003, 6, 31, 7)]:
+        x = torch.randn(B, 1, T, dtype=torch.double, requires_grad=True)
+        w = torch.randn(nf, 1, K, dtype=torch.double)
+        y0 = F.conv1d(x, w, stride=st)
+        g = torch.randn_like(y0)
+        (g0,) = torch.autograd.grad(y0, x, g)
+        x1 = x.detach().clone().requires_grad_(True)
+        y1 = sincfb._StridedCorrelationFrozen.apply(x1, w, st)
+        (g1,) = torch.autograd.grad(y1, x1, g)
+        assert y1.shape == y0.shape and (y0 - y1).abs().max().item() < 1e-12 and (g0 - g1).abs().max().item() < 1e-12
+
+
+def test_context_attention_split_equals_the_concatenated_convolution():
+    """W [x; mean 1^T; std 1^T] = W_x x + (W_mean mean + W_std std + b) 1^T  (models/rawnet3.py, RawNet3.forward)."""
+    import torch.nn as nn
+    torch.manual_seed(2)
+    B, C, T = 3, 16, 9
+    x = torch.randn(B, C, T, dtype=torch.double)
+    conv = nn.Conv1d(3 * C, 8, 1).double()
+    mean = x.mean(2, keepdim=True).repeat(1, 1, T)
+    std = torch.sqrt(x.var(2, keepdim=True).clamp(min=1e-4, max=1e4)).repeat(1, 1, T)
+    ref = conv(torch.cat((x, mean, std), 1))
+    W = conv.weight[:, :, 0]
+    const = x.mean(2) @ W[:, C:2 * C].t() + torch.sqrt(x.var(2).clamp(min=1e-4, max=1e4)) @ W[:, 2 * C:].t() + conv.bias
+    h = torch.baddbmm(const.unsqueeze(2), W[:, :C].unsqueeze(0).expand(B, -1, -1), x)
+    assert (ref - h).abs().max().item() < 1e-12
