@@ -29,6 +29,7 @@ SIGNATURES = {
     "advstep_pgd_l2_init_philox_f32": (ctypes.c_int, [_p, _p, _i64, _i64, _f32, _f32, _f32, _u64, _u64, _p, _sz, _p]),
     "advstep_pgd_l2_step_f32": (ctypes.c_int, [_p, _p, _p, _p, _i64, _i64, _f32, _f32, _f32, _f32, _f32, _p, _p,
                                                _p, _sz, _p]),
+    "advstep_pgd_l2_repaired_rows": (ctypes.c_int, [_p, _sz, _i64, _i64, _p, _p]),
     "advstep_cw_init_w_f32": (ctypes.c_int, [_p, _p, _i64, _p]),
     "advstep_cw_tanh_sqdist_f32": (ctypes.c_int, [_p, _p, _p, _p, _i64, _i64, _p, _sz, _p]),
     "advstep_cw_adam_step_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _i64, _f64, _f64, _f64, _f64, _p]),

@@ -14,6 +14,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared (see build.py).
 
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -558,36 +559,63 @@ __global__ __launch_bounds__(kBlock) void pgd_l2_project_kernel(const float *__r
 // agent-scope store, re-read with agent-scope loads until every tag of the row shows the phase: the data is the flag, no
 // fence — /opt/skills/guides/cdna_hip_programming.md Guideline 16, form R2).  The granules are zeroed by a memset node
 // before every launch; tag = phase (1, 2).  The partial sums and their re-reduction are the three-kernel path's own
-// (same block_reduce, same order): results are bit-identical to it.  Used only when every workgroup of the launch is
-// resident at once (B * C <= 8 per CU * 256 CUs at <= 64 VGPRs), so a spinning workgroup never waits for one that has no
-// slot; spins are bounded all the same.
+// (same block_reduce, same order): results are bit-identical to it.
+//
+// Co-residency.  A spinning workgroup must not wait for one that has no slot.  The host takes this path only when the
+// launch fits the device's resident capacity for THIS kernel (CU count x hipOccupancyMaxActiveBlocksPerMultiprocessor,
+// queried once per device: l2_resident_capacity) — but capacity is not a guarantee: another stream or process may hold
+// slots (two ranks sharing a device, a partitioned device).  So the wait is bounded, and a sweep that does not complete
+// does NOT produce a wrong row: the workgroup raises the row's flag in the workspace, poisons its later granules (its
+// siblings stop waiting at once) and leaves; a repair kernel queued behind every single-pass launch recomputes flagged rows
+// from global memory with the three-kernel path's arithmetic (one workgroup per row, tiles in sequence: same partial sums,
+// same re-reduction, same bits) and returns immediately for all other rows.
 typedef unsigned long long __attribute__((address_space(1))) gu64;
+constexpr unsigned kPoisonTag = 0xFFFFFFFFu;
 
+// Returns the row sum; *failed (workgroup-uniform, valid after the call) tells that the sweep was abandoned.
 __device__ __forceinline__ float row_exchange_sum(unsigned long long *granules, int C, int tile, float mine, unsigned phase,
-                                                  float *lds) {
-    if (threadIdx.x == 0)
+                                                  unsigned spin_limit, float *lds, int *lds_failed) {
+    if (threadIdx.x == 0) {
+        *lds_failed = 0;
         __hip_atomic_store((gu64 *)(granules + tile), ((unsigned long long)phase << 32) | __float_as_uint(mine),
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // (a sweep that never completes — a workgroup of the row that is never scheduled — leaves NaN: the row comes out NaN
-    // instead of the launch hanging or a wrong number passing silently)
-    float v = (int)threadIdx.x < C ? __builtin_nanf("") : 0.0f;
+    }
+    float v = 0.0f;
     if (threadIdx.x < 64) {                       // wave 0 sweeps the row's granules: lane i < C reads granule i
-        for (unsigned spins = 0; spins < (1u << 22); ++spins) {
-            bool ok = true;
+        bool done = false;
+        for (unsigned spins = 0; spins < spin_limit; ++spins) {
+            bool ok = true, poisoned = false;
             unsigned long long x = 0;
             if ((int)threadIdx.x < C) {
                 x = __hip_atomic_load((gu64 *)(granules + threadIdx.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 ok = (unsigned)(x >> 32) == phase;
+                poisoned = (unsigned)(x >> 32) == kPoisonTag;
             }
+            if (__any(poisoned)) break;
             if (__all(ok)) {
                 v = (int)threadIdx.x < C ? __uint_as_float((unsigned)x) : 0.0f;
+                done = true;
                 break;
             }
             __builtin_amdgcn_s_sleep(2);
         }
+        if (!done && threadIdx.x == 0) *lds_failed = 1;
     }
     // same reduction as reduce_partials(): thread i holds partial i (C <= 64 on this path), the others the identity
+    // (block_reduce's barrier also publishes *lds_failed)
     return block_reduce(v, SumOp(), lds);
+}
+
+// A workgroup that gives up: flag the row, poison this workgroup's granules of the phases it will not reach.
+__device__ __forceinline__ void row_exchange_abandon(unsigned *fail, int64_t b, unsigned long long *g0, unsigned long long *g1,
+                                                     int tile) {
+    if (threadIdx.x == 0) {
+        __hip_atomic_store((unsigned __attribute__((address_space(1))) *)(fail + b), 1u, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long poison = (unsigned long long)kPoisonTag << 32;
+        if (g0) __hip_atomic_store((gu64 *)(g0 + tile), poison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (g1) __hip_atomic_store((gu64 *)(g1 + tile), poison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // Register budget: all 2 048 workgroups (8 192 waves) must be resident, i.e. 64 VGPRs per lane, and adv + grad + orig of a tile
@@ -600,9 +628,11 @@ __global__ __launch_bounds__(kBlock, 8) void pgd_l2_fused_kernel(const float *__
                                                                  float alpha, float eps, float eps_div, float lo, float hi,
                                                                  unsigned long long *__restrict__ gran_g,
                                                                  unsigned long long *__restrict__ gran_d,
+                                                                 unsigned *__restrict__ fail, unsigned spin_limit,
                                                                  float *__restrict__ gnorm, float *__restrict__ dnorm) {
     __shared__ float4 xs[kTileVec];
     __shared__ float lds[12];
+    __shared__ int failed;
     const int tile = blockIdx.x, C = gridDim.x;
     const int64_t b = blockIdx.y;
     float4 a[kVecs], g[kVecs];
@@ -618,7 +648,11 @@ __global__ __launch_bounds__(kBlock, 8) void pgd_l2_fused_kernel(const float *__
 #pragma unroll
     for (int j = 0; j < kVecs; ++j) s += (g[j].x * g[j].x + g[j].y * g[j].y) + (g[j].z * g[j].z + g[j].w * g[j].w);
     s = block_reduce(s, SumOp(), lds);
-    const float gsq = row_exchange_sum(gran_g + b * C, C, tile, s, 1u, lds + 4);
+    const float gsq = row_exchange_sum(gran_g + b * C, C, tile, s, 1u, spin_limit, lds + 4, &failed);
+    if (failed) {
+        row_exchange_abandon(fail, b, gran_g + b * C, gran_d + b * C, tile);
+        return;
+    }
     const float gn_raw = sqrtf(gsq);
     const float gn = gn_raw + eps_div;
     s = 0.0f;
@@ -637,7 +671,11 @@ __global__ __launch_bounds__(kBlock, 8) void pgd_l2_fused_kernel(const float *__
         s += (m.x * m.x + m.y * m.y) + (m.z * m.z + m.w * m.w);
     }
     s = block_reduce(s, SumOp(), lds + 8);
-    const float dn = sqrtf(row_exchange_sum(gran_d + b * C, C, tile, s, 2u, lds + 4));
+    const float dn = sqrtf(row_exchange_sum(gran_d + b * C, C, tile, s, 2u, spin_limit, lds + 4, &failed));
+    if (failed) {
+        row_exchange_abandon(fail, b, nullptr, gran_d + b * C, tile);
+        return;
+    }
     const float f = min_nan((1.0f / dn) * eps, 1.0f);
 #pragma unroll
     for (int j = 0; j < kVecs; ++j) {      // d recomputed (same expressions, same bits) rather than kept across the exchange
@@ -657,6 +695,88 @@ __global__ __launch_bounds__(kBlock, 8) void pgd_l2_fused_kernel(const float *__
         if (gnorm) gnorm[b] = gn_raw;
         if (dnorm) dnorm[b] = dn;
     }
+}
+
+// Repair pass of the single-pass step: one workgroup per row, returns at once unless the row's flag is up.  The row's tiles
+// are visited in sequence with the three-kernel path's own expressions and reductions (sumsq_partial / pgd_l2_delta /
+// pgd_l2_project), so a repaired row carries the same bits as any other.  adv / orig / grad are re-read from global memory:
+// the single-pass path is not taken when `out` aliases an input.
+template <bool VEC>
+__global__ __launch_bounds__(kBlock) void pgd_l2_repair_kernel(const float *__restrict__ adv, const float *__restrict__ grad,
+                                                               const float *__restrict__ orig, float *out, int64_t T, int C,
+                                                               float alpha, float eps, float eps_div, float lo, float hi,
+                                                               const unsigned *__restrict__ fail, float *__restrict__ gnorm,
+                                                               float *__restrict__ dnorm) {
+    const int64_t b = blockIdx.x;
+    if (!fail[b]) return;
+    __shared__ float gpart[64], dpart[64], lds[12];
+    float4 a[kVecs], g[kVecs], x[kVecs];
+    for (int tile = 0; tile < C; ++tile) {
+        load_tile<VEC>(grad + b * T, T, tile, 0.0f, g);
+        float s = 0.0f;
+#pragma unroll
+        for (int j = 0; j < kVecs; ++j) s += (g[j].x * g[j].x + g[j].y * g[j].y) + (g[j].z * g[j].z + g[j].w * g[j].w);
+        s = block_reduce(s, SumOp(), lds);
+        if (threadIdx.x == 0) gpart[tile] = s;
+        __syncthreads();
+    }
+    const float gn_raw = sqrtf(reduce_partials(gpart, C, 0.0f, SumOp(), lds + 4));
+    const float gn = gn_raw + eps_div;
+    for (int tile = 0; tile < C; ++tile) {
+        load_tile<VEC>(adv + b * T, T, tile, 0.0f, a);
+        load_tile<VEC>(grad + b * T, T, tile, 0.0f, g);
+        load_tile<VEC>(orig + b * T, T, tile, 0.0f, x);
+        float s = 0.0f;
+#pragma unroll
+        for (int j = 0; j < kVecs; ++j) {
+            float4 d;
+            d.x = (a[j].x + alpha * (g[j].x / gn)) - x[j].x;
+            d.y = (a[j].y + alpha * (g[j].y / gn)) - x[j].y;
+            d.z = (a[j].z + alpha * (g[j].z / gn)) - x[j].z;
+            d.w = (a[j].w + alpha * (g[j].w / gn)) - x[j].w;
+            if (!in_row(T, tile, j, 0)) d.x = 0.0f;
+            if (!in_row(T, tile, j, 1)) d.y = 0.0f;
+            if (!in_row(T, tile, j, 2)) d.z = 0.0f;
+            if (!in_row(T, tile, j, 3)) d.w = 0.0f;
+            s += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+        }
+        s = block_reduce(s, SumOp(), lds);
+        if (threadIdx.x == 0) dpart[tile] = s;
+        __syncthreads();
+    }
+    const float dn = sqrtf(reduce_partials(dpart, C, 0.0f, SumOp(), lds + 8));
+    const float f = min_nan((1.0f / dn) * eps, 1.0f);
+    for (int tile = 0; tile < C; ++tile) {
+        load_tile<VEC>(adv + b * T, T, tile, 0.0f, a);
+        load_tile<VEC>(grad + b * T, T, tile, 0.0f, g);
+        load_tile<VEC>(orig + b * T, T, tile, 0.0f, x);
+#pragma unroll
+        for (int j = 0; j < kVecs; ++j) {
+            float4 d;
+            d.x = (a[j].x + alpha * (g[j].x / gn)) - x[j].x;
+            d.y = (a[j].y + alpha * (g[j].y / gn)) - x[j].y;
+            d.z = (a[j].z + alpha * (g[j].z / gn)) - x[j].z;
+            d.w = (a[j].w + alpha * (g[j].w / gn)) - x[j].w;
+            a[j].x = clampf(x[j].x + d.x * f, lo, hi);
+            a[j].y = clampf(x[j].y + d.y * f, lo, hi);
+            a[j].z = clampf(x[j].z + d.z * f, lo, hi);
+            a[j].w = clampf(x[j].w + d.w * f, lo, hi);
+        }
+        store_tile<VEC>(out + b * T, T, tile, a);
+    }
+    if (threadIdx.x == 0) {
+        if (gnorm) gnorm[b] = gn_raw;
+        if (dnorm) dnorm[b] = dn;
+    }
+}
+
+// rows whose flag is up (diagnostics / tests: how often the repair pass had work)
+__global__ __launch_bounds__(64) void count_flags_kernel(const unsigned *__restrict__ fail, int64_t B, int *__restrict__ count) {
+    int n = 0;
+    for (int64_t i = threadIdx.x; i < B; i += 64) n += fail[i] != 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) n += __shfl_xor(n, off, 64);
+    if (threadIdx.x == 0) *count = n;
 }
 
 // ---- a6: PGD-L2 random start -----------------------------------------------------------------------------------
@@ -750,8 +870,10 @@ template <bool VEC>
 __global__ __launch_bounds__(kBlock, 8) void pgd_l2_init_philox_fused_kernel(const float *__restrict__ x, float *out, int64_t T,
                                                                              float eps, float lo, float hi, uint64_t seed,
                                                                              uint64_t offset,
-                                                                             unsigned long long *__restrict__ gran) {
+                                                                             unsigned long long *__restrict__ gran,
+                                                                             unsigned *__restrict__ fail, unsigned spin_limit) {
     __shared__ float lds[8];
+    __shared__ int failed;
     const int tile = blockIdx.x, C = gridDim.x;
     const int64_t b = blockIdx.y;
     float4 nz[kVecs];
@@ -761,7 +883,11 @@ __global__ __launch_bounds__(kBlock, 8) void pgd_l2_init_philox_fused_kernel(con
     for (int j = 0; j < kVecs; ++j)
         s += (nz[j].x * nz[j].x + nz[j].y * nz[j].y) + (nz[j].z * nz[j].z + nz[j].w * nz[j].w);
     s = block_reduce(s, SumOp(), lds);
-    const float nrm = sqrtf(row_exchange_sum(gran + b * C, C, tile, s, 1u, lds + 4));
+    const float nrm = sqrtf(row_exchange_sum(gran + b * C, C, tile, s, 1u, spin_limit, lds + 4, &failed));
+    if (failed) {
+        row_exchange_abandon(fail, b, gran + b * C, nullptr, tile);
+        return;
+    }
     const uint64_t off1 = offset + 1;
     const Quad rq = philox4x32_10((uint32_t)b, (uint32_t)((uint64_t)b >> 32), (uint32_t)off1, (uint32_t)(off1 >> 32),
                                   (uint32_t)seed, (uint32_t)(seed >> 32));
@@ -776,6 +902,45 @@ __global__ __launch_bounds__(kBlock, 8) void pgd_l2_init_philox_fused_kernel(con
         xv[j].w = clampf(xv[j].w + nz[j].w * scale, lo, hi);
     }
     store_tile<VEC>(out + b * T, T, tile, xv);
+}
+
+// Repair pass of the single-pass start (see pgd_l2_repair_kernel): the two-kernel path's arithmetic, one workgroup per
+// flagged row.
+template <bool VEC>
+__global__ __launch_bounds__(kBlock) void pgd_l2_init_philox_repair_kernel(const float *__restrict__ x, float *out, int64_t T, int C,
+                                                                           float eps, float lo, float hi, uint64_t seed,
+                                                                           uint64_t offset, const unsigned *__restrict__ fail) {
+    const int64_t b = blockIdx.x;
+    if (!fail[b]) return;
+    __shared__ float npart[64], lds[8];
+    float4 nz[kVecs], xv[kVecs];
+    for (int tile = 0; tile < C; ++tile) {
+        philox_normal_tile(T, tile, (uint32_t)b, seed, offset, nz);
+        float s = 0.0f;
+#pragma unroll
+        for (int j = 0; j < kVecs; ++j)
+            s += (nz[j].x * nz[j].x + nz[j].y * nz[j].y) + (nz[j].z * nz[j].z + nz[j].w * nz[j].w);
+        s = block_reduce(s, SumOp(), lds);
+        if (threadIdx.x == 0) npart[tile] = s;
+        __syncthreads();
+    }
+    const float nrm = sqrtf(reduce_partials(npart, C, 0.0f, SumOp(), lds + 4));
+    const uint64_t off1 = offset + 1;
+    const Quad rq = philox4x32_10((uint32_t)b, (uint32_t)((uint64_t)b >> 32), (uint32_t)off1, (uint32_t)(off1 >> 32),
+                                  (uint32_t)seed, (uint32_t)(seed >> 32));
+    const float scale = (u01(rq.v[0]) / nrm) * eps;
+    for (int tile = 0; tile < C; ++tile) {
+        load_tile<VEC>(x + b * T, T, tile, 0.0f, xv);
+        philox_normal_tile(T, tile, (uint32_t)b, seed, offset, nz);
+#pragma unroll
+        for (int j = 0; j < kVecs; ++j) {
+            xv[j].x = clampf(xv[j].x + nz[j].x * scale, lo, hi);
+            xv[j].y = clampf(xv[j].y + nz[j].y * scale, lo, hi);
+            xv[j].z = clampf(xv[j].z + nz[j].z * scale, lo, hi);
+            xv[j].w = clampf(xv[j].w + nz[j].w * scale, lo, hi);
+        }
+        store_tile<VEC>(out + b * T, T, tile, xv);
+    }
 }
 
 // ---- a7: CW -------------------------------------------------------------------------------------------------------
@@ -885,7 +1050,9 @@ inline size_t row_ws_plane(int64_t B, int64_t T) {
     const size_t one = (size_t)B * (size_t)tiles_per_row(T) * sizeof(float);
     return (one + 15) & ~(size_t)15;
 }
-inline size_t row_ws_bytes(int64_t B, int64_t T) { return 4 * row_ws_plane(B, T); }
+// ... followed by one 32-bit "row needs repair" flag per row (single-pass PGD-L2 paths)
+inline size_t row_ws_flags(int64_t B) { return ((size_t)B * sizeof(unsigned) + 15) & ~(size_t)15; }
+inline size_t row_ws_bytes(int64_t B, int64_t T) { return 4 * row_ws_plane(B, T) + row_ws_flags(B); }
 inline bool carve_ws(void *ws, size_t ws_bytes, int64_t B, int64_t T, RowWs *out) {
     if (!ws || !aligned16(ws) || ws_bytes < row_ws_bytes(B, T)) return false;
     out->p0 = static_cast<float *>(ws);
@@ -897,6 +1064,43 @@ inline bool carve_ws(void *ws, size_t ws_bytes, int64_t B, int64_t T, RowWs *out
 inline bool l2_single_pass() {
     const char *e = getenv("ADVSTEP_L2_SINGLE_PASS");
     return !(e && e[0] == '0');
+}
+
+// Bound of the in-launch wait, in sweeps (one sweep = an agent-scope load + s_sleep, ~1 us): ~0.1 s, after which the row goes
+// to the repair pass.  ADVSTEP_L2_SPIN_LIMIT overrides it (0 = every row gives up at once: tests of the repair pass).
+inline unsigned l2_spin_limit() {
+    const char *e = getenv("ADVSTEP_L2_SPIN_LIMIT");
+    if (e && *e) return (unsigned)strtoul(e, nullptr, 10);
+    return 1u << 17;
+}
+
+// How many workgroups of `kernel` (kBlock threads, its static LDS) the CURRENT device holds at once: CU count x the
+// occupancy the runtime computes for this kernel's registers / LDS.  Queried once per (device, kernel); 0 if the query
+// fails (the caller then takes the multi-kernel path).  ADVSTEP_L2_CAPACITY overrides it (tests: a "smaller device").
+enum { kCapStepVec, kCapStepScalar, kCapInitVec, kCapInitScalar, kCapKinds };
+inline int64_t l2_resident_capacity(int kind, const void *kernel) {
+    const char *e = getenv("ADVSTEP_L2_CAPACITY");
+    if (e && *e) return (int64_t)strtoll(e, nullptr, 10);
+    static std::atomic<int64_t> cache[kCapKinds][64];      // zero-initialised: 0 = not queried yet, -1 = query failed
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    int64_t c = cache[kind][dev].load(std::memory_order_relaxed);
+    if (c == 0) {
+        int cus = 0, per_cu = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0) == hipSuccess && cus > 0 && per_cu > 0)
+            c = (int64_t)cus * per_cu;
+        else
+            c = -1;
+        (void)hipGetLastError();
+        cache[kind][dev].store(c, std::memory_order_relaxed);
+    }
+    return c > 0 ? c : 0;
+}
+
+inline bool overlaps(const void *a, const void *b, size_t bytes) {
+    const uintptr_t x = reinterpret_cast<uintptr_t>(a), y = reinterpret_cast<uintptr_t>(b);
+    return x < y + bytes && y < x + bytes;
 }
 
 // grid.y is limited to 65535 rows per launch; batches beyond that are launched in slabs.
@@ -1113,16 +1317,25 @@ int advstep_pgd_l2_init_philox_f32(const float *x, float *out, int64_t B, int64_
     hipStream_t st = as_stream(stream);
     const bool vec = rows_vec(T, {x, out});
     const int C = tiles_per_row(T);
-    if (l2_single_pass() && C <= 64 && B * C <= 8 * 256) {
-        const size_t plane = 2 * row_ws_plane(B, T);
-        if (hipMemsetAsync(ws, 0, plane, st) != hipSuccess) return ADVSTEP_ELAUNCH;
+    const void *fused = vec ? (const void *)pgd_l2_init_philox_fused_kernel<true> : (const void *)pgd_l2_init_philox_fused_kernel<false>;
+    if (l2_single_pass() && C <= 64 && !overlaps(x, out, (size_t)B * T * sizeof(float)) &&
+        B * C <= l2_resident_capacity(vec ? kCapInitVec : kCapInitScalar, fused)) {
+        // granules + row flags zeroed by one memset node; the repair kernel behind the launch serves flagged rows
+        if (hipMemsetAsync(ws, 0, row_ws_bytes(B, T), st) != hipSuccess) return ADVSTEP_ELAUNCH;
         unsigned long long *gran = static_cast<unsigned long long *>(ws);
-        if (vec)
+        unsigned *fail = reinterpret_cast<unsigned *>(static_cast<char *>(ws) + 4 * row_ws_plane(B, T));
+        const unsigned spins = l2_spin_limit();
+        if (vec) {
             hipLaunchKernelGGL(pgd_l2_init_philox_fused_kernel<true>, dim3(C, (unsigned)B), dim3(kBlock), 0, st, x, out, T, eps, lo,
-                               hi, seed, offset, gran);
-        else
+                               hi, seed, offset, gran, fail, spins);
+            hipLaunchKernelGGL(pgd_l2_init_philox_repair_kernel<true>, dim3((unsigned)B), dim3(kBlock), 0, st, x, out, T, C, eps,
+                               lo, hi, seed, offset, fail);
+        } else {
             hipLaunchKernelGGL(pgd_l2_init_philox_fused_kernel<false>, dim3(C, (unsigned)B), dim3(kBlock), 0, st, x, out, T, eps, lo,
-                               hi, seed, offset, gran);
+                               hi, seed, offset, gran, fail, spins);
+            hipLaunchKernelGGL(pgd_l2_init_philox_repair_kernel<false>, dim3((unsigned)B), dim3(kBlock), 0, st, x, out, T, C, eps,
+                               lo, hi, seed, offset, fail);
+        }
         return status_after_launch();
     }
     hipLaunchKernelGGL(philox_normal_sumsq_kernel, dim3(C, (unsigned)B), dim3(kBlock), 0, st, T, seed, offset, w.p0);
@@ -1141,18 +1354,29 @@ int advstep_pgd_l2_step_f32(const float *adv, const float *grad, const float *or
     hipStream_t st = as_stream(stream);
     const bool vec = rows_vec(T, {adv, grad, orig, out});
     const int C = tiles_per_row(T);
-    if (l2_single_pass() && C <= 64 && B * C <= 8 * 256) {
-        // every workgroup resident at once (8 per CU at <= 64 VGPRs): one launch, 16 B per sample
+    const void *fused = vec ? (const void *)pgd_l2_fused_kernel<true> : (const void *)pgd_l2_fused_kernel<false>;
+    const size_t row_bytes = (size_t)B * T * sizeof(float);
+    if (l2_single_pass() && C <= 64 && !overlaps(adv, out, row_bytes) && !overlaps(grad, out, row_bytes) &&
+        !overlaps(orig, out, row_bytes) && B * C <= l2_resident_capacity(vec ? kCapStepVec : kCapStepScalar, fused)) {
+        // the launch fits the device's resident capacity for this kernel: one launch, 16 B per sample; granules + row flags
+        // zeroed by one memset node, the repair kernel behind the launch serves rows whose exchange was abandoned
         const size_t plane = 2 * row_ws_plane(B, T);
-        if (hipMemsetAsync(ws, 0, 2 * plane, st) != hipSuccess) return ADVSTEP_ELAUNCH;
+        if (hipMemsetAsync(ws, 0, row_ws_bytes(B, T), st) != hipSuccess) return ADVSTEP_ELAUNCH;
         unsigned long long *gg = static_cast<unsigned long long *>(ws);
         unsigned long long *gd = reinterpret_cast<unsigned long long *>(static_cast<char *>(ws) + plane);
-        if (vec)
+        unsigned *fail = reinterpret_cast<unsigned *>(static_cast<char *>(ws) + 2 * plane);
+        const unsigned spins = l2_spin_limit();
+        if (vec) {
             hipLaunchKernelGGL(pgd_l2_fused_kernel<true>, dim3(C, (unsigned)B), dim3(kBlock), 0, st, adv, grad, orig, out, T, alpha,
-                               eps, eps_div, lo, hi, gg, gd, gnorm, dnorm);
-        else
+                               eps, eps_div, lo, hi, gg, gd, fail, spins, gnorm, dnorm);
+            hipLaunchKernelGGL(pgd_l2_repair_kernel<true>, dim3((unsigned)B), dim3(kBlock), 0, st, adv, grad, orig, out, T, C, alpha,
+                               eps, eps_div, lo, hi, fail, gnorm, dnorm);
+        } else {
             hipLaunchKernelGGL(pgd_l2_fused_kernel<false>, dim3(C, (unsigned)B), dim3(kBlock), 0, st, adv, grad, orig, out, T, alpha,
-                               eps, eps_div, lo, hi, gg, gd, gnorm, dnorm);
+                               eps, eps_div, lo, hi, gg, gd, fail, spins, gnorm, dnorm);
+            hipLaunchKernelGGL(pgd_l2_repair_kernel<false>, dim3((unsigned)B), dim3(kBlock), 0, st, adv, grad, orig, out, T, C, alpha,
+                               eps, eps_div, lo, hi, fail, gnorm, dnorm);
+        }
         return status_after_launch();
     }
     ADV_LAUNCH_ROWS(sumsq_partial_kernel, vec, B, T, st, grad + b0 * T, T, w.p0 + b0 * C);
@@ -1160,6 +1384,16 @@ int advstep_pgd_l2_step_f32(const float *adv, const float *grad, const float *or
                     w.p0 + b0 * C, w.p1 + b0 * C, gnorm ? gnorm + b0 : nullptr);
     ADV_LAUNCH_ROWS(pgd_l2_project_kernel, vec, B, T, st, adv + b0 * T, grad + b0 * T, orig + b0 * T, out + b0 * T, T,
                     alpha, eps, eps_div, lo, hi, w.p0 + b0 * C, w.p1 + b0 * C, dnorm ? dnorm + b0 : nullptr);
+    return status_after_launch();
+}
+
+int advstep_pgd_l2_repaired_rows(const void *ws, size_t ws_bytes, int64_t B, int64_t T, int *count,
+                                 advstep_stream_t stream) {
+    ADV_REQUIRE(B >= 0 && T >= 0 && count);
+    if (B == 0 || T == 0) return hipMemsetAsync(count, 0, sizeof(int), as_stream(stream)) == hipSuccess ? ADVSTEP_OK : ADVSTEP_ELAUNCH;
+    if (!ws || !aligned16(ws) || ws_bytes < row_ws_bytes(B, T)) return ADVSTEP_EWORKSPACE;
+    const unsigned *fail = reinterpret_cast<const unsigned *>(static_cast<const char *>(ws) + 4 * row_ws_plane(B, T));
+    hipLaunchKernelGGL(count_flags_kernel, dim3(1), dim3(64), 0, as_stream(stream), fail, B, count);
     return status_after_launch();
 }
 

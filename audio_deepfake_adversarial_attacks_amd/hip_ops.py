@@ -252,6 +252,19 @@ def pgd_l2_step(adv, grad, orig, alpha: float, eps: float, eps_div: float = 1e-1
     return (out, gn, dn) if return_norms else out
 
 
+def pgd_l2_repaired_rows(like: torch.Tensor) -> int:
+    """Diagnostics (synchronises): how many rows of the LAST single-pass pgd_l2_step / pgd_l2_init call on this device and
+    stream were recomputed by the repair kernel because their in-launch norm exchange was abandoned (include/advstep.h)."""
+    _require(like, "like")
+    B, T = _rows(like, "like")
+    count = torch.zeros(1, dtype=torch.int32, device=like.device)
+    with torch.cuda.device(like.device):
+        ws, ws_bytes = _workspace(like.device, B, T)
+        st = _lib.load().advstep_pgd_l2_repaired_rows(ws, ws_bytes, B, T, count.data_ptr(), _stream(like.device))
+    _lib.check(st, "advstep_pgd_l2_repaired_rows")
+    return int(count.item())
+
+
 # ---------------------------------------------------------------------------------------------------------
 # a7
 # ---------------------------------------------------------------------------------------------------------

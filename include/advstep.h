@@ -111,6 +111,14 @@ int advstep_pgd_l2_step_f32(const float *adv, const float *grad, const float *or
                             int64_t T, float alpha, float eps, float eps_div, float lo, float hi,
                             float *gnorm, float *dnorm, void *ws, size_t ws_bytes, advstep_stream_t stream);
 
+/* Diagnostics for the single-pass forms of the two calls above (no reference counterpart).  When a (B, T) launch fits the
+ * device's resident capacity, advstep_pgd_l2_step_f32 / advstep_pgd_l2_init_philox_f32 exchange the row norms inside ONE
+ * launch; a row whose exchange could not complete within its bound (another stream or process holding the compute units)
+ * is recomputed by a repair kernel queued behind the launch — same arithmetic, same bits, never a wrong or NaN row.
+ * This writes to *count (device int) how many rows of the LAST such call on `ws` went through the repair kernel. */
+int advstep_pgd_l2_repaired_rows(const void *ws, size_t ws_bytes, int64_t B, int64_t T, int *count,
+                                 advstep_stream_t stream);
+
 /* ---- a7: Carlini-Wagner (L2, tanh space, Adam) ---------------------------------------------------------- */
 
 /* adversarial_attacks/torchattacks/attacks/cw.py:57,117-122   w = 0.5 * log((1 + y) / (1 - y)), y = x*2 - 1 */

@@ -34,13 +34,15 @@ def attack_mode(model, model_training=True, batchnorm_training=False, dropout_tr
             model.train()
 
 
-def _cost_and_grad(model, adv, labels):
-    """pgd.py:60-72: logits -> cat([-z, z]) -> CrossEntropyLoss -> gradient w.r.t. the input."""
+def _cost_and_grad(model, adv, labels, with_cost=False):
+    """pgd.py:60-72: logits -> cat([-z, z]) -> CrossEntropyLoss -> gradient w.r.t. the input.
+    with_cost (tests only): also return the scalar loss and the logits the reference computes on the way."""
     adv.requires_grad = True
-    outputs = model(adv)
-    outputs = torch.cat([-outputs, outputs], dim=1)
+    z = model(adv)
+    outputs = torch.cat([-z, z], dim=1)
     cost = nn.CrossEntropyLoss()(outputs, labels)
-    return torch.autograd.grad(cost, adv, retain_graph=False, create_graph=False)[0]
+    grad = torch.autograd.grad(cost, adv, retain_graph=False, create_graph=False)[0]
+    return (grad, cost.detach(), z.detach()) if with_cost else grad
 
 
 def to_minmax(batch_x):
@@ -70,9 +72,9 @@ def pgd(model, images, labels, eps=0.3, alpha=2 / 255, steps=40, random_start=Tr
             noise = torch.empty_like(adv).uniform_(-eps, eps)
         adv = torch.clamp(adv + noise, min=0, max=1).detach()
     for _ in range(steps):
-        grad = _cost_and_grad(model, adv, labels)
+        grad, cost, z = _cost_and_grad(model, adv, labels, with_cost=True)
         if trace is not None:
-            trace.append((adv.detach().clone(), grad.clone()))
+            trace.append((adv.detach().clone(), grad.clone(), cost.clone(), z.clone()))
         adv = adv.detach() + alpha * grad.sign()
         delta = torch.clamp(adv - images, min=-eps, max=eps)
         adv = torch.clamp(images + delta, min=0, max=1).detach()
@@ -97,9 +99,9 @@ def pgdl2(model, images, labels, eps=1.0, alpha=0.2, steps=40, random_start=True
         delta *= r / n * eps
         adv = torch.clamp(adv + delta, min=0, max=1).detach()
     for _ in range(steps):
-        grad = _cost_and_grad(model, adv, labels)
+        grad, cost, z = _cost_and_grad(model, adv, labels, with_cost=True)
         if trace is not None:
-            trace.append((adv.detach().clone(), grad.clone()))
+            trace.append((adv.detach().clone(), grad.clone(), cost.clone(), z.clone()))
         grad_norms = torch.norm(grad.view(batch_size, -1), p=2, dim=1) + eps_for_division
         grad = grad / grad_norms.view(batch_size, 1)
         adv = adv.detach() + alpha * grad
@@ -119,7 +121,7 @@ def _cw_f(outputs, labels, kappa):
     return torch.clamp((j - i), min=-kappa)
 
 
-def cw(model, images, labels, c=1e-4, kappa=0, steps=1000, lr=0.01):
+def cw(model, images, labels, c=1e-4, kappa=0, steps=1000, lr=0.01, trace=None):
     images = images.clone().detach()
     labels = labels.clone().detach()
     y = images * 2 - 1
@@ -149,6 +151,9 @@ def cw(model, images, labels, c=1e-4, kappa=0, steps=1000, lr=0.01):
         best_l2 = mask * current_l2.detach() + (1 - mask) * best_l2
         mask = mask.view([-1] + [1] * (dim - 1))
         best_adv = mask * adv.detach() + (1 - mask) * best_adv
+        if trace is not None:
+            trace.append((cost.detach().clone(), current_l2.detach().clone(), outputs.detach()[:, 1].clone(),
+                          adv.detach().clone()))
         if step % max(steps // 10, 1) == 0:
             if cost.item() > prev_cost:
                 return best_adv

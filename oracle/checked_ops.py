@@ -46,11 +46,34 @@ def _close(name, got, want, atol=0.0, rtol=0.0):
 
 
 class CheckedOps:
+    """`every` > 1 samples: of each entry point's launches only number 0, every, 2 * every ... are re-computed by the
+    oracle (the others run unchecked) — for full-size workloads, where one check copies four (128, 64600) arrays to
+    the host.  `calls` counts all launches, `checked` the compared ones."""
     NAME = "hip+oracle-check"
+    SAMPLED = ("to_minmax", "revert_minmax", "fgsm_step", "pgd_linf_init", "pgd_linf_step", "pgd_l2_init", "pgd_l2_step",
+               "cw_init_w", "cw_tanh_sqdist", "cw_adam_step", "cw_best_update", "ce2_loss_grad")
 
-    def __init__(self, hip_ops):
+    def __init__(self, hip_ops, every: int = 1):
         self.hip = hip_ops
         self.calls = Counter()
+        self.checked = Counter()
+        self.every = max(int(every), 1)
+        for name in self.SAMPLED:
+            setattr(self, name, self._sampled(name, getattr(self, name), getattr(hip_ops, name)))
+
+    def _sampled(self, name, checked_fn, plain_fn):
+        seen = Counter()
+
+        def run(*args, **kwargs):
+            n = seen[name]
+            seen[name] += 1
+            if n % self.every == 0:
+                self.checked[name] += 1
+                return checked_fn(*args, **kwargs)
+            self.calls[name] += 1
+            return plain_fn(*args, **kwargs)
+
+        return run
 
     # a1 / a2 -------------------------------------------------------------------------------------------
     def to_minmax(self, batch_x):
@@ -212,3 +235,49 @@ class CheckedOps:
         _close("fab_backward_step.res2", res2, _np(cr), rtol=1e-5)
         _exact("fab_backward_step.adv", adv, _np(ca))
         self.calls["fab_backward_step"] += 1
+
+
+class TracingOps:
+    """TEST INFRASTRUCTURE — an op table that forwards every call to `ops` unchanged and keeps, per attack iteration, what
+    the reference's loop would show at that point: the iterate entering the update step, the input gradient, the loss and
+    the logits (PGD / PGDL2: oracle/attacks.py `trace` holds the CPU twin), and for CW the per-utterance squared
+    distances.  Used by the end-to-end GPU-vs-CPU-oracle tests (tests/test_gpu_e2e_parity.py)."""
+
+    def __init__(self, ops):
+        self.ops = ops
+        self.NAME = getattr(ops, "NAME", "ops") + "+trace"
+        self.steps = []          # (adv_in, grad, cost (1,), z (B, 1)) per update launch
+        self.cw_l2 = []          # (B,) per CW iteration
+        self.cw_adv = []         # (B, T) per CW iteration: 1/2 (tanh w + 1)
+        self._pending = None
+
+    def __getattr__(self, name):
+        return getattr(self.ops, name)
+
+    def ce2_loss_grad(self, z, labels, scale=1.0):
+        dz, loss = self.ops.ce2_loss_grad(z, labels, scale)
+        self._pending = (loss.detach().clone(), z.detach().clone())
+        return dz, loss
+
+    def _note(self, adv, grad):
+        cost, z = self._pending if self._pending is not None else (None, None)
+        self.steps.append((adv.detach().clone(), grad.detach().clone(), cost, z))
+        self._pending = None
+
+    def pgd_linf_step(self, adv, grad, orig, *args, **kwargs):
+        self._note(adv, grad)
+        return self.ops.pgd_linf_step(adv, grad, orig, *args, **kwargs)
+
+    def pgd_l2_step(self, adv, grad, orig, *args, **kwargs):
+        self._note(adv, grad)
+        return self.ops.pgd_l2_step(adv, grad, orig, *args, **kwargs)
+
+    def fgsm_step(self, x, grad, *args, **kwargs):
+        self._note(x, grad)
+        return self.ops.fgsm_step(x, grad, *args, **kwargs)
+
+    def cw_tanh_sqdist(self, w, x, adv_out=None):
+        adv, l2 = self.ops.cw_tanh_sqdist(w, x, adv_out=adv_out)
+        self.cw_l2.append(l2.detach().clone())
+        self.cw_adv.append(adv.detach().clone())
+        return adv, l2

@@ -197,8 +197,9 @@ def test_detectors_with_fused_elementwise_passes_agree_with_plain_modules(cuda, 
     fig = {"logit_max_abs": (z0 - z1).abs().max().item(), "logit_scale": z0.abs().max().item(),
            "grad_rel_l2": ((g0 - g1).norm() / g0.norm()).item()}
     parity_record[f"{name}_fused_elementwise_vs_plain_modules"] = fig
-    assert fig["logit_max_abs"] <= 1e-4 * max(fig["logit_scale"], 1.0), fig
-    assert fig["grad_rel_l2"] <= 5e-3, fig
+    # measured (profiles/r02_parity.json): SpecRNet logits 1.5e-8, gradient relative L2 3.2e-7; RawNet3 8.9e-8 / 7.9e-6
+    bound = {"specrnet": (1.5e-7, 3.2e-6), "rawnet3": (9e-7, 8e-5)}[name]
+    assert fig["logit_max_abs"] <= bound[0] and fig["grad_rel_l2"] <= bound[1], fig
     for p in model.parameters():
         p.requires_grad_(True)
 

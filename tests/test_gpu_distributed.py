@@ -116,3 +116,88 @@ def test_bench_launches_its_own_ranks(cuda):
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 16 and line["scaling"] == "weak"
     assert line["value"] == pytest.approx(16 / (line["ms_per_step"] * 1e-3), rel=1e-6)
     assert "cpu_baseline" not in line and line["roofline"]["launches_timed"] == 40
+
+
+# ---- RCCL itself, on the one device this pool has ---------------------------------------------------------
+
+_RCCL_SCRIPT = r"""
+import json, os, sys, warnings
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["ADVSTEP_REPO"])
+import yaml
+from audio_deepfake_adversarial_attacks_amd import torchattacks
+from audio_deepfake_adversarial_attacks_amd.datasets.synthetic import SyntheticDetectionDataset
+from audio_deepfake_adversarial_attacks_amd.evaluation import aggregate_across_ranks, generate_attacks
+from audio_deepfake_adversarial_attacks_amd.torchattacks import graphed
+from audio_deepfake_adversarial_attacks_amd.utils import set_seed
+
+dev = torch.device("cuda:0")
+torch.cuda.set_device(dev)
+cfg = yaml.safe_load(open(os.path.join(os.environ["ADVSTEP_REPO"], "configs", "aa_evaluation", "lcnn.yaml")).read())
+data = SyntheticDetectionDataset(32)
+attack = {"eps": 0.003, "steps": 6, "random_start": False}
+
+
+def evaluate():
+    set_seed(42)
+    graphed.clear()
+    return generate_attacks([None, None, None], cfg, "cuda:0", attack_model_config=cfg, attack_method=torchattacks.PGD,
+                            attack_params=dict(attack), batch_size=8, dataset=data, share_weights=True, shuffle=True,
+                            num_workers=0, return_scores=True)
+
+
+def table(n, seed):
+    g = torch.Generator().manual_seed(seed)
+    p = torch.rand(n, generator=g).to(dev)
+    y = torch.randint(0, 2, (n,), generator=g).to(dev)
+    lab = (p + 0.5).int()
+    return p, lab, y, (lab == y.int()).sum(), torch.tensor(n, device=dev)
+
+
+plain_table = aggregate_across_ranks(*table(50, 3))
+plain = evaluate()                                             # no process group: the non-distributed path
+plain_graphs = len(graphed._GRAPHS)
+
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)      # RCCL communicator on cuda:0
+with warnings.catch_warnings(record=True) as caught:
+    warnings.simplefilter("always")
+    t = torch.arange(4, dtype=torch.float32, device=dev)
+    dist.all_reduce(t)                                          # the collective kernels really run
+    parts = [torch.empty_like(t)]
+    dist.all_gather(parts, t)
+    dist.barrier()
+    rccl_table = aggregate_across_ranks(*table(50, 3))
+    sharded = evaluate()                                        # generate_attacks under the process group, hipGraph path on
+    rccl_graphs = len(graphed._GRAPHS)
+dist.destroy_process_group()
+out = {"all_reduce": t.tolist(), "all_gather": parts[0].tolist(), "graphs_plain": plain_graphs, "graphs_rccl": rccl_graphs,
+       "capture_warnings": [str(w.message) for w in caught if "capture" in str(w.message)],
+       "tables_equal": all(np.array_equal(a, b) for a, b in zip(plain_table, rccl_table)),
+       "scores_equal": all(np.array_equal(plain["scores"][k], sharded["scores"][k]) for k in plain["scores"]),
+       "report_plain": {k: v for k, v in plain.items() if k != "scores"},
+       "report_rccl": {k: v for k, v in sharded.items() if k != "scores"},
+       "backend": dist.Backend.NCCL, "nccl_version": list(torch.cuda.nccl.version())}
+print("RESULT " + json.dumps(out), flush=True)
+"""
+
+
+@pytest.mark.timeout(900)
+def test_rccl_process_group_on_one_device(cuda, tmp_path):
+    """`backend="nccl"` (= RCCL) with ONE rank on cuda:0: communicator set-up, all_reduce / all_gather / barrier on device
+    tensors, `aggregate_across_ranks` through it (same table as without a process group), and the shipped
+    `generate_attacks` loop under it with the hipGraph replay on — the capture must succeed while RCCL's watchdog thread
+    is alive (graphed.py captures in thread_local error mode for exactly that) and the scores must equal the
+    non-distributed run bit for bit.  What this does NOT cover is ranks on distinct devices (xGMI transport): this pool
+    has single-GPU boxes."""
+    script = tmp_path / "rccl_one_rank.py"
+    script.write_text(_RCCL_SCRIPT)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(ADVSTEP_REPO=str(ROOT), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    proc = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=800)
+    assert proc.returncode == 0, (proc.stdout[-1500:], proc.stderr[-3000:])
+    res = json.loads([l for l in proc.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    assert res["all_reduce"] == [0.0, 1.0, 2.0, 3.0] and res["all_gather"] == [0.0, 1.0, 2.0, 3.0]
+    assert res["tables_equal"] and res["scores_equal"], res
+    assert res["report_plain"] == res["report_rccl"] and res["report_rccl"]["num_total"] == 32
+    assert res["graphs_plain"] >= 1 and res["graphs_rccl"] >= 1, res          # 4 batches: captured at the second
+    assert not res["capture_warnings"], res

@@ -1,5 +1,7 @@
 """`-m gpu`: every C-ABI entry point of libadvstep.so against (i) the reference's golden vectors and (ii) the
 plain-C oracle on seeded inputs, through the product's ctypes binding (hip_ops -> libadvstep.so)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -320,3 +322,104 @@ def test_pgd_l2_philox_start_single_pass_equals_two_kernel_path(cuda, monkeypatc
         outs.append(hip_ops.pgd_l2_init(x, 0.1, seed=1234, offset=5))
     assert torch.equal(outs[1], outs[0]) and torch.equal(outs[2], outs[0])
     assert ((outs[0] - x).norm(dim=1) <= 0.1 * (1 + 1e-5)).all() and not torch.equal(outs[0], x)
+
+
+def _l2_inputs(B, T, cuda):
+    g = torch.Generator().manual_seed(B * 31 + T)
+    orig = torch.rand(B, T, generator=g).to(cuda)
+    adv = (orig + (torch.rand(B, T, generator=g).to(cuda) - 0.5) * 0.01).clamp(0, 1)
+    grad = (torch.randn(B, T, generator=g) * 1e-3).to(cuda)
+    return adv, grad, orig
+
+
+@pytest.mark.parametrize("B,T", [(128, 64_600), (5, 64_600), (3, 4_099), (2, 100)])
+def test_pgd_l2_repair_pass_when_the_exchange_is_abandoned(cuda, monkeypatch, B, T):
+    """ADVICE r02 / VERDICT r02 item 7: a row whose in-launch norm exchange does not complete must not come out NaN.  With
+    the wait bound forced to 0 sweeps EVERY workgroup abandons its exchange, flags its row and leaves; the repair kernel
+    queued behind the launch recomputes the rows with the three-kernel path's arithmetic: bit-identical outputs and norms,
+    and the diagnostic counter says all B rows were repaired (0 in a normal launch)."""
+    from audio_deepfake_adversarial_attacks_amd import hip_ops
+    adv, grad, orig = _l2_inputs(B, T, cuda)
+    monkeypatch.setenv("ADVSTEP_L2_SINGLE_PASS", "0")
+    want = hip_ops.pgd_l2_step(adv, grad, orig, 0.2, 0.1, return_norms=True)
+    want_init = hip_ops.pgd_l2_init(orig, 0.1, seed=99, offset=3)
+    monkeypatch.setenv("ADVSTEP_L2_SINGLE_PASS", "1")
+    got = hip_ops.pgd_l2_step(adv, grad, orig, 0.2, 0.1, return_norms=True)
+    assert hip_ops.pgd_l2_repaired_rows(adv) == 0
+    monkeypatch.setenv("ADVSTEP_L2_SPIN_LIMIT", "0")
+    rep = hip_ops.pgd_l2_step(adv, grad, orig, 0.2, 0.1, return_norms=True)
+    assert hip_ops.pgd_l2_repaired_rows(adv) == B
+    rep_init = hip_ops.pgd_l2_init(orig, 0.1, seed=99, offset=3)
+    assert hip_ops.pgd_l2_repaired_rows(orig) == B
+    for a, b, c in zip(want, got, rep):
+        assert torch.equal(a, b) and torch.equal(a, c)
+    assert torch.equal(want_init, rep_init) and torch.isfinite(rep[0]).all()
+
+
+def test_pgd_l2_single_pass_respects_device_capacity_and_aliasing(cuda, monkeypatch):
+    """The single-pass path is taken only when the launch fits the device's resident capacity for the kernel (CU count x
+    occupancy, queried from the runtime — ADVSTEP_L2_CAPACITY stands in for a smaller / partitioned device) and when `out`
+    does not alias an input (the repair pass re-reads them); otherwise the three-kernel path runs.  Same bits every way."""
+    from audio_deepfake_adversarial_attacks_amd import hip_ops
+    B, T = 16, 64_600
+    adv, grad, orig = _l2_inputs(B, T, cuda)
+    monkeypatch.setenv("ADVSTEP_L2_SINGLE_PASS", "0")
+    want = hip_ops.pgd_l2_step(adv, grad, orig, 0.2, 0.1)
+    monkeypatch.setenv("ADVSTEP_L2_SINGLE_PASS", "1")
+    monkeypatch.setenv("ADVSTEP_L2_SPIN_LIMIT", "0")        # if the single-pass path ran, every row would be flagged
+    monkeypatch.setenv("ADVSTEP_L2_CAPACITY", str(B * 16 - 1))
+    hip_ops.pgd_l2_step(adv, grad, orig, 0.2, 0.1)           # leaves the flags of an earlier call untouched ...
+    monkeypatch.setenv("ADVSTEP_L2_CAPACITY", str(B * 16))
+    assert torch.equal(hip_ops.pgd_l2_step(adv, grad, orig, 0.2, 0.1), want)
+    assert hip_ops.pgd_l2_repaired_rows(adv) == B            # ... this one fits: single pass, all rows repaired
+    monkeypatch.delenv("ADVSTEP_L2_CAPACITY")
+    monkeypatch.delenv("ADVSTEP_L2_SPIN_LIMIT")
+    assert torch.equal(hip_ops.pgd_l2_step(adv, grad, orig, 0.2, 0.1), want)
+    assert hip_ops.pgd_l2_repaired_rows(adv) == 0
+    inplace = adv.clone()
+    hip_ops.pgd_l2_step(inplace, grad, orig, 0.2, 0.1, out=inplace)      # in-place update (include/advstep.h allows it)
+    assert torch.equal(inplace, want)
+
+
+_TWO_PROCESS_SCRIPT = r"""
+import os, sys, torch
+sys.path.insert(0, os.environ["ADVSTEP_REPO"])
+from audio_deepfake_adversarial_attacks_amd import hip_ops
+dev = torch.device("cuda:0")
+g = torch.Generator().manual_seed(int(sys.argv[1]))
+B, T = 128, 64600
+orig = torch.rand(B, T, generator=g).to(dev)
+adv = (orig + (torch.rand(B, T, generator=g).to(dev) - 0.5) * 0.01).clamp(0, 1)
+grad = (torch.randn(B, T, generator=g) * 1e-3).to(dev)
+repaired = 0
+cur = adv
+for it in range(int(sys.argv[2])):
+    os.environ["ADVSTEP_L2_SINGLE_PASS"] = "1"
+    got = hip_ops.pgd_l2_step(cur, grad, orig, 0.2, 0.1)
+    repaired += hip_ops.pgd_l2_repaired_rows(cur)
+    os.environ["ADVSTEP_L2_SINGLE_PASS"] = "0"
+    want = hip_ops.pgd_l2_step(cur, grad, orig, 0.2, 0.1)
+    if not torch.equal(got, want) or not torch.isfinite(got).all():
+        print("MISMATCH at iteration", it, flush=True)
+        sys.exit(3)
+    cur = got
+    grad = grad.roll(1, dims=1)
+print("ok repaired_rows", repaired, flush=True)
+"""
+
+
+def test_pgd_l2_single_pass_with_two_processes_sharing_the_device(cuda, tmp_path):
+    """Two processes on the ONE device, both running the single-pass PGDL2 step at B = 128 (2 048 workgroups each: together
+    twice the resident capacity) for 150 iterations, each comparing every result with the three-kernel path: bit-identical
+    and finite, whether or not a row had to go through the repair pass (the count is printed)."""
+    import subprocess
+    import sys
+    from tests.conftest import ROOT
+    script = tmp_path / "two_proc.py"
+    script.write_text(_TWO_PROCESS_SCRIPT)
+    env = dict(os.environ, ADVSTEP_REPO=str(ROOT))
+    procs = [subprocess.Popen([sys.executable, str(script), str(seed), "150"], env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for seed in (1, 2)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0 and "ok repaired_rows" in o, o[-2000:]

@@ -1,8 +1,8 @@
 """`-m gpu`: the detectors' SHIPPED device paths (fused HIP kernels with frozen parameters, i.e. what runs inside an
 attack) against the logits and input gradients the REFERENCE's own model classes produced on CPU
 (tests/golden/{lcnn,specrnet,rawnet3}_body.npz — reference src/models/lcnn.py:166-208, specrnet.py:141-181,
-rawnet3.py:81-137).  Tolerances are float32 cross-device bounds, stated per test; the measured figures go to the parity
-record (profiles/r02_parity.json)."""
+rawnet3.py:81-137).  Tolerances are float32 cross-device bounds, stated per test and kept within 10x of the figures
+measured on MI355X (profiles/r02_parity.json, r03_parity.json), so a kernel that loses three decimal digits fails."""
 import pytest
 import torch
 
@@ -34,10 +34,9 @@ def gradient_figures(got, want):
 
 def test_lcnn_fused_device_path_matches_reference_body(cuda, golden, parity_record):
     """BaseLCNN: first-block kernel, Winograd 3x3 blocks on the matrix cores, 1x1 blocks, folded BatchNorm, persistent
-    LSTM — vs the reference's CPU logits / grad_spec.  Measured: logits 1.5e-8, gradient relative L2 6.4e-7, no entry off
-    by 1e-3 of the largest.  Bounds: logits 1e-6 abs (|logit| ~ 0.1); gradient relative L2 1e-4 — or, if a near-tie
-    max-feature-map / pool winner goes the other way under the different summation order (none does on this input), at
-    most 8 entries off by more than 1e-3 of the largest entry and relative L2 5e-3."""
+    LSTM — vs the reference's CPU logits / grad_spec.  Measured: logits 3e-8, gradient relative L2 6.4e-7, worst entry
+    6.5e-7 of the largest, no max-feature-map / pool winner re-routed on this input.  Bounds: logits 3e-7 abs
+    (|logit| ~ 0.1); gradient relative L2 6e-6, no entry off by more than 1e-5 of the largest."""
     from audio_deepfake_adversarial_attacks_amd.models import lcnn
     g = golden("lcnn_body")
     body = lcnn.BaseLCNN(input_channels=1, num_coefficients=80)
@@ -52,17 +51,16 @@ def test_lcnn_fused_device_path_matches_reference_body(cuda, golden, parity_reco
     with torch.no_grad():
         fig["logit_eval_max_abs"] = (body.eval()(spec.detach()) - T(g["logits"]).to(cuda)).abs().max().item()
     parity_record["lcnn_body_fused_vs_reference"] = fig
-    assert fig["logit_max_abs"] <= 1e-6 and fig["logit_eval_max_abs"] <= 1e-6, fig
-    flipped = fig["grad_frac_off_by_1e-3_of_max"] * want_g.numel()
-    assert fig["grad_rel_l2"] <= (1e-4 if flipped == 0 else 5e-3) and flipped <= 8, fig
+    assert fig["logit_max_abs"] <= 3e-7 and fig["logit_eval_max_abs"] <= 3e-7, fig
+    assert fig["grad_rel_l2"] <= 6e-6 and fig["grad_max_abs_over_max"] <= 1e-5, fig
 
 
 def test_specrnet_device_path_matches_reference_body(cuda, golden, parity_record):
-    """BaseSpecRNet on the device (residual blocks + the fused GRU kernels) vs the reference's CPU logits / grad_spec.
-    The residual blocks' 3x3 convolutions run in MIOpen (fp32 Winograd), the reference's on CPU as direct convolutions:
-    MaxPool2d winners at near ties differ and re-route gradient entries.  Measured: logits 3e-8; gradient relative L2
-    3.5e-3, 0.011 % of the entries off by more than 1e-3 of the largest, worst entry 1.4 % of the largest.
-    Bounds: logits 1e-6 abs; gradient relative L2 1e-2, at most 0.1 % of the entries off."""
+    """BaseSpecRNet on the device — residual blocks on the Winograd matrix-core kernel (`advstep_resconv_*`) and the
+    vector-ALU kernels for the 2-channel ends, fused elementwise / pooling passes, fused GRU — vs the reference's CPU logits
+    / grad_spec.  Measured since the blocks left MIOpen (round 2): logits 1.5e-8, gradient relative L2 6.4e-7, worst entry
+    6.7e-7 of the largest, no pooling winner re-routed on this input.  Bounds: logits 2e-7 abs; gradient relative L2 6e-6,
+    no entry off by more than 1e-5 of the largest."""
     from audio_deepfake_adversarial_attacks_amd.models import specrnet
     g = golden("specrnet_body")
     body = specrnet.BaseSpecRNet(specrnet.get_config(2), device=str(cuda))
@@ -74,15 +72,16 @@ def test_specrnet_device_path_matches_reference_body(cuda, golden, parity_record
     fig = gradient_figures(grad, T(g["grad_spec"]).to(cuda))
     fig["logit_max_abs"] = (out - T(g["logits_attackmode"]).to(cuda)).abs().max().item()
     parity_record["specrnet_body_device_vs_reference"] = fig
-    assert fig["logit_max_abs"] <= 1e-6, fig
-    assert fig["grad_rel_l2"] <= 1e-2 and fig["grad_frac_off_by_1e-3_of_max"] <= 1e-3, fig
+    assert fig["logit_max_abs"] <= 2e-7, fig
+    assert fig["grad_rel_l2"] <= 6e-6 and fig["grad_max_abs_over_max"] <= 1e-5, fig
 
 
 def test_rawnet3_device_path_matches_reference_body(cuda, golden, parity_record):
     """RawNet3 after its first layer on the device — the dilated Res2Net convolutions as GEMMs over shifted views
     (models/rawnet3.py:_same_conv1d), library GEMMs for the 1x1 convolutions — vs the reference class's CPU logits and
-    gradient w.r.t. the tensor leaving conv1.  Bounds: logits 1e-4 abs (2 300 GEMM-accumulated channels ahead of the
-    statistics pooling); gradient relative L2 1e-3."""
+    gradient w.r.t. the tensor leaving conv1.  Measured: logits 4.8e-7, gradient relative L2 3.5e-5, worst entry 4e-5 of the
+    largest (2 300 GEMM-accumulated channels ahead of the statistics pooling; Tensile's fp32 GEMMs sum in another order than
+    the CPU's).  Bounds: logits 5e-6 abs; gradient relative L2 3.5e-4, no entry off by more than 4e-4 of the largest."""
     from tests.test_models import rawnet3_like_fixture
     g = golden("rawnet3_body")
     model = attack_mode_frozen(rawnet3_like_fixture(g).to(cuda))
@@ -93,5 +92,5 @@ def test_rawnet3_device_path_matches_reference_body(cuda, golden, parity_record)
     fig = gradient_figures(grad, T(g["grad_h"]).to(cuda))
     fig["logit_max_abs"] = (out - T(g["logits_attackmode"]).to(cuda)).abs().max().item()
     parity_record["rawnet3_body_device_vs_reference"] = fig
-    assert fig["logit_max_abs"] <= 1e-4, fig
-    assert fig["grad_rel_l2"] <= 1e-3, fig
+    assert fig["logit_max_abs"] <= 5e-6, fig
+    assert fig["grad_rel_l2"] <= 3.5e-4 and fig["grad_max_abs_over_max"] <= 4e-4, fig

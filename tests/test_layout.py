@@ -42,8 +42,9 @@ def test_library_basics_without_gpu(lib):
     assert lib.advstep_abi_version() == 1
     assert lib.advstep_device_count() >= 0
     assert lib.advstep_status_string(0) == b"ok" and b"workspace" in lib.advstep_status_string(2)
-    # 4 planes of ceil(T / 4096) floats per row (two partial-sum planes, or two planes of 8-byte granules)
-    assert lib.advstep_row_workspace_bytes(128, 64_600) == 4 * 128 * 16 * 4
+    # 4 planes of ceil(T / 4096) floats per row (two partial-sum planes, or two planes of 8-byte granules) + one 32-bit
+    # "row needs repair" flag per row (single-pass PGD-L2 paths)
+    assert lib.advstep_row_workspace_bytes(128, 64_600) == 4 * 128 * 16 * 4 + 128 * 4
     assert lib.advstep_row_workspace_bytes(1, 1) == 64 and lib.advstep_row_workspace_bytes(0, 5) == 0
 
 
