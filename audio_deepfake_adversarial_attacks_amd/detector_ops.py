@@ -495,7 +495,7 @@ def resconv(x1: torch.Tensor, x2: Optional[torch.Tensor], U: torch.Tensor, rows:
         if x2.shape[0] != N or tuple(x2.shape[2:]) != (H, W):
             raise ValueError("x1 and x2 must share batch and spatial dimensions")
     y = torch.empty((N, rows, H, W), dtype=x1.dtype, device=x1.device)
-    with _Launch("resconv_forward", x1.device):
+    with _Launch("resconv_forward", x1.device, work=8.0 * N * rows * (K1 + K2) * H * W):
         st = _lib.load().advstep_resconv_forward_f32(x1.data_ptr(), None if x2 is None else x2.data_ptr(), U.data_ptr(),
                                                      None if shift is None else shift.data_ptr(), float(slope), y.data_ptr(), N,
                                                      K1, K2, rows, H, W, _stream(x1.device))
@@ -513,7 +513,7 @@ def resconv_pool2(x1: torch.Tensor, x2: Optional[torch.Tensor], U: torch.Tensor,
         _require(x2, "x2")
     y = torch.empty((N, rows, H // 2, W // 2), dtype=x1.dtype, device=x1.device)
     sel = torch.empty(max(y.numel(), 1), dtype=torch.uint8, device=x1.device)
-    with _Launch("resconv_pool2_forward", x1.device):
+    with _Launch("resconv_pool2_forward", x1.device, work=8.0 * N * rows * (K1 + K2) * H * W):
         st = _lib.load().advstep_resconv_pool2_forward_f32(x1.data_ptr(), None if x2 is None else x2.data_ptr(), U.data_ptr(),
                                                            None if bias is None else bias.data_ptr(), y.data_ptr(), sel.data_ptr(),
                                                            N, K1, K2, rows, H, W, _stream(x1.device))
@@ -534,7 +534,7 @@ def resconv_pooled_grad(gy: torch.Tensor, sel: torch.Tensor, U: torch.Tensor, ro
         if tuple(h.shape) != (N, rows, H, W):
             raise ValueError("h must have the output's shape")
     g = torch.empty((N, rows, H, W), dtype=gy.dtype, device=gy.device)
-    with _Launch("resconv_pooled_grad", gy.device):
+    with _Launch("resconv_pooled_grad", gy.device, work=8.0 * N * rows * K * H * W):
         st = _lib.load().advstep_resconv_pooled_grad_f32(gy.data_ptr(), sel.data_ptr(), U.data_ptr(),
                                                          None if h is None else h.data_ptr(), float(slope), g.data_ptr(), N, K, rows,
                                                          H, W, _stream(gy.device))
@@ -627,6 +627,16 @@ def res_block_supported(conv1, conv2, down) -> bool:
     return (resconv_supported(cout, cin if down is not None else 0, cout)
             and resconv_supported(cout, 0, cout) and resconv_supported(cin, 0, cout)
             and resconv_supported(cout, cout if down is not None else 0, cin))
+
+
+def res_block_shape_supported(x_shape, cout: int) -> bool:
+    """The size limits the block's kernels enforce on the host side (csrc/lcnn_wino.hip:resconv_check, csrc/detector_conv.hip:
+    32-bit buffer offsets per tensor, 31-bit pooled-cell indices, grid.y <= 65535 samples in the vector-ALU kernels) for an
+    input of shape (N, cin, H, W).  A batch beyond them takes the MIOpen + elementwise-kernel path instead of raising."""
+    N, cin, H, W = (int(v) for v in x_shape)
+    big = max(cin, cout)
+    return (N <= 65535 and N * big * H * W * 4 < (1 << 31) and N * cout * H * W * 4 < (1 << 33)
+            and N * ((H + 1) // 2) * ((W + 1) // 2) < (1 << 31))
 
 
 def res_block_plan(block, conv1, bn2, conv2, down, slope: float) -> ResBlockPlan:

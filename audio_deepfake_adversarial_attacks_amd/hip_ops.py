@@ -30,6 +30,7 @@ NAME = "hip"
 
 _workspaces: Dict[Tuple[int, int], torch.Tensor] = {}
 _profile: Optional[Dict[str, List[Tuple[torch.cuda.Event, torch.cuda.Event]]]] = None
+_profile_work: Dict[str, List[float]] = {}      # per bracketed launch: the arithmetic the caller says it did (flop), or 0
 
 
 def _require(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
@@ -84,10 +85,13 @@ def _out_like(ref: torch.Tensor, out: Optional[torch.Tensor], name: str = "out")
 
 
 class _Launch:
-    """Device guard + optional HIP-event bracket around one C-ABI call (events sit on the launch stream)."""
+    """Device guard + optional HIP-event bracket around one C-ABI call (events sit on the launch stream).  `work` = the
+    floating-point operations the launch must put through the matrix cores (Winograd F(2x2, 3x3) kernels: 2 x 16 products per
+    2x2 output tile, output row and reduction channel = a direct 3x3 convolution's count / 2.25; unpadded), kept next to the
+    bracket's duration for bench.py's model-side roofline."""
 
-    def __init__(self, name: str, device: torch.device):
-        self.name, self.device = name, device
+    def __init__(self, name: str, device: torch.device, work: float = 0.0):
+        self.name, self.device, self.work = name, device, work
         self.guard = torch.cuda.device(device)
 
     def __enter__(self):
@@ -102,6 +106,7 @@ class _Launch:
         if self.pair is not None:
             self.pair[1].record(torch.cuda.current_stream(self.device))
             _profile[self.name].append(self.pair)
+            _profile_work.setdefault(self.name, []).append(self.work)
         return self.guard.__exit__(*exc)
 
 
@@ -109,14 +114,18 @@ def start_profile(*entry_points: str) -> None:
     """Bracket every later launch of the named entry points with HIP events on their launch stream."""
     global _profile
     _profile = {n: [] for n in entry_points}
+    _profile_work.clear()
 
 
-def stop_profile() -> Dict[str, List[float]]:
-    """Synchronise and return {entry point: [milliseconds per launch]}."""
+def stop_profile(with_work: bool = False):
+    """Synchronise and return {entry point: [milliseconds per launch]} (with_work: also {entry point: [flop per launch]})."""
     global _profile
     prof, _profile = _profile or {}, None
     torch.cuda.synchronize()
-    return {n: [a.elapsed_time(b) for a, b in pairs] for n, pairs in prof.items()}
+    ms = {n: [a.elapsed_time(b) for a, b in pairs] for n, pairs in prof.items()}
+    if with_work:
+        return ms, {n: list(_profile_work.get(n, [])) for n in prof}
+    return ms
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -258,7 +258,7 @@ class _Conv3x3MfmPool2(torch.autograd.Function):
         lib = _lib.load()
         per_out = C * (H // 2) * (W // 2)
         for lo, hi in _batch_chunks(N, max(Cin * H * W, 1)):
-            with _Launch("conv3x3_mfm_pool2_forward", x.device):
+            with _Launch("conv3x3_mfm_pool2_forward", x.device, work=16.0 * (hi - lo) * C * Cin * H * W):
                 st = lib.advstep_conv3x3_mfm_pool2_forward_f32(
                     x[lo:hi].data_ptr(), U.data_ptr(), bias.data_ptr() if bias is not None else None, bn_mean, bn_invstd,
                     y[lo:hi].data_ptr() if hi > lo else None, idx.data_ptr() + lo * per_out, hi - lo, Cin, C, H, W,
@@ -279,7 +279,7 @@ class _Conv3x3MfmPool2(torch.autograd.Function):
         gx = torch.empty((N, Cin, H, W), dtype=gy.dtype, device=gy.device)
         per_cell = C * (H // 2) * (W // 2)
         for lo, hi in _batch_chunks(N, max(4 * per_cell, Cin * H * W, 1)):
-            with _Launch("conv3x3_mfm_pool2_backward", gy.device):
+            with _Launch("conv3x3_mfm_pool2_backward", gy.device, work=16.0 * (hi - lo) * C * Cin * H * W):
                 st = lib.advstep_conv3x3_mfm_pool2_backward_f32(gy[lo:hi].data_ptr(), idx.data_ptr() + lo * per_cell,
                                                                 U.data_ptr(), gx[lo:hi].data_ptr(), hi - lo, Cin, C, H, W,
                                                                 _stream(gy.device))
@@ -303,7 +303,7 @@ class _Conv3x3Mfm(torch.autograd.Function):
         per_sel = C * ((H + 1) // 2) * ((W + 1) // 2)
         sel = torch.empty(max(N * per_sel, 1), dtype=torch.uint8, device=x.device)
         for lo, hi in _batch_chunks(N, max(Cin * H * W, 1)):
-            with _Launch("conv3x3_mfm_forward", x.device):
+            with _Launch("conv3x3_mfm_forward", x.device, work=16.0 * (hi - lo) * C * Cin * H * W):
                 st = lib.advstep_conv3x3_mfm_forward_f32(
                     x[lo:hi].data_ptr(), U.data_ptr(), bias.data_ptr() if bias is not None else None, bn_mean, bn_invstd,
                     y[lo:hi].data_ptr(), sel.data_ptr() + lo * per_sel, hi - lo, Cin, C, H, W, _stream(x.device))
@@ -325,7 +325,7 @@ class _Conv3x3Mfm(torch.autograd.Function):
         _lib.check(st, "advstep_conv3x3_mfm_backward_f32")
         gx = torch.empty((N, Cin, H, W), dtype=gy.dtype, device=gy.device)
         for lo, hi in _batch_chunks(N, max(2 * C * H * W, 1)):
-            with _Launch("conv3x3_backward_data", gy.device):
+            with _Launch("conv3x3_backward_data", gy.device, work=16.0 * (hi - lo) * C * Cin * H * W):
                 st = lib.advstep_conv3x3_backward_data_f32(gconv[lo:hi].data_ptr(), U.data_ptr(), gx[lo:hi].data_ptr(), hi - lo,
                                                            Cin, 2 * C, H, W, _stream(gy.device))
             _lib.check(st, "advstep_conv3x3_backward_data_f32")

@@ -234,7 +234,8 @@ def _same_conv1d(x: torch.Tensor, conv: nn.Conv1d, with_bias: bool = True) -> to
     bias = conv.bias if with_bias else None
     if not (x.is_cuda and _gemm_conv1d_enabled() and conv.stride == (1,) and conv.groups == 1 and k % 2 == 1 and k > 1
             and conv.padding == ((k // 2) * d,) and conv.padding_mode == "zeros"):
-        return F.conv1d(x, conv.weight, bias, conv.stride, conv.padding, conv.dilation, conv.groups)
+        # the module's own forward path, so a non-zero padding_mode keeps its reflect / circular padding
+        return conv(x) if (with_bias or conv.bias is None) else conv._conv_forward(x, conv.weight, None)
     frozen = not (torch.is_grad_enabled() and (conv.weight.requires_grad or (bias is not None and bias.requires_grad)))
     if frozen and x.dtype == torch.float32 and x.shape[-1] > (k // 2) * d and _inplace_conv1d_enabled():
         return _SameConv1dFrozen.apply(x, conv.weight.detach(), None if bias is None else bias.detach(), d)

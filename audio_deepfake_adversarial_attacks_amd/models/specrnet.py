@@ -53,7 +53,8 @@ class Residual_block2D(nn.Module):
         import torch.nn.functional as F
         from .. import detector_ops as D
         down = self.conv_downsample if self.downsample else None
-        if _fused_conv_enabled() and x.dim() == 4 and D.res_block_supported(self.conv1, self.conv2, down):
+        if (_fused_conv_enabled() and x.dim() == 4 and D.res_block_supported(self.conv1, self.conv2, down)
+                and D.res_block_shape_supported(x.shape, self.conv1.out_channels)):
             # the whole block on the matrix cores (detector_ops._ResBlock): downsample inside conv2's reduction, pooling in
             # its epilogue, transposed convolutions through the same kernel on the way back
             return D.res_block(x, D.res_block_plan(self, self.conv1, self.bn2, self.conv2, down, self.lrelu.negative_slope))

@@ -32,6 +32,12 @@ class CW(Attack):
         self.steps = steps
         self.lr = lr
         self._supported_mode = ["default", "targeted"]
+        self._early_stop = True
+
+    def set_early_stop(self, enabled: bool = True) -> None:
+        """Additive (not in the reference): False keeps iterating when the loss check of cw.py:105-110 would return early —
+        for timing all `steps` iterations; the default reproduces the reference."""
+        self._early_stop = bool(enabled)
 
     def forward(self, images, labels):
         ops = self.ops
@@ -76,7 +82,7 @@ class CW(Attack):
             # cw.py:105-110: early stop when the loss stops decreasing (one host sync per check)
             if step % check_every == 0:
                 cost_now = cost.item()
-                if cost_now > prev_cost:
+                if cost_now > prev_cost and self._early_stop:
                     return best_adv
                 prev_cost = cost_now
 

@@ -9,9 +9,10 @@ graph launch per two iterations.
 
 What is baked into a captured graph and therefore part of its key: the device pointers of the static input buffers (owned
 here), of the model's parameters and of every cache derived from them (prepared Winograd weights, packed GRU weights,
-filterbank tables) — so the key carries the parameters' version counters and the modules' train/eval flags; a graph is
-captured only when the same key shows up a second time (an adversarial-training step changes the weights before every
-attack call: those calls stay eager).  Random starts are drawn OUTSIDE the graph (a fresh Philox key per call).
+filterbank tables) — so the key carries the parameters' version counters and the modules' train/eval flags; the ADVSTEP_* switches and the labels'
+dtype / shape; a graph is captured only when the same key shows up a second time (an adversarial-training step changes the
+weights before every attack call: those calls stay eager), and capturing a workload under a new state drops the captures of
+the same workload under older states (each holds a private memory pool).  Random starts are drawn OUTSIDE the graph (a fresh Philox key per call).
 
 Eager fallback, always bit-identical: CPU op tables / checked ops (tests), active launch profiling (bench.py brackets
 the update kernel with HIP events, which cannot be recorded into a graph), ADVSTEP_ATTACK_GRAPH=0, or a failed capture."""
@@ -25,8 +26,14 @@ import torch
 
 _GRAPHS: Dict[tuple, "_Captured"] = {}
 _SEEN: Dict[tuple, int] = {}
+_FAILED: set = set()          # family keys (model, attack, shape, hyper-parameters) whose capture failed: they stay eager
 _MAX_GRAPHS = 8
-_failed_once = False
+
+
+def _toggles() -> Tuple:
+    """Every ADVSTEP_* environment switch, sorted: the model's forward and the step kernels read them at call time, so a
+    captured kernel sequence is only valid for the values it was captured under (A/B runs flip them between calls)."""
+    return tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith("ADVSTEP_")))
 
 
 def enabled() -> bool:
@@ -68,7 +75,9 @@ class _Captured:
         # thread-local capture mode: with N > 1 ranks the RCCL watchdog thread (event queries), and in the CLI the DataLoader's
         # pinning thread, make HIP calls of their own while this thread captures; in the default "global" mode any such call
         # invalidates the capture
-        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+        # captured on the warm-up stream: everything keyed by the launch stream (hip_ops' row-reduction workspace) was created
+        # by the warm-up, OUTSIDE the capture, so nothing that outlives this object is allocated from the graph's private pool
+        with torch.cuda.graph(self.graph, stream=side, capture_error_mode="thread_local"):
             two_iterations()
 
     def run(self, adv, images, labels, target, pairs: int) -> torch.Tensor:
@@ -85,31 +94,40 @@ def run_iterations(attack, adv: torch.Tensor, images: torch.Tensor, labels: torc
                    steps: int, step_fn: Callable, hyper: Tuple) -> torch.Tensor:
     """`steps` iterations of  adv <- step_fn(adv, grad(adv), images, out)  starting from `adv`; returns the final adv
     (detached, own storage).  step_fn(adv, grad, images, out) must write `out` (a different buffer than `adv`)."""
-    global _failed_once
     from .. import hip_ops
     ops = attack.ops
     use_graph = (enabled() and ops is hip_ops and hip_ops._profile is None and adv.is_cuda and steps >= 4
                  and not torch.cuda.is_current_stream_capturing())
     done = 0
     if use_graph:
-        key = (id(attack.model), attack.__class__.__name__, hyper, attack._targeted, tuple(adv.shape), str(adv.device),
-               _state_signature(attack.model))
+        # family: what makes two calls the same workload; state: what a capture bakes in beyond that (parameter / buffer
+        # storage and versions, train/eval flags, the ADVSTEP_* switches the kernels read at call time)
+        family = (id(attack.model), attack.__class__.__name__, hyper, attack._targeted, tuple(adv.shape), str(adv.device),
+                  labels.dtype, tuple(labels.shape))
+        key = family + (_state_signature(attack.model), _toggles())
         cap = _GRAPHS.get(key)
-        if cap is None:
+        if cap is None and family not in _FAILED:
             _SEEN[key] = _SEEN.get(key, 0) + 1
             if len(_SEEN) > 64:
                 _SEEN.clear()
-            if _SEEN.get(key, 0) >= 2 and not _failed_once:
+            if _SEEN.get(key, 0) >= 2:
+                # a capture of this family under ANOTHER state can never be replayed again once the state moved on (training
+                # changed the weights, a switch was flipped): drop it now — each holds a private pool with the whole
+                # forward + backward activation set
+                for stale in [k for k in _GRAPHS if k[:len(family)] == family]:
+                    del _GRAPHS[stale]
+                for stale in [k for k in _SEEN if k[:len(family)] == family and k != key]:
+                    del _SEEN[stale]
                 try:
                     cap = _Captured(attack, images, labels, target, step_fn)
                     if len(_GRAPHS) >= _MAX_GRAPHS:
                         _GRAPHS.pop(next(iter(_GRAPHS)))
                     _GRAPHS[key] = cap
-                except Exception as exc:  # noqa: BLE001 — any capture problem means: stay eager, loudly, once
-                    _failed_once = True
+                except Exception as exc:  # noqa: BLE001 — any capture problem means: this workload stays eager, loudly
+                    _FAILED.add(family)
                     torch.cuda.synchronize()
                     warnings.warn(f"hipGraph capture of the {attack.__class__.__name__} iteration failed ({exc!r}); "
-                                  "continuing with eager launches")
+                                  "continuing with eager launches for this workload")
                     cap = None
         if cap is not None:
             adv = cap.run(adv, images, labels, target, steps // 2).detach().clone()
@@ -127,3 +145,4 @@ def clear() -> None:
     """Drop every captured graph (tests; also releases the graphs' private memory pools)."""
     _GRAPHS.clear()
     _SEEN.clear()
+    _FAILED.clear()

@@ -37,6 +37,7 @@ if str(ROOT) not in sys.path:
 
 T = 64_600
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3   # same guide: FP32 (matrix) 157.3 TFLOP/s spec (v_mfma_f32_16x16x4_f32 / 32x32x2_f32), dense
 LCNN = ("lcnn", {"frontend_algorithm": ["lfcc"], "input_channels": 1})
 SPECRNET = ("specrnet", {"frontend_algorithm": ["mel_spec"], "input_channels": 2})
 RAWNET3 = ("rawnet3", {})
@@ -58,6 +59,13 @@ WORKLOADS = {
                  "and with CW c=1 kappa=0 steps=100 lr=0.01, each adversarial batch scored by the target",
             kernel=("cw_adam_step", 32, "advstep_cw_adam_step_f32 (cw_adam_vec_kernel)")),
 }
+# matrix-core kernels of the attacked model (lcnn_ops / detector_ops launch names); their launches carry the flop they must
+# put through the matrix cores (Winograd F(2x2, 3x3): a direct 3x3 convolution's count / 2.25, unpadded)
+MODEL_MATRIX_KERNELS = {
+    1: ("conv3x3_mfm_pool2_forward", "conv3x3_mfm_pool2_backward", "conv3x3_mfm_forward", "conv3x3_backward_data"),
+    2: ("resconv_forward", "resconv_pool2_forward", "resconv_pooled_grad"),
+    3: (),        # RawNet3: library GEMMs (rocBLAS / hipBLASLt), no hand-written matrix-core kernel to price
+}
 PROFILED = ("pgd_linf_step", "pgd_linf_init", "pgd_l2_step", "pgd_l2_init", "fgsm_step", "cw_adam_step",
             "cw_tanh_sqdist", "cw_best_update", "minmax_normalize", "minmax_revert", "ce2_loss_grad")
 
@@ -70,6 +78,9 @@ def parse(argv=None):
     p.add_argument("--config", type=int, default=1, choices=sorted(WORKLOADS), help="BASELINE.json configs[N]")
     p.add_argument("--batch", type=int, default=None, help="utterances per GPU per step (default: the config's)")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-extras", action="store_true",
+                   help="skip the legs after the timed region (graph-replay timing, model-side roofline, cold-regime and "
+                        "live PMC traffic of the priced kernel); N = 1 only anyway")
     p.add_argument("--cpu-threads", type=int, default=0, help="host threads for the CPU baseline (0 = swept default)")
     p.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
                    help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only for single-GPU rehearsals)")
@@ -121,10 +132,39 @@ def cpu_baseline(config: int, threads: int, iterations: float = 0.0):
         return dict(fail, sample="timed out (900 s)")
 
 
+def live_traffic(entry_point: str, B: int):
+    """HBM bytes per launch of the priced kernel MEASURED IN THIS RUN: two `rocprofv3 --pmc` passes (FETCH_SIZE, WRITE_SIZE:
+    they do not fit one pass; --kernel-trace only, no other trace domain) over tools/traffic_probe.py — the same entry
+    point, same batch, operands rotated past the Infinity Cache — reduced with the guide's gfx950 corrections
+    (tools/hbm_traffic.py).  Returns (bytes or None, provenance)."""
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    sys.path.insert(0, str(ROOT / "tools"))
+    import hbm_traffic
+    try:
+        with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+            for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+                cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", f"{tmp}/{counter}", "--",
+                       sys.executable, str(ROOT / "tools" / "traffic_probe.py"), "--entry", entry_point, "--batch", str(B)]
+                subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, timeout=300)
+            paths = glob.glob(f"{tmp}/*/*/*counter_collection.csv") + glob.glob(f"{tmp}/*/*counter_collection.csv")
+            row = hbm_traffic.reduce(paths, batch_override=B).get(entry_point)
+    except (subprocess.TimeoutExpired, OSError, SystemExit, KeyError, ValueError) as exc:
+        return None, f"live PMC pass failed: {exc!r}"
+    if not row:
+        return None, "live PMC pass produced no counter rows for this kernel"
+    return row["hbm_bytes_per_launch"], ("measured in this run: " + hbm_traffic.SOURCE + f"; {row['launches_averaged']} launches "
+                                         f"of tools/traffic_probe.py --entry {entry_point} --batch {B}")
+
+
 def measured_traffic(entry_point: str, B: int):
-    """HBM bytes per launch of the priced kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE in
-    separate runs, gfx950 corrections applied; tools/hbm_traffic.py writes the file).  Counters cannot be read inside
-    an un-profiled run, so the line says where the figure comes from; null when no pass exists for this batch size."""
+    """Fallback when the live pass is unavailable: HBM bytes per launch from the committed rocprofv3 --pmc passes
+    (profiles/hbm_traffic.json, written by tools/hbm_traffic.py); null when no pass exists for this batch size."""
     path = ROOT / "profiles" / "hbm_traffic.json"
     if not path.exists():
         return None, "no PMC pass committed"
@@ -246,7 +286,11 @@ def main():
         avg_ms = sum(step_ms) / len(step_ms)
         launch_bytes = bytes_per_sample * B * T
         achieved = launch_bytes / (avg_ms * 1e-3) / 1e9
-        traffic, provenance = measured_traffic(entry, B)
+        extras = world == 1 and not args.no_extras
+        traffic, provenance = live_traffic(entry, B) if extras else (None, "")
+        if traffic is None:
+            t2, p2 = measured_traffic(entry, B)
+            traffic, provenance = t2, (p2 + (f" (live pass: {provenance})" if provenance else ""))
         # what an event pair measures with NOTHING between its two records (the command processor's own gap): reported beside
         # `avg_launch_ms`, not subtracted from it — it is most of the difference to the kernel trace's average duration
         stream = torch.cuda.current_stream(device)
@@ -309,11 +353,88 @@ def main():
                                                         "utterances_per_s": round(B / (ms * 1e-3), 1)}
         if k == 1:
             line["adv_eval"] = line["adv_eval"][attacks[0][0]]
+        if extras:
+            # (1) the shipped default path: the same K steps with launch profiling OFF, so the PGD / PGDL2 inner loop replays
+            #     from its hipGraph (torchattacks/graphed.py; the timed region above brackets the priced kernel with HIP
+            #     events, which a graph cannot carry, and therefore launches eagerly).  Two untimed batches first: a graph is
+            #     captured when the same (model state, shape) shows up a second time.
+            from audio_deepfake_adversarial_attacks_amd.torchattacks import graphed
+            timed_loop(0, min(2, n_batches))
+            timed_loop(0, min(2, n_batches))
+            sync_all()
+            t1 = time.perf_counter()
+            o2, c2, _ = timed_loop(args.warmup, n_batches)
+            aggregate(o2, c2, args.steps)
+            sync_all()
+            dt = time.perf_counter() - t1
+            line["shipped_path"] = {"launch_path": "hipGraph replay of the attack iteration" if len(graphed._GRAPHS) else
+                                    "eager launches (this workload's attacks do not replay from a graph)",
+                                    "graphs_captured": len(graphed._GRAPHS), "steps": args.steps,
+                                    "ms_per_step": 1e3 * dt / args.steps, "value": utterances / dt, "unit": "utterances/s"}
+            del o2, c2
+            # (2) model-side roofline: ONE step with HIP events around every launch of the attacked model's hand-written
+            #     matrix-core kernels (outside the timed region: ~400 event pairs per step would cost it ~2 %)
+            names = MODEL_MATRIX_KERNELS[args.config]
+            if names:
+                hip_ops.start_profile(*names)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                timed_loop(args.warmup, args.warmup + 1)
+                e1.record()
+                ms, work = hip_ops.stop_profile(with_work=True)
+                step_ms_profiled = e0.elapsed_time(e1)
+                tot_ms = sum(sum(v) for v in ms.values())
+                tot_flop = sum(sum(v) for v in work.values())
+                if tot_ms > 0:
+                    tflops = tot_flop / (tot_ms * 1e-3) / 1e12
+                    line["roofline_model"] = {
+                        "kernel": "wino3x3_kernel family (csrc/lcnn_wino.hip: Winograd F(2x2, 3x3) on v_mfma_f32_16x16x4_f32) via "
+                                  + ", ".join(n for n in names if ms.get(n)),
+                        "bound": "mfma", "dtype": "f32", "achieved": tflops, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": tflops / MFMA_F32_PEAK_TFLOPS,
+                        "flop_convention": "products the Winograd algorithm must put through the matrix cores (a direct 3x3 "
+                                           "convolution's count / 2.25, unpadded channels); direct-convolution-equivalent = "
+                                           "achieved x 2.25",
+                        "direct_conv_equivalent_tflops": 2.25 * tflops,
+                        "kernel_ms_per_step": tot_ms, "share_of_step": tot_ms / step_ms_profiled, "launches_timed":
+                        sum(len(v) for v in ms.values()),
+                        "per_entry_point": {n: {"launches": len(ms[n]), "ms_per_step": round(sum(ms[n]), 3),
+                                                "tflops": round(sum(work[n]) / (sum(ms[n]) * 1e-3) / 1e12, 2)}
+                                            for n in names if ms.get(n)},
+                    }
+            # (3) the priced kernel with its operands rotated past the 256 MiB Infinity Cache (the hot figure above runs on a
+            #     132 MB working set that the cache holds): same clock, one event pair per launch
+            sys.path.insert(0, str(ROOT / "tools"))
+            import traffic_probe
+            cold_ms = traffic_probe.cold_launch_ms(entry, B, device)
+            line["roofline"]["avg_launch_ms_cold"] = cold_ms
+            line["roofline"]["achieved_cold"] = launch_bytes / (cold_ms * 1e-3) / 1e9
+            line["roofline"]["frac_cold"] = line["roofline"]["achieved_cold"] / HBM_PEAK_GBS
+        # CW stops early on its own cost (cw.py:107-110): report what it executed, per iteration, and price the CPU leg at the
+        # iterations the GPU run executed
+        cw_iters = len(kernel_ms.get("cw_adam_step", ())) / args.steps if args.config == 3 else 0.0
+        if cw_iters:
+            cw = line["per_attack"]["CW"]
+            cw["iterations_per_batch"] = cw_iters
+            cw["ms_per_iteration"] = round(cw["ms_per_batch"] / cw_iters, 3)
+            cw["note"] = (f"cw.py:107-110 stops on its own cost after {cw_iters:g} of 100 iterations on this input; "
+                          "ms_per_iteration is the comparable figure")
+            if extras:
+                # the same attack with the early stop switched off (CW.set_early_stop(False), additive): all 100 iterations
+                atk_cw = dict(attacks)["CW"]
+                atk_cw.set_early_stop(False)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                adv_full = attack_batch(atk_cw, x_all[:B], y_all[:B])
+                score_batch(target, adv_full)
+                e1.record()
+                torch.cuda.synchronize()
+                atk_cw.set_early_stop(True)
+                full_ms = e0.elapsed_time(e1)
+                cw["without_early_stop"] = {"iterations": atk_cw.steps, "ms_per_batch": round(full_ms, 1),
+                                            "ms_per_iteration": round(full_ms / atk_cw.steps, 3),
+                                            "utterances_per_s": round(B / (full_ms * 1e-3), 2)}
         if world == 1 and not args.no_cpu_baseline:
-            # CW stops early on its own cost (cw.py:107-110): price the CPU leg at the iterations the GPU run executed
-            cw_iters = len(kernel_ms.get("cw_adam_step", ())) / args.steps if args.config == 3 else 0.0
-            if cw_iters:
-                line["per_attack"]["CW"]["iterations_per_batch"] = cw_iters
             line["cpu_baseline"] = cpu_baseline(args.config, args.cpu_threads, cw_iters)
         print(json.dumps(line), flush=True)
 

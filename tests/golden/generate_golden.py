@@ -591,6 +591,42 @@ def gen_frontends_xcheck():
     np.savez_compressed(OUT / "frontends_xcheck.npz", **out)
 
 
+def gen_frontends_batch_floor():
+    """The one reading of torchaudio 0.10's LFCC that gen_frontends_xcheck cannot see: `amplitude_to_DB(top_db=80)` on
+    the 3-D (B, n_filter, time) tensor LFCC hands it takes its floor from the maximum over the WHOLE BATCH
+    (src/frontends.py:24-32 -> torchaudio LFCC.forward; SURVEY.md section 7 "Unpinned third-party arithmetic").  Still not
+    the reference — third-party pieces (transformers.audio_utils framing / window / FFT / triangular bank, scipy's DCT) with
+    the batch-wide floor applied BY HAND between them:
+
+      x          (3, 16160): a loud (x 6), a quiet (x 0.002) and a near-silent (x 3e-4) utterance
+      lfcc_batch (3, 80, frames): dB = 10 log10(max(bands, 1e-10)); floor = max over all three utterances - 80;
+                  dB = max(dB, floor); DCT.  The quiet utterances sit largely BELOW the loud one's floor.
+      lfcc_each  (3, 80, frames): the same with the floor taken per utterance (what processing one utterance at a time, or
+                  a different sharding of the batch, would give) — must differ from lfcc_batch for rows 1 and 2."""
+    import scipy.fft
+    from transformers import audio_utils as au
+
+    window = au.window_function(400, "hann", periodic=True)
+    linear_bank = au._create_triangular_filter_bank(np.linspace(0, 8000, 257), np.linspace(0.0, 8000.0, 130))   # (257, 128)
+    x = waveforms(3, 16_160, 95)
+    x[0] *= 6.0
+    x[1] *= 0.002
+    x[2] *= 3e-4
+    db = []
+    for row in x.numpy():
+        power = au.spectrogram(row, window, frame_length=400, hop_length=160, fft_length=512, power=2.0, center=True,
+                               pad_mode="reflect", onesided=True)
+        db.append(10.0 * np.log10(np.maximum(linear_bank.T @ power, 1e-10)))
+    db = np.stack(db)                                                        # (3, 128, frames), float64
+    batch = np.maximum(db, db.max() - 80.0)
+    each = np.maximum(db, db.max(axis=(1, 2), keepdims=True) - 80.0)
+    assert (batch[1] != each[1]).mean() > 0.2 and (batch[2] != each[2]).mean() > 0.9 and np.array_equal(batch[0], each[0])
+    dct = lambda a: scipy.fft.dct(a, type=2, norm="ortho", axis=1)[:, :80]
+    np.savez_compressed(OUT / "frontends_batch_floor.npz", x=npy(x), lfcc_batch=dct(batch).astype(np.float32),
+                        lfcc_each=dct(each).astype(np.float32),
+                        floored_share=np.array([(db[k] < db.max() - 80.0).mean() for k in range(3)]))
+
+
 def gen_datasets():
     """PadDataset.apply_pad, wavefake_preprocessing_on_batch (SoX steps off), the corpus
     listings of DetectionDataset on the miniature corpora of tests/helpers.build_corpus_trees, and AttackAnalyser's
@@ -711,10 +747,14 @@ def main():
     gen_model_bodies()
     gen_rawnet3_body()
     gen_frontends_xcheck()
+    gen_frontends_batch_floor()
     gen_datasets()
     for p in sorted(OUT.glob("*.npz")):
         print(f"{p.name}: {p.stat().st_size / 1e6:.2f} MB")
 
 
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["frontends_batch_floor"]:      # third-party code only: does not need the reference tree
+        gen_frontends_batch_floor()
+    else:
+        main()

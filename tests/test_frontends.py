@@ -139,3 +139,30 @@ def test_lfcc_restatement_matches_independent_implementation(golden, tag):
 @pytest.mark.parametrize("tag", XCHECK_CASES)
 def test_mel_spec_restatement_matches_independent_implementation(golden, tag):
     assert mel_error(F.MelSpecFrontend(), golden("frontends_xcheck"), tag) <= 2e-5  # measured 7e-6 .. 9e-6
+
+
+# ---- the batch-wide dB floor (tests/golden/frontends_batch_floor.npz; generate_golden.py::gen_frontends_batch_floor) ---------
+
+def batch_floor_errors(frontend, fixture, device="cpu"):
+    """(error of LFCC(whole batch) vs the hand-applied batch-wide floor, error of the SAME batch vs per-utterance floors,
+    error of LFCC one utterance at a time vs per-utterance floors), each max-abs over the output scale."""
+    x = torch.from_numpy(fixture["x"]).to(device)
+    batch = torch.from_numpy(fixture["lfcc_batch"]).to(device)
+    each = torch.from_numpy(fixture["lfcc_each"]).to(device)
+    scale = batch.abs().max()
+    got = frontend(x)
+    alone = torch.cat([frontend(x[i:i + 1]) for i in range(x.shape[0])])
+    return (((got - batch).abs().max() / scale).item(), ((got - each).abs().max() / scale).item(),
+            ((alone - each).abs().max() / scale).item())
+
+
+def test_lfcc_db_floor_is_taken_over_the_whole_batch(golden):
+    """A loud, a quiet and a near-silent utterance in ONE batch: 64 % / 100 % of the two quiet ones' band values lie below
+    (loudest value of the batch - 80 dB) and are floored there — the restatement's reading of torchaudio 0.10's
+    amplitude_to_DB on LFCC's 3-D input (src/frontends.py:24-32).  The third-party chain with that floor applied by hand
+    agrees to 1e-5 of scale; per-utterance floors (what another chunking of the batch would give — the reason shards are
+    contiguous) do NOT: they differ by tens of dB-scaled coefficients."""
+    vs_batch, vs_each, alone_vs_each = batch_floor_errors(F.LFCC(), golden("frontends_batch_floor"))
+    assert vs_batch <= 1e-5, vs_batch
+    assert vs_each >= 1e-2, vs_each                 # the batch result is NOT the per-utterance one
+    assert alone_vs_each <= 1e-5, alone_vs_each     # one utterance at a time reproduces the per-utterance floors

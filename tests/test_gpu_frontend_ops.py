@@ -215,3 +215,17 @@ def test_fused_mel_spec_matches_independent_implementation(cuda, golden, parity_
     err = mel_error(frontends.MelSpecFrontend().to(cuda), golden("frontends_xcheck"), tag, cuda)
     parity_record[f"fused_mel_spec_vs_third_party_{tag}_max_over_scale"] = err
     assert err <= 2e-5, err
+
+
+def test_fused_lfcc_db_floor_is_taken_over_the_whole_batch(cuda, golden, parity_record):
+    """tests/test_frontends.py::test_lfcc_db_floor_is_taken_over_the_whole_batch for the fused kernels (the floor is a
+    batch-wide maximum found in a separate launch, `advstep_lfcc_reduce_max_f32`): the batch result equals the third-party
+    chain with the batch-wide floor applied by hand, and is NOT what per-utterance floors give."""
+    from audio_deepfake_adversarial_attacks_amd import frontends
+    from tests.test_frontends import batch_floor_errors
+    vs_batch, vs_each, alone_vs_each = batch_floor_errors(frontends.LFCC().to(cuda), golden("frontends_batch_floor"), cuda)
+    parity_record["fused_lfcc_batch_floor"] = {"vs_batch_wide_floor_max_over_scale": vs_batch,
+                                               "vs_per_utterance_floors_max_over_scale": vs_each,
+                                               "one_at_a_time_vs_per_utterance_floors": alone_vs_each}
+    assert vs_batch <= 2e-5 and alone_vs_each <= 2e-5, (vs_batch, alone_vs_each)
+    assert vs_each >= 1e-2, vs_each

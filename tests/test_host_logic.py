@@ -335,3 +335,41 @@ def test_fab_public_gradient_helpers_keep_reference_shapes(golden):
     df_t, dg_t = atk.get_diff_logits_grads_batch_targeted(x01, y, 1 - y)
     assert df_t.shape == (6, 1) and dg_t.shape == (6, 1, x01.shape[1])
     assert torch.allclose(df_t[:, 0], df[u, 1 - y]) and torch.allclose(dg_t[:, 0], dg[u, 1 - y])
+
+
+def test_res_block_shape_limits_mirror_the_kernels():
+    """an oversize batch must take the fallback path instead of raising from inside the fused block — the
+    predicate restates resconv_check / fewin_dims_ok (32-bit buffer offsets per tensor, grid.y <= 65535)."""
+    from audio_deepfake_adversarial_attacks_amd import detector_ops as D
+    assert D.res_block_shape_supported((128, 2, 80, 404), 20)           # BASELINE configs[2], block0
+    assert D.res_block_shape_supported((128, 20, 40, 202), 64)
+    assert not D.res_block_shape_supported((1024, 2, 80, 404), 20)      # 1024 x 20 x 80 x 404 x 4 B > 2 GiB
+    assert not D.res_block_shape_supported((70_000, 1, 4, 4), 4)        # grid.y
+
+
+def test_same_conv1d_fallback_keeps_the_modules_padding_mode():
+    """the helper's fallback must run the module's own forward (reflect / circular padding), also without bias."""
+    import torch.nn as nn
+    from audio_deepfake_adversarial_attacks_amd.models import rawnet3 as R
+    torch.manual_seed(0)
+    conv = nn.Conv1d(4, 4, 3, dilation=2, padding=2, padding_mode="reflect")
+    x = torch.randn(2, 4, 20)
+    assert torch.equal(R._same_conv1d(x, conv, True), conv(x))
+    want = conv(x) - conv.bias.view(1, -1, 1)
+    assert torch.allclose(R._same_conv1d(x, conv, False), want, atol=1e-6)
+    zeros = nn.Conv1d(4, 4, 3, dilation=2, padding=2)
+    assert torch.equal(R._same_conv1d(x, zeros, True), zeros(x))
+
+
+def test_graph_cache_key_carries_switches_and_labels(monkeypatch):
+    """what a captured graph bakes in beyond the weights — the ADVSTEP_* switches read at call time — is part of
+    its key; clear() also forgets failed captures."""
+    from audio_deepfake_adversarial_attacks_amd.torchattacks import graphed
+    monkeypatch.setenv("ADVSTEP_L2_SINGLE_PASS", "1")
+    a = graphed._toggles()
+    monkeypatch.setenv("ADVSTEP_L2_SINGLE_PASS", "0")
+    b = graphed._toggles()
+    assert a != b and ("ADVSTEP_L2_SINGLE_PASS", "0") in b
+    graphed._FAILED.add(("x",))
+    graphed.clear()
+    assert not graphed._FAILED and not graphed._GRAPHS and not graphed._SEEN

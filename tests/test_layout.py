@@ -45,7 +45,7 @@ def test_library_basics_without_gpu(lib):
     # 4 planes of ceil(T / 4096) floats per row (two partial-sum planes, or two planes of 8-byte granules) + one 32-bit
     # "row needs repair" flag per row (single-pass PGD-L2 paths)
     assert lib.advstep_row_workspace_bytes(128, 64_600) == 4 * 128 * 16 * 4 + 128 * 4
-    assert lib.advstep_row_workspace_bytes(1, 1) == 64 and lib.advstep_row_workspace_bytes(0, 5) == 0
+    assert lib.advstep_row_workspace_bytes(1, 1) == 64 + 16 and lib.advstep_row_workspace_bytes(0, 5) == 0
 
 
 def test_argument_validation_needs_no_device(lib):

@@ -24,13 +24,14 @@ T = 64_600
 # entry point -> (kernel-name patterns of ONE call, algorithmic bytes per sample, batch size of the pass = bench.py's)
 ENTRY_POINTS = {
     "pgd_linf_step": ([r"flat_vec_kernel<3,.*PgdLinfOp"], 16, 128),
-    "pgd_l2_step": ([r"pgd_l2_fused_kernel"], 16, 128),      # (three-kernel path: sumsq_partial + pgd_l2_delta + pgd_l2_project)
+    # one call = the single-pass kernel + the repair kernel queued behind it (reads one flag per row unless a row was abandoned)
+    "pgd_l2_step": ([r"pgd_l2_fused_kernel", r"pgd_l2_repair_kernel"], 16, 128),   # (three-kernel path: sumsq_partial + pgd_l2_delta + pgd_l2_project)
     "cw_adam_step": ([r"cw_adam_vec_kernel"], 32, 64),
 }
 
 
-def main():
-    out, paths = sys.argv[1], sys.argv[2:]
+def reduce(paths, batch_override=None):
+    """{entry point: traffic row} from rocprofv3 counter_collection CSVs (FETCH_SIZE and WRITE_SIZE passes)."""
     # kernel name -> counter -> [(grid size, value)]
     rows = collections.defaultdict(lambda: collections.defaultdict(list))
     for path in paths:
@@ -39,12 +40,13 @@ def main():
                 rows[r["Kernel_Name"]][r["Counter_Name"]].append((int(r["Grid_Size"]), float(r["Counter_Value"])))
     table = {}
     for entry, (patterns, bytes_per_sample, batch) in ENTRY_POINTS.items():
+        batch = batch_override or batch
         fetch = write = 0.0
         launches, found = None, True
-        for pat in patterns:
+        for n_pat, pat in enumerate(patterns):
             names = [k for k in rows if re.search(pat, k)]
             if not names or not all(c in rows[names[0]] for c in ("FETCH_SIZE", "WRITE_SIZE")):
-                found = False
+                found = n_pat > 0 and launches is not None        # companion kernels are optional (older builds lack them)
                 break
             k = names[0]
             f_vals = [v for _, v in rows[k]["FETCH_SIZE"]]
@@ -61,6 +63,16 @@ def main():
         table[entry] = {"batch": batch, "hbm_bytes_per_launch": fetch + write, "fetch_bytes_corrected": fetch,
                         "write_bytes": write, "algorithmic_bytes_per_launch": bytes_per_sample * batch * T,
                         "ratio_to_algorithmic": (fetch + write) / (bytes_per_sample * batch * T), "launches_averaged": launches}
+    return table
+
+
+SOURCE = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), cold regime (5 buffer sets); both counters in KiB, "
+          "FETCH_SIZE x 2 (gfx950 16 B/lane coalesced-read correction); reduced by tools/hbm_traffic.py")
+
+
+def main():
+    out, paths = sys.argv[1], sys.argv[2:]
+    table = reduce(paths)
     doc = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over tools/kernel_microbench.py, cold regime "
                      "(5 buffer sets); both counters in KiB, FETCH_SIZE x 2 (gfx950 16 B/lane coalesced-read correction); "
                      "reduced by tools/hbm_traffic.py",
