@@ -4,7 +4,11 @@ from __future__ import annotations
 import ctypes
 from pathlib import Path
 
-_LIB_PATH = Path(__file__).resolve().parent / "libadvstep.so"
+import os
+
+# ADVSTEP_LIB: another build of the library (A/B measurements of experimental kernels); the default is the in-tree build,
+# which must match the present sources (build key) to load
+_LIB_PATH = Path(os.environ.get("ADVSTEP_LIB") or Path(__file__).resolve().parent / "libadvstep.so")
 _lib = None
 
 OK, EINVAL, EWORKSPACE, ELAUNCH, ENODEVICE = 0, 1, 2, 3, 4

@@ -26,9 +26,15 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
                "-shared"]
 
 
+def _flags() -> list:
+    """HIPCC_FLAGS + ADVSTEP_EXTRA_HIPCC_FLAGS (experiments: -DWINO_PREFETCH=2 ...); part of the build key."""
+    import os
+    return HIPCC_FLAGS + os.environ.get("ADVSTEP_EXTRA_HIPCC_FLAGS", "").split()
+
+
 def build_key() -> str:
     """SHA-256 over the compiler flags and the bytes of every source and header: what the library was built from."""
-    h = hashlib.sha256(" ".join(HIPCC_FLAGS).encode())
+    h = hashlib.sha256(" ".join(_flags()).encode())
     for p in SOURCES + HEADERS:
         h.update(p.name.encode())
         h.update(p.read_bytes())
@@ -45,7 +51,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     if not force and is_current():
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc, *HIPCC_FLAGS, f"-I{ROOT / 'include'}", *map(str, SOURCES), "-o", str(LIB)]
+    cmd = [hipcc, *_flags(), f"-I{ROOT / 'include'}", *map(str, SOURCES), "-o", str(LIB)]
     if verbose:
         print(" ".join(cmd))
     STAMP.unlink(missing_ok=True)

@@ -216,7 +216,9 @@ struct GenArgs {
     int xcd;          // 1: workgroups b, b + 8, b + 16, ... (one XCD, one L2) take the slices of the same tile ranges
 };
 
-template <int EPI, bool STREAM, int SRC, int NT = 2, bool GEN = false>
+// WODD (SRC 0): the plane width is odd, so the last tile of a row has no second column and its pair load's second element must
+//     be masked; even widths (all of LCNN's) skip those 4 selects per k-step.
+template <int EPI, bool STREAM, int SRC, int NT = 2, bool GEN = false, bool WODD = false>
 __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restrict__ x, const uint8_t *__restrict__ xsel,
                                                            const float *__restrict__ U,
                                                            const float *__restrict__ bias,
@@ -242,10 +244,33 @@ __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restri
 #pragma unroll
         for (int i = 0; i < kChunkFloats / 4 / kThreads; ++i) dst[threadIdx.x + i * kThreads] = src[threadIdx.x + i * kThreads];
     };
+    // Per-slice epilogue constants, staged once per workgroup (round 3; they were 16 global loads + their address arithmetic per
+    // tile group): cst[0..15] / cst[16..31] = what is added to the two accumulator tiles' rows — the convolution's bias (EPI 1 / 2:
+    // of the two max-feature-map halves, minus the folded BatchNorm's mean: max-feature-map and max-pool commute with a
+    // per-channel shift), EPI 3's shift, EPI 4's bias; cst[32..47] = the BatchNorm's 1 / std (EPI 1 / 2).  The additive part
+    // enters through the matrix instruction's C operand: position (1, 1) of M reaches all four outputs of A^T M A with weight
+    // +1, so its accumulator starts at the constant instead of 0 and the epilogue has no bias adds.
+    constexpr bool kHasConst = EPI == 1 || EPI == 2 || EPI == 3 || EPI == 4;
+    __shared__ __attribute__((aligned(16))) float cst[48];
+    if (kHasConst && threadIdx.x < 48) {
+        const int q = threadIdx.x >> 4, j = threadIdx.x & 15;
+        float v = q == 2 ? 1.0f : 0.0f;
+        if (EPI == 1 || EPI == 2) {
+            const int ch = slice * 16 + j;
+            if (ch < Cout) {
+                if (q == 2) v = bn_mean ? bn_invstd[ch] : 1.0f;
+                else v = (bias ? bias[ch + q * Cout] : 0.0f) - (bn_mean ? bn_mean[ch] : 0.0f);
+            }
+        } else if (q < 2) {
+            const int ch = slice * 32 + q * 16 + j;
+            if (ch < Cout && bias) v = bias[ch];
+        }
+        cst[threadIdx.x] = v;
+    }
     if (!STREAM) {
         for (int c = 0; c < chunks; ++c) copy_chunk(c, c);
-        __syncthreads();
     }
+    if (!STREAM || kHasConst) __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, nl = lane & 15;
     const int TH = (H + 1) >> 1, TW = (W + 1) >> 1;
     const int tiles = N * TH * TW, groups = (tiles + 15) >> 4;
@@ -360,7 +385,7 @@ __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restri
                         float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, e), __builtin_bit_cast(int, a), 0x101, 0xf, 0xf, false));
                     d[p][0] = ok_l[p] ? left : 0.0f;
                     d[p][1] = a;
-                    d[p][2] = ok_2[p] ? b : 0.0f;
+                    d[p][2] = (WODD && !ok_2[p]) ? 0.0f : b;      // even width: an invalid row's pair was loaded as 0 already
                     d[p][3] = ok_r[p] ? right : 0.0f;
                 }
             } else {
@@ -406,6 +431,11 @@ __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restri
             }
             __builtin_amdgcn_sched_barrier(0);
             const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+            f32x4 c0 = zero, c1 = zero;                         // the first k-step's C operand of position (1, 1): see cst[]
+            if (decltype(first)::value && kHasConst) {
+                c0 = *reinterpret_cast<const f32x4 *>(cst + 4 * g);
+                c1 = *reinterpret_cast<const f32x4 *>(cst + 16 + 4 * g);
+            }
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int grp = 0; grp < 8; ++grp) {
@@ -413,9 +443,11 @@ __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restri
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     const int xi = 2 * grp + e;
-                    acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[grp][e].x, v[xi >> 2][xi & 3], decltype(first)::value ? zero : acc[xi][0], 0, 0, 0);
+                    acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[grp][e].x, v[xi >> 2][xi & 3],
+                                                                      decltype(first)::value ? (xi == 5 ? c0 : zero) : acc[xi][0], 0, 0, 0);
                     if (NT == 2)
-                        acc[xi][NT - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[grp][e].y, v[xi >> 2][xi & 3], decltype(first)::value ? zero : acc[xi][NT - 1], 0, 0, 0);
+                        acc[xi][NT - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[grp][e].y, v[xi >> 2][xi & 3],
+                                                                           decltype(first)::value ? (xi == 5 ? c1 : zero) : acc[xi][NT - 1], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -477,12 +509,10 @@ __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restri
             if (EPI == 1) {
                 const int ch = slice * 16 + 4 * g + r;
                 const bool live = ch < Cout;
-                const int chs = live ? ch : 0;
-                const float ba = bias ? bias[chs] : 0.0f, bb = bias ? bias[chs + Cout] : 0.0f;
-                int code;
-                float vbest = pool_select(yy[0][0][0] + ba, yy[1][0][0] + bb, yy[0][0][1] + ba, yy[1][0][1] + bb,
-                                          yy[0][1][0] + ba, yy[1][1][0] + bb, yy[0][1][1] + ba, yy[1][1][1] + bb, code);
-                if (bn_mean) vbest = (vbest - bn_mean[chs]) * bn_invstd[chs];
+                int code;       // (bias - BatchNorm mean came in through the accumulator of position (1, 1): cst[])
+                float vbest = pool_select(yy[0][0][0], yy[1][0][0], yy[0][0][1], yy[1][0][1], yy[0][1][0], yy[1][1][0], yy[0][1][1],
+                                          yy[1][1][1], code);
+                if (bn_mean) vbest *= cst[32 + 4 * g + r];
                 if (valid && live && th < Ho && tw < Wo) {
                     const size_t o = ((size_t)n * Cout + ch) * Ho * Wo + (size_t)th * Wo + tw;
                     y[o] = vbest;
@@ -493,19 +523,17 @@ __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restri
                 // "second half won" bits (bit = 2 * row + col), (N, C, TH, TW)
                 const int ch = slice * 16 + 4 * g + r;
                 const bool live = ch < Cout;
-                const int chs = live ? ch : 0;
-                const float ba = bias ? bias[chs] : 0.0f, bb = bias ? bias[chs + Cout] : 0.0f;
-                const float mu = bn_mean ? bn_mean[chs] : 0.0f, sc = bn_mean ? bn_invstd[chs] : 1.0f;
+                const float sc = cst[32 + 4 * g + r];
                 float out[2][2];
                 uint32_t bits = 0;
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
-                        const float va = yy[0][i][j] + ba, vb = yy[1][i][j] + bb;
+                        const float va = yy[0][i][j], vb = yy[1][i][j];
                         const bool tb = mfm_takes_b(va, vb);
                         bits |= (uint32_t)tb << (2 * i + j);
-                        out[i][j] = ((tb ? vb : va) - mu) * sc;
+                        out[i][j] = bn_mean ? (tb ? vb : va) * sc : (tb ? vb : va);
                     }
                 if (valid && live) {
                     float *o = y + (((size_t)n * Cout + ch) * H + 2 * th) * W + 2 * tw;
@@ -523,12 +551,11 @@ __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restri
                 for (int m = 0; m < NT; ++m) {
                     const int ch = slice * 32 + m * 16 + 4 * g + r;
                     const bool live = ch < Cout;
-                    const float b = bias ? bias[live ? ch : 0] : 0.0f;
                     float best = -INFINITY;
                     int code = 0;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {      // ATen's scan: row-major, take when (v > best) || isnan(v)
-                        const float v = yy[m][e >> 1][e & 1] + b;
+                        const float v = yy[m][e >> 1][e & 1];
                         if (v > best || v != v) { best = v; code = e; }
                     }
                     if (valid && live && th < Ho && tw < Wo) {
@@ -543,10 +570,9 @@ __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restri
                     const int ch = slice * 32 + m * 16 + 4 * g + r;
                     if (!(valid && ch < Cout)) continue;
                     if (EPI == 3) {
-                        const float b = bias ? bias[ch] : 0.0f;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const float v = yy[m][e >> 1][e & 1] + b;
+                            const float v = yy[m][e >> 1][e & 1];
                             yy[m][e >> 1][e & 1] = v > 0.0f ? v : v * ga.slope;
                         }
                     }
@@ -626,6 +652,7 @@ int launch_wino(const float *x, const uint8_t *xsel, const float *U, const float
     const bool stream = chunks > kMaxResident;
     const int64_t groups = ceil_div(N * ((H + 1) / 2) * ((W + 1) / 2), 16);
     const size_t lds = (size_t)(stream ? 2 : chunks) * kChunkFloats * sizeof(float);
+    const bool wodd = SRC == 0 && (W & 1);
     auto go = [&](auto kernel, int n_slices, int slice0) {
         int ranges = cus / n_slices;
         if ((int64_t)ranges * kWaves > groups) ranges = (int)ceil_div(groups, kWaves);
@@ -652,13 +679,13 @@ int launch_wino(const float *x, const uint8_t *xsel, const float *U, const float
         const int live_last = (int)(Cout - (int64_t)(slices - 1) * 32);
         if (live_last <= 16 && half_slice_enabled()) {
             full = slices - 1;
-            if (stream) go(wino3x3_kernel<EPI, true, SRC, 1, GEN>, 1, slices - 1);
-            else go(wino3x3_kernel<EPI, false, SRC, 1, GEN>, 1, slices - 1);
+            if (stream) wodd ? go(wino3x3_kernel<EPI, true, SRC, 1, GEN, SRC == 0>, 1, slices - 1) : go(wino3x3_kernel<EPI, true, SRC, 1, GEN>, 1, slices - 1);
+            else wodd ? go(wino3x3_kernel<EPI, false, SRC, 1, GEN, SRC == 0>, 1, slices - 1) : go(wino3x3_kernel<EPI, false, SRC, 1, GEN>, 1, slices - 1);
         }
     }
     if (full > 0) {
-        if (stream) go(wino3x3_kernel<EPI, true, SRC, 2, GEN>, full, 0);
-        else go(wino3x3_kernel<EPI, false, SRC, 2, GEN>, full, 0);
+        if (stream) wodd ? go(wino3x3_kernel<EPI, true, SRC, 2, GEN, SRC == 0>, full, 0) : go(wino3x3_kernel<EPI, true, SRC, 2, GEN>, full, 0);
+        else wodd ? go(wino3x3_kernel<EPI, false, SRC, 2, GEN, SRC == 0>, full, 0) : go(wino3x3_kernel<EPI, false, SRC, 2, GEN>, full, 0);
     }
     return status_after_launch();
 }
