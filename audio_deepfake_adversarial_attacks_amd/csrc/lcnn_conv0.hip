@@ -51,6 +51,29 @@ __device__ __forceinline__ float pool_select(float a00, float b00, float a01, fl
     return best;
 }
 
+// The same selection in 4 + 15 instead of ~33 vector instructions (round 3): gfx950's v_maximum3_f32 propagates NaN, so the
+// maximum of the 8 candidates is the pooled value whenever no candidate is NaN, and the winner's code is the FIRST candidate
+// in the reference's scan order (a00, b00, a01, b01, a10, b10, a11, b11: `a` keeps ties inside a position, the earlier position
+// keeps ties between positions) that equals it.  A NaN among the candidates (best != best) takes the step-by-step rule above.
+// (A tie between -0 and +0 returns +0 where the scan returns the first: convolution outputs, not bit-compared.)
+__device__ __forceinline__ float pool_select_fast(float a00, float b00, float a01, float b01, float a10, float b10,
+                                                  float a11, float b11, int &code) {
+    const float best = __builtin_elementwise_maximum(
+        __builtin_elementwise_maximum(__builtin_elementwise_maximum(a00, b00), __builtin_elementwise_maximum(a01, b01)),
+        __builtin_elementwise_maximum(__builtin_elementwise_maximum(a10, b10), __builtin_elementwise_maximum(a11, b11)));
+    if (best != best) return pool_select(a00, b00, a01, b01, a10, b10, a11, b11, code);
+    int c = 7;
+    c = a11 == best ? 3 : c;
+    c = b10 == best ? 6 : c;
+    c = a10 == best ? 2 : c;
+    c = b01 == best ? 5 : c;
+    c = a01 == best ? 1 : c;
+    c = b00 == best ? 4 : c;
+    c = a00 == best ? 0 : c;
+    code = c;
+    return best;
+}
+
 __global__ __launch_bounds__(kBlock) void conv5_mfm_pool2_forward_kernel(const float *__restrict__ x,
                                                                          const float *__restrict__ weight,
                                                                          const float *__restrict__ bias,
@@ -107,10 +130,16 @@ __global__ __launch_bounds__(kBlock) void conv5_mfm_pool2_forward_kernel(const f
                 b1 = __builtin_elementwise_fma((f32x2){ub, ub}, t1, b1);
             }
         }
-        const float ba = bias ? bias[c] : 0.0f, bb = bias ? bias[c + C] : 0.0f;
         int code;
-        const float v = pool_select(a0.x + ba, b0.x + bb, a0.y + ba, b0.y + bb, a1.x + ba, b1.x + bb, a1.y + ba, b1.y + bb,
-                                    code);
+        // bias AFTER the taps, as the reference's convolution adds it (starting the accumulators at the bias was measured: it
+        // re-routes 34 near-tie winners of 33 M against the MIOpen path on the LFCC input, whose sums are ~1e3 x the bias);
+        // four packed adds
+        const float ba = bias ? bias[c] : 0.0f, bb = bias ? bias[c + C] : 0.0f;
+        a0 += (f32x2){ba, ba};
+        a1 += (f32x2){ba, ba};
+        b0 += (f32x2){bb, bb};
+        b1 += (f32x2){bb, bb};
+        const float v = pool_select_fast(a0.x, b0.x, a0.y, b0.y, a1.x, b1.x, a1.y, b1.y, code);
         yn[(int64_t)c * Ho * Wo] = v;
         in[(int64_t)c * Ho * Wo] = (uint8_t)code;
     }
@@ -175,6 +204,9 @@ __global__ __launch_bounds__(kBlock) void conv5_mfm_pool2_backward_kernel(const 
     // function of the 3 code bits: an 8-entry byte-offset table in LDS (one ds_read instead of six VALU instructions).
     f32x2 acc0 = {0.0f, 0.0f}, acc1 = {0.0f, 0.0f};
     const char *lut_b = reinterpret_cast<const char *>(lut);
+    // (Round 3, measured and not kept: requesting channel c + 1's nine (selection byte, gradient) pairs before channel c's are
+    // consumed — two register sets, scheduling barriers — 150 -> 159 us; the offset table as five VALU instructions instead of
+    // an LDS read: 161 us.  The loop is bound by its 27 LDS reads per channel, not by the latency of its 18 vector-memory loads.)
     for (int c = 0; c < C; ++c) {
         const uint32_t gsoff = (uint32_t)c * plane * 4u, isoff = (uint32_t)c * plane;   // wave-uniform
         const char *wc = reinterpret_cast<const char *>(wl + c * kTabWords);
