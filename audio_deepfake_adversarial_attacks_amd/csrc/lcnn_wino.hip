@@ -261,11 +261,33 @@ __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restri
     const int slice = slice0 + slice_i;
     const int chunks = (K + kChunkCin - 1) / kChunkCin, steps = K / 4;
     const float *Usl = U + (int64_t)slice * chunks * kChunkFloats;
+    // STREAM with a compact source: a chunk goes global -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers, nothing
+    // to wait for at the point of issue; round 3).  Through registers the four loads of a chunk are followed at once by their four
+    // ds_write, i.e. by s_waitcnt vmcnt(0), right after every chunk barrier.  Measured: compact-source input gradients 286 -> 281
+    // and 170 -> 167 us; the dense-source ones get SLOWER (276 -> 287 us: with a DMA in flight hipcc waits vmcnt(0) at the next
+    // use of an ordinary load, which drains their patch prefetch), so they keep the register path.  The DMA's completion is waited
+    // for (vmcnt(0)) before the barrier that publishes the chunk.  The LDS destination of a wave-instruction is a wave-uniform
+    // base + lane x 16 B, which is exactly this copy's layout.
+#ifndef WINO_GLDS
+#define WINO_GLDS (SRC == 1)
+#endif
     auto copy_chunk = [&](int chunk, int buf) {
         const float4 *src = reinterpret_cast<const float4 *>(Usl + (int64_t)chunk * kChunkFloats);
         float4 *dst = reinterpret_cast<float4 *>(u_s + buf * kChunkFloats);
+        if (STREAM && WINO_GLDS) {
+            const int w64 = (threadIdx.x >> 6) << 6;
 #pragma unroll
-        for (int i = 0; i < kChunkFloats / 4 / kThreads; ++i) dst[threadIdx.x + i * kThreads] = src[threadIdx.x + i * kThreads];
+            for (int i = 0; i < kChunkFloats / 4 / kThreads; ++i)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + threadIdx.x + i * kThreads),
+                                                 (__attribute__((address_space(3))) void *)(dst + w64 + i * kThreads), 16, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < kChunkFloats / 4 / kThreads; ++i) dst[threadIdx.x + i * kThreads] = src[threadIdx.x + i * kThreads];
+        }
+    };
+    // every LDS-DMA transfer of this wave has landed (vmcnt(0); expcnt / lgkmcnt untouched) — before the barrier that publishes it
+    auto dma_landed = [&]() {
+        if (STREAM && WINO_GLDS) __builtin_amdgcn_s_waitcnt(0x0F70);
     };
     // Per-slice epilogue constants, staged once per workgroup (round 3; they were 16 global loads + their address arithmetic per
     // tile group): cst[0..15] / cst[16..31] = what is added to the two accumulator tiles' rows — the convolution's bias (EPI 1 / 2:
@@ -483,6 +505,7 @@ __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restri
         if (STREAM) {
             __syncthreads();            // previous iteration's readers are done with both buffers
             copy_chunk(0, 0);
+            dma_landed();
             __syncthreads();
         }
         load_patch(da, 0);
@@ -494,6 +517,7 @@ __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restri
 #pragma unroll 1
         for (int s = 2; s + 1 < steps; s += 2) {
             if (STREAM && (s & 3) == 0) {
+                dma_landed();
                 __syncthreads();        // chunk s/4 is complete in its buffer; chunk s/4 - 1 is free
                 if (s / 4 + 1 < chunks) copy_chunk(s / 4 + 1, (s / 4 + 1) & 1);
             }
@@ -507,7 +531,10 @@ __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restri
             // an odd number of k-steps (K a multiple of 4, not of 8 — SpecRNet's 20-channel layers: 5 steps instead of 6): the last
             // one on its own; its patch was requested by the last pair (or by the prologue when steps == 3)
             const int s = steps - 1;
-            if (STREAM && (s & 3) == 0) __syncthreads();        // its chunk was copied one pair earlier
+            if (STREAM && (s & 3) == 0) {                       // its chunk was copied one pair earlier
+                dma_landed();
+                __syncthreads();
+            }
             step(da, s, a_ptr(s, STREAM ? ((s >> 2) & 1) : (s >> 2)), std::false_type{});
         }
 
