@@ -174,7 +174,8 @@ class Attack(object):
             self._save_print(progress, rob_acc, l2, elapsed, end="\n")
         if was_training:
             self.model.train()
-        self._return_type = requested_type
+        # (attack.py:173-175 switches the return type to 'float' for the duration of save() and never switches it back: kept —
+        # tests/golden/attack_save.npz records the reference leaving 'float' behind after an 'int' save)
         if return_verbose:
             return rob_acc, l2, elapsed
 

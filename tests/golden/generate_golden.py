@@ -591,6 +591,32 @@ def gen_frontends_xcheck():
     np.savez_compressed(OUT / "frontends_xcheck.npz", **out)
 
 
+def gen_attack_save(ta, aa_utils):
+    """Attack.save (adversarial_attacks/torchattacks/attack.py:149-233) run by the REFERENCE: FGSM over a two-batch loader with
+    the surrogate detector, `save_pred=True`, once with return type 'float' and once 'int' — the saved (adversarials, labels,
+    predictions) tuples and the returned (robust accuracy, mean L2 of the not-right rows)."""
+    import tempfile
+    out = {}
+    model = surrogate(91)
+    out.update({f"model_{k}": npy(v) for k, v in model.state_dict().items()})
+    x01, _, _ = aa_utils.to_minmax(waveforms(4, T_SMALL, 92))
+    y = torch.tensor([0, 0, 0, 1])      # `pred` is max over the single logit's dim: always 0 (kept as the reference computes it)
+    out["x"], out["y"] = npy(x01), npy(y)
+    loader = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(x01, y), batch_size=2, shuffle=False)
+    for kind in ("float", "int"):
+        atk = ta.FGSM(model, eps=0.001)
+        atk.set_training_mode(model_training=True, batchnorm_training=False)
+        atk.set_return_type(kind)
+        with tempfile.TemporaryDirectory() as tmp:
+            path = Path(tmp) / "adv.pt"
+            rob_acc, l2, _ = atk.save(loader, save_path=str(path), verbose=False, return_verbose=True, save_pred=True)
+            adv, labels, preds = torch.load(path)
+        out[f"{kind}_adv"], out[f"{kind}_labels"], out[f"{kind}_preds"] = npy(adv), npy(labels), npy(preds)
+        out[f"{kind}_rob_acc"], out[f"{kind}_l2"] = np.float64(rob_acc), np.float64(l2)
+        out[f"{kind}_return_type_after"] = np.array(atk._return_type)    # the reference leaves 'float' behind (attack.py:175)
+    np.savez_compressed(OUT / "attack_save.npz", **out)
+
+
 def gen_frontends_batch_floor():
     """The one reading of torchaudio 0.10's LFCC that gen_frontends_xcheck cannot see: `amplitude_to_DB(top_db=80)` on
     the 3-D (B, n_filter, time) tensor LFCC hands it takes its floor from the maximum over the WHOLE BATCH
@@ -743,6 +769,7 @@ def main():
     gen_fab_projections()
     gen_fab_attack(ta, aa_utils)
     gen_trainer()
+    gen_attack_save(ta, aa_utils)
     gen_metrics()
     gen_model_bodies()
     gen_rawnet3_body()
@@ -756,5 +783,11 @@ def main():
 if __name__ == "__main__":
     if sys.argv[1:] == ["frontends_batch_floor"]:      # third-party code only: does not need the reference tree
         gen_frontends_batch_floor()
+    elif sys.argv[1:] == ["attack_save"]:              # one fixture, same set-up as main()
+        _import_reference()
+        torch.set_num_threads(1)
+        from adversarial_attacks import torchattacks as ta
+        from src.aa import utils as aa_utils
+        gen_attack_save(ta, aa_utils)
     else:
         main()
