@@ -151,7 +151,7 @@ def live_traffic(entry_point: str, B: int):
             for counter in ("FETCH_SIZE", "WRITE_SIZE"):
                 cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", f"{tmp}/{counter}", "--",
                        sys.executable, str(ROOT / "tools" / "traffic_probe.py"), "--entry", entry_point, "--batch", str(B)]
-                subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, timeout=300)
+                subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, timeout=150)
             paths = glob.glob(f"{tmp}/*/*/*counter_collection.csv") + glob.glob(f"{tmp}/*/*counter_collection.csv")
             row = hbm_traffic.reduce(paths, batch_override=B).get(entry_point)
     except (subprocess.TimeoutExpired, OSError, SystemExit, KeyError, ValueError) as exc:
