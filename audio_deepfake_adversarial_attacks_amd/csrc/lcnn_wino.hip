@@ -94,6 +94,7 @@ __device__ __forceinline__ float pool_select_fast(float a00, float b00, float a0
 // mode 0 (forward, max-feature-map pairs): output row (slice, j, m) = conv channel m * C + slice * 16 + j, g = weight.
 // mode 1 (input gradient): the convolution that maps d(conv out) (2C channels) to d(conv in) (Cin channels) has kernel
 //         g'[ci][co][a][b] = weight[co][ci][2 - a][2 - b]; output row (slice, j, m) = input channel slice*32 + m*16 + j.
+// mode 2: mode 1 with the reduction channels in the compact source's order (halves interleaved per k-step, see below).
 // U: [slice][chunk][xi][16 cin][16 j][2 m], zero where a row / channel does not exist.
 __global__ void wino_prepare_kernel(const float *__restrict__ weight, const float *__restrict__ kscale,
                                     float *__restrict__ U, int Cin, int Cout, int mode, int slices, int chunks) {
@@ -113,16 +114,20 @@ __global__ void wino_prepare_kernel(const float *__restrict__ weight, const floa
 #pragma unroll
             for (int b = 0; b < 3; ++b) g[a][b] = live ? weight[((int64_t)co * Cin + k) * 9 + a * 3 + b] : 0.0f;
     } else {
+        // mode 2 (the compact source of advstep_conv3x3_mfm_pool2_backward_f32): the reduction runs over the two halves of a
+        // max-feature-map channel in ADJACENT k-steps — k-step 2 j holds channels 4 j .. 4 j + 3 of the first half, k-step
+        // 2 j + 1 the same channels of the second half — so one load of the pooled gradients + selection bytes serves both
+        const int kk = mode == 2 ? ((k >> 2) & 1) * (Cout / 2) + (k >> 3) * 4 + (k & 3) : k;
         const int ci = slice * 32 + m * 16 + j;
         live = ci < Cin;
 #pragma unroll
         for (int a = 0; a < 3; ++a)
 #pragma unroll
-            for (int b = 0; b < 3; ++b) g[a][b] = live ? weight[((int64_t)k * Cin + ci) * 9 + (2 - a) * 3 + (2 - b)] : 0.0f;
-        // a per-channel factor on d(conv out) — the folded BatchNorm's invstd of max-feature-map channel k % C — is a
+            for (int b = 0; b < 3; ++b) g[a][b] = live ? weight[((int64_t)kk * Cin + ci) * 9 + (2 - a) * 3 + (2 - b)] : 0.0f;
+        // a per-channel factor on d(conv out) — the folded BatchNorm's invstd of max-feature-map channel kk % C — is a
         // factor on row k of the operand
         if (kscale) {
-            const float f = kscale[k % (Cout / 2)];
+            const float f = kscale[kk % (Cout / 2)];
 #pragma unroll
             for (int a = 0; a < 3; ++a)
 #pragma unroll
@@ -406,7 +411,7 @@ __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restri
 #pragma unroll
                 for (int p = 0; p < 4; ++p) load_row(dst, p, xr, pair_off[p], edge_off[p], soff);
             } else {
-                const int k0 = 4 * s, c0 = SRC == 1 && k0 >= Cs ? k0 - Cs : k0;      // wave-uniform: channel of lane group 0
+                const int k0 = 4 * s, c0 = k0;      // wave-uniform: channel of lane group 0 (SRC 1: `s` counts k-step PAIRS)
                 const uint32_t soff = (uint32_t)c0 * cplane;
                 const bool lane_ok = SRC == 1 || !GEN || k0 + g < ga.Kreal;        // padded reduction channels read 0
 #pragma unroll
@@ -434,7 +439,7 @@ __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restri
                     d[p][3] = ok_r[p] ? right : 0.0f;
                 }
             } else {
-                const uint32_t half_bit = SRC == 1 && 4 * s >= Cs ? 4u : 0u;         // wave-uniform
+                const uint32_t half_bit = SRC == 1 && (s & 1) ? 4u : 0u;              // wave-uniform: odd k-steps are the second half
 #pragma unroll
                 for (int p = 0; p < 4; ++p)
 #pragma unroll
@@ -502,6 +507,39 @@ __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restri
         auto a_ptr = [&](int s, int buf) { return u_s + buf * kChunkFloats + (((s & 3) * 4 + g) * 16 + nl) * 2; };
 
         Patch da, db;
+        if constexpr (SRC == 1) {
+            // Compact max-feature-map source (round 3): the two halves (c, c + C) of a pooled channel read the SAME pooled gradient
+            // and selection byte, so the reduction is ordered half 0 / half 1 of channels 4 j .. 4 j + 3 in k-steps 2 j / 2 j + 1
+            // (U prepared with mode 2) and ONE patch serves two k-steps: half the vector-memory loads of the k loop.  `da` is
+            // the pair in use, `db` the next pair, requested two k-steps before it is copied into `da` (18 moves per pair):
+            // these kernels' loads come from the Infinity Cache / HBM (62 MB of pooled gradients + bytes per layer) and the one
+            // k-step of distance they had did not cover them.  The loop body stays two k-steps long (a four-step body that
+            // alternates two buffers without the moves spills 39 registers: 281 -> 310 us).
+            load_patch(da, 0);
+            load_patch(db, 1);
+            if (STREAM) {
+                __syncthreads();            // previous iteration's readers are done with both buffers
+                copy_chunk(0, 0);
+                dma_landed();
+                __syncthreads();
+                copy_chunk(1, 1);           // chunks >= 2 always here
+            }
+            step(da, 0, a_ptr(0, 0), std::true_type{});
+            step(da, 1, a_ptr(1, 0), std::false_type{});
+#pragma unroll 1
+            for (int s = 2; s < steps; s += 2) {
+                da = db;
+                if (s + 2 < steps) load_patch(db, (s + 2) >> 1);
+                if (STREAM && (s & 3) == 0) {
+                    dma_landed();
+                    __syncthreads();        // chunk s/4 is complete in its buffer; chunk s/4 - 1 is free
+                    if (s / 4 + 1 < chunks) copy_chunk(s / 4 + 1, (s / 4 + 1) & 1);
+                }
+                const int buf = STREAM ? ((s >> 2) & 1) : (s >> 2);
+                step(da, s, a_ptr(s, buf), std::false_type{});
+                step(da, s + 1, a_ptr(s + 1, buf), std::false_type{});
+            }
+        } else {
         if (STREAM) {
             __syncthreads();            // previous iteration's readers are done with both buffers
             copy_chunk(0, 0);
@@ -537,6 +575,7 @@ __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restri
             }
             step(da, s, a_ptr(s, STREAM ? ((s >> 2) & 1) : (s >> 2)), std::false_type{});
         }
+        }   // SRC != 1
 
         // epilogue: Y = A^T M A per (channel, tile)
         const int Ho = H >> 1, Wo = W >> 1;
@@ -754,7 +793,7 @@ int advstep_conv3x3_supported(int64_t Cin, int64_t Cout) {
 }
 
 size_t advstep_conv3x3_prepared_floats(int64_t Cin, int64_t Cout, int mode) {
-    if (!advstep_conv3x3_supported(Cin, Cout) || (mode != 0 && mode != 1)) return 0;
+    if (!advstep_conv3x3_supported(Cin, Cout) || mode < 0 || mode > 2) return 0;
     const int64_t K = mode == 0 ? Cin : Cout;
     const int64_t slices = mode == 0 ? ceil_div(Cout / 2, 16) : ceil_div(Cin, 32);
     return (size_t)(slices * (K / kChunkCin) * kChunkFloats);
@@ -762,8 +801,8 @@ size_t advstep_conv3x3_prepared_floats(int64_t Cin, int64_t Cout, int mode) {
 
 int advstep_conv3x3_prepare_f32(const float *weight, const float *gscale, float *U, int64_t Cin, int64_t Cout, int mode,
                                 advstep_stream_t stream) {
-    WINO_REQUIRE(weight && U && advstep_conv3x3_supported(Cin, Cout) && (mode == 0 || mode == 1));
-    WINO_REQUIRE(gscale == nullptr || mode == 1);
+    WINO_REQUIRE(weight && U && advstep_conv3x3_supported(Cin, Cout) && mode >= 0 && mode <= 2);
+    WINO_REQUIRE(gscale == nullptr || mode != 0);
     const int K = (int)(mode == 0 ? Cin : Cout);
     const int slices = (int)(mode == 0 ? ceil_div(Cout / 2, 16) : ceil_div(Cin, 32));
     const int total = slices * 32 * K;

@@ -346,7 +346,7 @@ def conv3x3_mfm_pool2(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torc
     """MaxPool2d(2, 2)(MFM(conv2d(x, weight, bias, padding=1))) [then eval BatchNorm], Winograd on the matrix cores."""
     weight = weight if weight.is_contiguous() else weight.contiguous()
     return _Conv3x3MfmPool2.apply(x.contiguous(), weight, bias, bn, _prepared_weights(weight, 0),
-                                  _prepared_weights(weight, 1, None if bn is None else bn[1]))
+                                  _prepared_weights(weight, 2, None if bn is None else bn[1]))
 
 
 

@@ -99,7 +99,9 @@ int advstep_conv1x1_mfm_backward_f32(const float *gy, const void *sel, const flo
  *   mode 0: forward operand, from weight (2C, Cin, 3, 3);
  *   mode 1: operand of the input-gradient convolution (rotated, transposed kernel), from the same weight tensor;
  *           gscale (C = Cout / 2 floats, or NULL) multiplies the rows of conv channels c and c + C: the invstd of the
- *           eval-mode BatchNorm folded behind the block, so the backward kernel needs no separate scaling pass.
+ *           eval-mode BatchNorm folded behind the block, so the backward kernel needs no separate scaling pass;
+ *   mode 2: mode 1 with the reduction channels in the order advstep_conv3x3_mfm_pool2_backward_f32 walks its compact source
+ *           (the two halves of a max-feature-map channel in adjacent k-steps: one load of the pooled gradient serves both).
  * advstep_conv3x3_prepared_floats() floats are written.  Cin % 16 == 0, Cin >= 32, (2C) % 32 == 0 (LCNN: 32/48/64 ->
  * 96/128/64); every tensor of a call must be smaller than 2 GiB (the caller splits the batch otherwise). */
 int advstep_conv3x3_supported(int64_t Cin, int64_t Cout);
@@ -130,7 +132,7 @@ int advstep_conv3x3_backward_data_f32(const float *gout, const float *U, float *
 
 /* Input gradient of the WHOLE block from its compact state: gy (N, C, H/2, W/2) and the forward's selection bytes.  The
  * (N, 2C, H, W) gradient of the conv output — gy routed to the winning position of the winning half, zero elsewhere —
- * is expanded on the fly inside the kernel's operand load and never written.  U: mode 1 (with the BatchNorm scale). */
+ * is expanded on the fly inside the kernel's operand load and never written.  U: mode 2 (with the BatchNorm scale). */
 int advstep_conv3x3_mfm_pool2_backward_f32(const float *gy, const uint8_t *idx, const float *U, float *gx, int64_t N,
                                            int64_t Cin, int64_t C, int64_t H, int64_t W, advstep_stream_t stream);
 

@@ -94,6 +94,8 @@ def main():
         u1 = torch.empty(lib.advstep_conv3x3_prepared_floats(cin, 2 * c, 1), device=dev)
         lib.advstep_conv3x3_prepare_f32(ww.data_ptr(), None, u0.data_ptr(), cin, 2 * c, 0, st)
         lib.advstep_conv3x3_prepare_f32(ww.data_ptr(), invstd.data_ptr(), u1.data_ptr(), cin, 2 * c, 1, st)
+        u2 = torch.empty(lib.advstep_conv3x3_prepared_floats(cin, 2 * c, 2), device=dev)       # the compact source's channel order
+        lib.advstep_conv3x3_prepare_f32(ww.data_ptr(), invstd.data_ptr(), u2.data_ptr(), cin, 2 * c, 2, st)
         gout = torch.randn(B, 2 * c, h, wd, device=dev)
         gxx = torch.empty_like(xx)
         fl = 2.0 * B * h * wd * cin * 2 * c * 9
@@ -103,7 +105,7 @@ def main():
         timeit(f"conv3x3_backward_data     {name} ({2 * c}->{cin}, {h}x{wd})", lambda: lib.advstep_conv3x3_backward_data_f32(
             gout.data_ptr(), u1.data_ptr(), gxx.data_ptr(), B, cin, 2 * c, h, wd, st), flops=fl)
         timeit(f"conv3x3_mfm_pool2_backward {name} ({2 * c}->{cin}, {h}x{wd})", lambda: lib.advstep_conv3x3_mfm_pool2_backward_f32(
-            yy.data_ptr(), ii.data_ptr(), u1.data_ptr(), gxx.data_ptr(), B, cin, c, h, wd, st), flops=fl)
+            yy.data_ptr(), ii.data_ptr(), u2.data_ptr(), gxx.data_ptr(), B, cin, c, h, wd, st), flops=fl)
 
     # ---- MFM + pool after the 3x3 convolutions
     for name, c, h, wd in (("L6 ", 48, 202, 40), ("L13", 64, 101, 20), ("L25", 32, 50, 10)):
