@@ -97,7 +97,7 @@ __global__ __launch_bounds__(4 * H) void lstm_backward_kernel(const float *__res
                                                               const float *__restrict__ w_hh,
                                                               const float *__restrict__ gates,
                                                               const float *__restrict__ cell, float *__restrict__ dgx,
-                                                              int T, int B, int D) {
+                                                              int T, int B, int D, int64_t dout_t_stride) {
     __shared__ __attribute__((aligned(16))) float dg_s[4 * H];
     __shared__ float part[4 * H];
     const int b = blockIdx.x, d = blockIdx.y, tid = threadIdx.x;
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(4 * H) void lstm_backward_kernel(const float *__res
                 const int tp = d == 0 ? step - 1 : T - step;
                 v.c_prev = cell[(((int64_t)tp * B + b) * D + d) * H + j];
             }
-            v.dout = dout[((int64_t)t * B + b) * D * H + d * H + j];
+            v.dout = dout[(int64_t)t * dout_t_stride + (int64_t)b * D * H + d * H + j];   // stride 0: the same (B, D H) for every t
         }
         return v;
     };
@@ -191,6 +191,58 @@ __global__ __launch_bounds__(4 * H) void lstm_backward_kernel(const float *__res
     }
 }
 
+
+// ---- what surrounds the two BLSTM layers in LCNN (src/models/lcnn.py:196-205), as three passes instead of ~15 ATen launches -------
+//   hidden = conv_out.permute(0, 2, 1, 3).contiguous().view(B, T, C W);  lstm = blstm2(blstm1(hidden));
+//   z = Linear((lstm + hidden).mean(1))
+// The recurrent kernels work sequence-first, so `hidden` is packed straight into (T, B, C W); the skip connection, the mean over
+// frames and the one-row Linear are one pass over the two (T, B, F) tensors; on the way back the mean's gradient is the same
+// (B, F) row for every frame (lstm_backward_kernel reads it with a zero frame stride) and the two gradients of `hidden` are
+// summed while they are put back into the convolution's (B, C, T, W) layout.
+
+// x4 (B, C, T, W) -> xt (T, B, C W)
+__global__ __launch_bounds__(256) void lcnn_tail_pack_kernel(const float *__restrict__ x4, float *__restrict__ xt, int B, int C,
+                                                             int T, int W) {
+    const int64_t total = (int64_t)T * B * C * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int w = (int)(i % W), c = (int)((i / W) % C), b = (int)((i / ((int64_t)W * C)) % B), t = (int)(i / ((int64_t)W * C * B));
+        xt[i] = x4[(((int64_t)b * C + c) * T + t) * W + w];
+    }
+}
+
+// z[b] = bias + sum_k w[k] * (1 / T) sum_t (a[t][b][k] + xt[t][b][k]);  one workgroup per utterance, F <= 256
+__global__ __launch_bounds__(256) void lcnn_tail_forward_kernel(const float *__restrict__ a, const float *__restrict__ xt,
+                                                                const float *__restrict__ w, const float *__restrict__ bias,
+                                                                float *__restrict__ z, int T, int B, int F) {
+    __shared__ float red[4];
+    const int b = blockIdx.x, k = threadIdx.x;
+    float acc = 0.0f;
+    if (k < F) {
+        float s = 0.0f;
+        for (int t = 0; t < T; ++t) {
+            const int64_t i = ((int64_t)t * B + b) * F + k;
+            s += a[i] + xt[i];
+        }
+        acc = (s / (float)T) * w[k];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) z[b] = ((red[0] + red[1]) + (red[2] + red[3])) + (bias ? bias[0] : 0.0f);
+}
+
+// dx4 (B, C, T, W) = dxt (T, B, C W) + g0 (B, C W)
+__global__ __launch_bounds__(256) void lcnn_tail_unpack_add_kernel(const float *__restrict__ dxt, const float *__restrict__ g0,
+                                                                   float *__restrict__ dx4, int B, int C, int T, int W) {
+    const int64_t total = (int64_t)B * C * T * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int w = (int)(i % W), t = (int)((i / W) % T), c = (int)((i / ((int64_t)W * T)) % C), b = (int)(i / ((int64_t)W * T * C));
+        const int k = c * W + w;
+        dx4[i] = dxt[((int64_t)t * B + b) * C * W + k] + g0[(int64_t)b * C * W + k];
+    }
+}
+
 }  // namespace
 
 #define LSTM_REQUIRE(cond) \
@@ -218,7 +270,50 @@ int advstep_lstm_backward_f32(const float *dout, const float *w_hh, const float 
     if (T == 0 || B == 0) return ADVSTEP_OK;
     LSTM_REQUIRE(dout && w_hh && gates && cell && dgx && T <= INT32_MAX && B <= INT32_MAX);
     hipLaunchKernelGGL(lstm_backward_kernel<80>, dim3((unsigned)B, (unsigned)D), dim3(320), 0, as_stream(stream), dout,
-                       w_hh, gates, cell, dgx, (int)T, (int)B, (int)D);
+                       w_hh, gates, cell, dgx, (int)T, (int)B, (int)D, (int64_t)B * D * H);
+    return status_after_launch();
+}
+
+int advstep_lstm_backward_bcast_f32(const float *dout_row, const float *w_hh, const float *gates, const float *cell,
+                                    float *dgx, int64_t T, int64_t B, int64_t D, int64_t H, advstep_stream_t stream) {
+    LSTM_REQUIRE(T >= 0 && B >= 0 && (D == 1 || D == 2) && advstep_lstm_supported(H));
+    if (T == 0 || B == 0) return ADVSTEP_OK;
+    LSTM_REQUIRE(dout_row && w_hh && gates && cell && dgx && T <= INT32_MAX && B <= INT32_MAX);
+    hipLaunchKernelGGL(lstm_backward_kernel<80>, dim3((unsigned)B, (unsigned)D), dim3(320), 0, as_stream(stream), dout_row,
+                       w_hh, gates, cell, dgx, (int)T, (int)B, (int)D, (int64_t)0);
+    return status_after_launch();
+}
+
+int advstep_lcnn_tail_pack_f32(const float *x4, float *xt, int64_t B, int64_t C, int64_t T, int64_t W, advstep_stream_t stream) {
+    LSTM_REQUIRE(B >= 0 && C >= 0 && T >= 0 && W >= 0);
+    const int64_t total = B * C * T * W;
+    if (total == 0) return ADVSTEP_OK;
+    LSTM_REQUIRE(x4 && xt && B <= INT32_MAX && C <= INT32_MAX && T <= INT32_MAX && W <= INT32_MAX);
+    const int64_t blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(lcnn_tail_pack_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, as_stream(stream), x4,
+                       xt, (int)B, (int)C, (int)T, (int)W);
+    return status_after_launch();
+}
+
+int advstep_lcnn_tail_forward_f32(const float *a, const float *xt, const float *w, const float *bias, float *z, int64_t T,
+                                  int64_t B, int64_t F, advstep_stream_t stream) {
+    LSTM_REQUIRE(T >= 1 && B >= 0 && F >= 1 && F <= 256);
+    if (B == 0) return ADVSTEP_OK;
+    LSTM_REQUIRE(a && xt && w && z && T <= INT32_MAX && B <= INT32_MAX);
+    hipLaunchKernelGGL(lcnn_tail_forward_kernel, dim3((unsigned)B), dim3(256), 0, as_stream(stream), a, xt, w, bias, z, (int)T,
+                       (int)B, (int)F);
+    return status_after_launch();
+}
+
+int advstep_lcnn_tail_unpack_add_f32(const float *dxt, const float *g0, float *dx4, int64_t B, int64_t C, int64_t T, int64_t W,
+                                     advstep_stream_t stream) {
+    LSTM_REQUIRE(B >= 0 && C >= 0 && T >= 0 && W >= 0);
+    const int64_t total = B * C * T * W;
+    if (total == 0) return ADVSTEP_OK;
+    LSTM_REQUIRE(dxt && g0 && dx4 && B <= INT32_MAX && C <= INT32_MAX && T <= INT32_MAX && W <= INT32_MAX);
+    const int64_t blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(lcnn_tail_unpack_add_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0,
+                       as_stream(stream), dxt, g0, dx4, (int)B, (int)C, (int)T, (int)W);
     return status_after_launch();
 }
 

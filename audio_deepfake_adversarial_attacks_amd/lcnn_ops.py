@@ -398,6 +398,86 @@ def lstm_layer(x: torch.Tensor, w_ih: torch.Tensor, w_hh: torch.Tensor, bias: to
     """x (T, B, I) -> (T, B, D*H) for one LSTM layer with D directions (parameters packed per direction)."""
     return _LstmLayer.apply(x.contiguous(), w_ih, w_hh, bias)
 
+class _LcnnTail(torch.autograd.Function):
+    """Everything between LCNN's convolution trunk and its logit (src/models/lcnn.py:196-205) as one autograd node:
+    pack -> [projection GEMM, recurrent kernel] x 2 -> skip + mean + Linear;  input gradient only.  12 launches forward +
+    backward instead of ~20 (the permute copies, the skip add, the mean, the expanded mean gradient, the gradient sum)."""
+
+    @staticmethod
+    def forward(ctx, x4, w_ih1, w_hh1, b1, w_ih2, w_hh2, b2, w_out, b_out):
+        _require(x4, "x4")
+        B, C, T, W = x4.shape
+        F = C * W
+        D, H4, H = w_hh1.shape
+        lib, dev = _lib.load(), x4.device
+        st = _stream(dev)
+
+        def layer(xin, w_ih, w_hh, bias):
+            gx = torch.addmm(bias, xin.view(T * B, -1), w_ih.t())
+            out = torch.empty((T, B, D * H), dtype=x4.dtype, device=dev)
+            gates = torch.empty((T, B, D, H4), dtype=x4.dtype, device=dev)
+            cell = torch.empty((T, B, D, H), dtype=x4.dtype, device=dev)
+            with _Launch("lstm_forward", dev):
+                s_ = lib.advstep_lstm_forward_f32(gx.data_ptr(), w_hh.data_ptr(), out.data_ptr(), gates.data_ptr(), cell.data_ptr(),
+                                                  T, B, D, H, st)
+            _lib.check(s_, "advstep_lstm_forward_f32")
+            return out, gates, cell
+
+        xt = torch.empty((T, B, F), dtype=x4.dtype, device=dev)
+        with _Launch("lcnn_tail_pack", dev):
+            s_ = lib.advstep_lcnn_tail_pack_f32(x4.data_ptr(), xt.data_ptr(), B, C, T, W, st)
+        _lib.check(s_, "advstep_lcnn_tail_pack_f32")
+        out1, gates1, cell1 = layer(xt, w_ih1, w_hh1, b1)
+        out2, gates2, cell2 = layer(out1, w_ih2, w_hh2, b2)
+        z = torch.empty((B, 1), dtype=x4.dtype, device=dev)
+        with _Launch("lcnn_tail_forward", dev):
+            s_ = lib.advstep_lcnn_tail_forward_f32(out2.data_ptr(), xt.data_ptr(), w_out.data_ptr(),
+                                                   b_out.data_ptr() if b_out is not None else None, z.data_ptr(), T, B, F, st)
+        _lib.check(s_, "advstep_lcnn_tail_forward_f32")
+        ctx.save_for_backward(gates1, cell1, gates2, cell2, w_ih1, w_hh1, w_ih2, w_hh2, w_out)
+        ctx.dims = (B, C, T, W, D, H)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        if any(ctx.needs_input_grad[1:]):
+            raise RuntimeError("lcnn_tail provides the input gradient only; call it with frozen parameters")
+        gates1, cell1, gates2, cell2, w_ih1, w_hh1, w_ih2, w_hh2, w_out = ctx.saved_tensors
+        B, C, T, W, D, H = ctx.dims
+        F = C * W
+        lib, dev = _lib.load(), dz.device
+        st = _stream(dev)
+        # the mean's gradient: the same row for every frame — of the second layer's output and of the skip connection
+        g0 = (dz.reshape(B, 1) * (w_out.reshape(1, F) / T)).contiguous()
+        dgx2 = torch.empty((T, B, D, 4 * H), dtype=dz.dtype, device=dev)
+        with _Launch("lstm_backward", dev):
+            s_ = lib.advstep_lstm_backward_bcast_f32(g0.data_ptr(), w_hh2.data_ptr(), gates2.data_ptr(), cell2.data_ptr(),
+                                                     dgx2.data_ptr(), T, B, D, H, st)
+        _lib.check(s_, "advstep_lstm_backward_bcast_f32")
+        dout1 = torch.mm(dgx2.view(T * B, D * 4 * H), w_ih2)                     # (T B, F) = d(first layer's output)
+        dgx1 = torch.empty((T, B, D, 4 * H), dtype=dz.dtype, device=dev)
+        with _Launch("lstm_backward", dev):
+            s_ = lib.advstep_lstm_backward_f32(dout1.data_ptr(), w_hh1.data_ptr(), gates1.data_ptr(), cell1.data_ptr(),
+                                               dgx1.data_ptr(), T, B, D, H, st)
+        _lib.check(s_, "advstep_lstm_backward_f32")
+        dxt = torch.mm(dgx1.view(T * B, D * 4 * H), w_ih1)
+        dx4 = torch.empty((B, C, T, W), dtype=dz.dtype, device=dev)
+        with _Launch("lcnn_tail_unpack_add", dev):
+            s_ = lib.advstep_lcnn_tail_unpack_add_f32(dxt.data_ptr(), g0.data_ptr(), dx4.data_ptr(), B, C, T, W, st)
+        _lib.check(s_, "advstep_lcnn_tail_unpack_add_f32")
+        return (dx4,) + (None,) * 8
+
+
+def lcnn_tail_supported(features: int, hidden_size: int, out_features: int) -> bool:
+    return lstm_supported(hidden_size) and 2 * hidden_size == features and features <= 256 and out_features == 1
+
+
+def lcnn_tail(x4: torch.Tensor, packed1, packed2, w_out: torch.Tensor, b_out: Optional[torch.Tensor]) -> torch.Tensor:
+    """x4 (B, C, T, W) conv-trunk output -> logits (B, 1): two BLSTM layers with the skip connection, mean over frames, Linear.
+    packed1 / packed2 = (w_ih (D*4H, F), w_hh (D, 4H, H), bias (D*4H)) of the two layers (models/lcnn.py:BLSTMLayer._packed)."""
+    return _LcnnTail.apply(x4.contiguous(), *packed1, *packed2, w_out.contiguous(), b_out)
+
+
 
 class _GruLayer(torch.autograd.Function):
     """One (bi)directional GRU layer, sequence-first, zero initial state; input gradient only (csrc/specrnet_gru.hip)."""

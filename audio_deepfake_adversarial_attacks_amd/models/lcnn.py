@@ -20,6 +20,10 @@ def _fused_mfm_enabled() -> bool:
     return os.environ.get("ADVSTEP_LCNN_FUSED", "1") != "0"
 
 
+def _fused_tail_enabled() -> bool:
+    return os.environ.get("ADVSTEP_LCNN_TAIL", "1") != "0"
+
+
 class BLSTMLayer(nn.Module):
     """Bidirectional LSTM that keeps (batch, length, dim) on both sides (lcnn.py:24-46)."""
 
@@ -234,10 +238,35 @@ class BaseLCNN(nn.Module):
                 i += 1
         return x
 
+    def _fused_tail(self, hidden4):
+        """The two BLSTM layers, the skip connection, the mean over frames and the read-out as ONE autograd node
+        (lcnn_ops.lcnn_tail): HIP tensor, frozen parameters (an attack or a scoring pass), the reference's layer shapes."""
+        if not (hidden4.is_cuda and hidden4.dtype == torch.float32 and _fused_tail_enabled() and _fused_lstm_enabled()):
+            return None
+        layers = list(self.m_before_pooling)
+        if len(layers) != 2 or not all(isinstance(m, BLSTMLayer) for m in layers) or not isinstance(self.m_output_act, nn.Linear):
+            return None
+        params = [p for m in layers for p in m.parameters()] + list(self.m_output_act.parameters())
+        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            return None
+        from .. import lcnn_ops
+        feats = hidden4.shape[1] * hidden4.shape[3]
+        lstms = [m.l_blstm for m in layers]
+        if not all(l.num_layers == 1 and l.bidirectional and l.bias and l.proj_size == 0 and l.input_size == feats
+                   and 2 * l.hidden_size == feats for l in lstms):
+            return None
+        if not lcnn_ops.lcnn_tail_supported(feats, lstms[0].hidden_size, self.m_output_act.out_features):
+            return None
+        return lcnn_ops.lcnn_tail(hidden4, layers[0]._packed(), layers[1]._packed(), self.m_output_act.weight.detach(),
+                                  None if self.m_output_act.bias is None else self.m_output_act.bias.detach())
+
     def _compute_embedding(self, x):
         batch_size = x.shape[0]
         # (B, C, coeff, frames) -> (B, C, frames, coeff) -> conv trunk -> (B, frames', C' * coeff')   (:190-199)
         hidden = self._transform(x.permute(0, 1, 3, 2))
+        fused = self._fused_tail(hidden) if hidden.dim() == 4 else None
+        if fused is not None:
+            return fused
         hidden = hidden.permute(0, 2, 1, 3).contiguous()
         hidden = hidden.view(batch_size, hidden.shape[1], -1)
         # two BLSTMs with a skip connection, mean over frames, linear read-out   (:202-205)

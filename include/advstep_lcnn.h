@@ -151,6 +151,24 @@ int advstep_lstm_forward_f32(const float *gx, const float *w_hh, float *out, flo
  * the layer input with one GEMM (dgx . W_ih). */
 int advstep_lstm_backward_f32(const float *dout, const float *w_hh, const float *gates, const float *cell, float *dgx,
                               int64_t T, int64_t B, int64_t D, int64_t H, advstep_stream_t stream);
+/* The same with ONE gradient row per (utterance, direction, unit) for every frame: dout_row (B, D*H) — what the mean over
+ * frames hands back (src/models/lcnn.py:205) — read with a zero frame stride, so the (T, B, D*H) expansion never exists. */
+int advstep_lstm_backward_bcast_f32(const float *dout_row, const float *w_hh, const float *gates, const float *cell,
+                                    float *dgx, int64_t T, int64_t B, int64_t D, int64_t H, advstep_stream_t stream);
+
+/* ---- around the two BLSTM layers  (src/models/lcnn.py:196-205) ---------------------------------------------------------------
+ *   hidden = conv_out.permute(0, 2, 1, 3).contiguous().view(B, T, C*W);  lstm = blstm2(blstm1(hidden));
+ *   z = Linear(C*W, 1)((lstm + hidden).mean(1))
+ * pack:        x4 (B, C, T, W) -> xt (T, B, C*W), the sequence-first layout the recurrent kernels read (one copy, not two);
+ * forward:     z (B) = bias + sum_k w[k] * mean_t(a[t][b][k] + xt[t][b][k]),  a = the second layer's output (T, B, F), F <= 256:
+ *              skip connection + mean over frames + one-row Linear in one pass;
+ * unpack_add:  dx4 (B, C, T, W) = dxt (T, B, C*W) + g0 (B, C*W): the two gradients of `hidden` (through the recurrent layers, and
+ *              the mean's row) summed while they go back to the convolution's layout. */
+int advstep_lcnn_tail_pack_f32(const float *x4, float *xt, int64_t B, int64_t C, int64_t T, int64_t W, advstep_stream_t stream);
+int advstep_lcnn_tail_forward_f32(const float *a, const float *xt, const float *w, const float *bias, float *z, int64_t T,
+                                  int64_t B, int64_t F, advstep_stream_t stream);
+int advstep_lcnn_tail_unpack_add_f32(const float *dxt, const float *g0, float *dx4, int64_t B, int64_t C, int64_t T, int64_t W,
+                                     advstep_stream_t stream);
 
 /* ---- recurrent part of a (bi)directional GRU layer  (src/models/specrnet.py:121-127,176-177: nn.GRU(64, 64, 2 layers,
  * bidirectional); MIOpen runs it as ~400 kernels of ~4 us per forward + backward) --------------------------------------

@@ -606,3 +606,38 @@ def test_specrnet_uses_gru_kernel_when_frozen_and_matches_miopen(cuda, monkeypat
     assert (g1 - g0).abs().max().item() <= 1e-4 * max(g0.abs().max().item(), 1e-6)
     for p in model.parameters():
         p.requires_grad_(True)
+
+
+def test_lcnn_tail_as_one_node_matches_the_separate_ops(cuda, monkeypatch, parity_record):
+    """lcnn_ops.lcnn_tail (pack -> two recurrent layers -> skip + mean + Linear as ONE autograd node, the mean's gradient read
+    with a zero frame stride, the two gradients of `hidden` summed while they return to the convolution's layout) against the
+    same fused LSTM kernels driven by the separate torch ops (src/models/lcnn.py:196-205): logits and the gradient w.r.t. the
+    convolution trunk's output.  Same kernels for the recurrences; only the summation order of the mean / Linear differs."""
+    from audio_deepfake_adversarial_attacks_amd.models import lcnn
+    torch.manual_seed(7)
+    body = lcnn.BaseLCNN(input_channels=1, num_coefficients=80).to(cuda)
+    body.train()
+    for m in body.modules():
+        if "BatchNorm" in m.__class__.__name__ or "Dropout" in m.__class__.__name__:
+            m.eval()
+    for p in body.parameters():
+        p.requires_grad_(False)
+    spec = torch.randn(6, 1, 80, 404, generator=torch.Generator().manual_seed(8)).to(cuda)
+
+    def run(tail):
+        monkeypatch.setenv("ADVSTEP_LCNN_TAIL", "1" if tail else "0")
+        a = spec.clone().requires_grad_(True)
+        z = body(a)
+        (g,) = torch.autograd.grad((z * torch.arange(1, 7, device=cuda).view(6, 1)).sum(), a)
+        return z.detach(), g
+
+    z0, g0 = run(False)
+    z1, g1 = run(True)
+    fig = {"logit_max_abs": (z0 - z1).abs().max().item(), "grad_rel_l2": ((g0 - g1).norm() / g0.norm()).item(),
+           "grad_max_abs_over_max": ((g0 - g1).abs().max() / g0.abs().max()).item()}
+    parity_record["lcnn_tail_one_node_vs_separate_ops"] = fig
+    assert z1.shape == (6, 1) and fig["logit_max_abs"] <= 3e-7, fig
+    assert fig["grad_rel_l2"] <= 5e-6 and fig["grad_max_abs_over_max"] <= 5e-6, fig
+    with torch.no_grad():                                  # the scoring pass (no autograd) takes the same node
+        monkeypatch.setenv("ADVSTEP_LCNN_TAIL", "1")
+        assert (body.eval()(spec) - body(spec)).abs().max().item() == 0.0
