@@ -579,6 +579,39 @@ __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restri
 
         // epilogue: Y = A^T M A per (channel, tile)
         const int Ho = H >> 1, Wo = W >> 1;
+        // EPI 5 reads the activation's output h at the tile's 2x2 positions of every row it stores — a 331 MB tensor at SpecRNet's
+        // first block, i.e. HBM latency.  All of a lane's reads (4 rows x NT tiles x 2 tile rows) are requested HERE, before the
+        // output transform's ~200 adds, instead of one row at a time right where they are used (round 3).
+        float hv5[EPI == 5 ? 4 : 1][EPI == 5 ? NT : 1][2][2];
+        if constexpr (EPI == 5) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int m = 0; m < NT; ++m) {
+                    const int ch = slice * 32 + m * 16 + 4 * g + r;
+                    const bool live = valid && ch < Cout;
+                    const float *hp = bn_mean + (((size_t)n * Cout + (live ? ch : 0)) * H + 2 * th) * W + 2 * tw;
+                    const bool h1 = 2 * th + 1 < H, w1 = 2 * tw + 1 < W;
+                    hv5[r][m][0][0] = hv5[r][m][0][1] = hv5[r][m][1][0] = hv5[r][m][1][1] = 1.0f;
+                    if (live) {
+                        if ((W & 1) == 0) {
+                            const f32x2 a = *reinterpret_cast<const f32x2 *>(hp);
+                            hv5[r][m][0][0] = a.x, hv5[r][m][0][1] = a.y;
+                            if (h1) {
+                                const f32x2 b = *reinterpret_cast<const f32x2 *>(hp + W);
+                                hv5[r][m][1][0] = b.x, hv5[r][m][1][1] = b.y;
+                            }
+                        } else {
+                            hv5[r][m][0][0] = hp[0];
+                            if (w1) hv5[r][m][0][1] = hp[1];
+                            if (h1) {
+                                hv5[r][m][1][0] = hp[W];
+                                if (w1) hv5[r][m][1][1] = hp[W + 1];
+                            }
+                        }
+                    }
+                }
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float yy[2][2][2];
@@ -668,26 +701,8 @@ __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restri
                     float *o = y + (((size_t)n * Cout + ch) * H + 2 * th) * W + 2 * tw;
                     const bool h1 = 2 * th + 1 < H;
                     if (EPI == 5) {
-                        const float *hp = bn_mean + (((size_t)n * Cout + ch) * H + 2 * th) * W + 2 * tw;
-                        const bool w1 = 2 * tw + 1 < W;
-                        float hv[2][2] = {{1.0f, 1.0f}, {1.0f, 1.0f}};
-                        if ((W & 1) == 0) {
-                            const f32x2 a = *reinterpret_cast<const f32x2 *>(hp);
-                            hv[0][0] = a.x, hv[0][1] = a.y;
-                            if (h1) {
-                                const f32x2 b = *reinterpret_cast<const f32x2 *>(hp + W);
-                                hv[1][0] = b.x, hv[1][1] = b.y;
-                            }
-                        } else {
-                            hv[0][0] = hp[0];
-                            if (w1) hv[0][1] = hp[1];
-                            if (h1) {
-                                hv[1][0] = hp[W];
-                                if (w1) hv[1][1] = hp[W + 1];
-                            }
-                        }
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) yy[m][e >> 1][e & 1] *= hv[e >> 1][e & 1] > 0.0f ? 1.0f : ga.slope;
+                        for (int e = 0; e < 4; ++e) yy[m][e >> 1][e & 1] *= hv5[r][m][e >> 1][e & 1] > 0.0f ? 1.0f : ga.slope;
                     }
                     if ((W & 1) == 0) {   // rows are 8-byte aligned: one 64-bit store per tile row
                         *reinterpret_cast<f32x2 *>(o) = (f32x2){yy[m][0][0], yy[m][0][1]};
