@@ -434,7 +434,16 @@ class _LcnnTail(torch.autograd.Function):
             s_ = lib.advstep_lcnn_tail_forward_f32(out2.data_ptr(), xt.data_ptr(), w_out.data_ptr(),
                                                    b_out.data_ptr() if b_out is not None else None, z.data_ptr(), T, B, F, st)
         _lib.check(s_, "advstep_lcnn_tail_forward_f32")
-        ctx.save_for_backward(gates1, cell1, gates2, cell2, w_ih1, w_hh1, w_ih2, w_hh2, w_out)
+        # w / T for the mean's gradient row: cached on the weight tensor (one launch per weight version, not per call)
+        cache = getattr(w_out, "_advstep_over_t", None)
+        key = (w_out._version, w_out.data_ptr(), T)
+        if cache is None or cache[0] != key:
+            cache = (key, (w_out.reshape(1, F) / T).contiguous())
+            try:
+                w_out._advstep_over_t = cache
+            except AttributeError:
+                pass
+        ctx.save_for_backward(gates1, cell1, gates2, cell2, w_ih1, w_hh1, w_ih2, w_hh2, cache[1])
         ctx.dims = (B, C, T, W, D, H)
         return z
 
@@ -442,13 +451,13 @@ class _LcnnTail(torch.autograd.Function):
     def backward(ctx, dz):
         if any(ctx.needs_input_grad[1:]):
             raise RuntimeError("lcnn_tail provides the input gradient only; call it with frozen parameters")
-        gates1, cell1, gates2, cell2, w_ih1, w_hh1, w_ih2, w_hh2, w_out = ctx.saved_tensors
+        gates1, cell1, gates2, cell2, w_ih1, w_hh1, w_ih2, w_hh2, w_over_t = ctx.saved_tensors
         B, C, T, W, D, H = ctx.dims
         F = C * W
         lib, dev = _lib.load(), dz.device
         st = _stream(dev)
         # the mean's gradient: the same row for every frame — of the second layer's output and of the skip connection
-        g0 = (dz.reshape(B, 1) * (w_out.reshape(1, F) / T)).contiguous()
+        g0 = dz.reshape(B, 1) * w_over_t
         dgx2 = torch.empty((T, B, D, 4 * H), dtype=dz.dtype, device=dev)
         with _Launch("lstm_backward", dev):
             s_ = lib.advstep_lstm_backward_bcast_f32(g0.data_ptr(), w_hh2.data_ptr(), gates2.data_ptr(), cell2.data_ptr(),

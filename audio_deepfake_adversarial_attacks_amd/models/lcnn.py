@@ -257,8 +257,9 @@ class BaseLCNN(nn.Module):
             return None
         if not lcnn_ops.lcnn_tail_supported(feats, lstms[0].hidden_size, self.m_output_act.out_features):
             return None
-        return lcnn_ops.lcnn_tail(hidden4, layers[0]._packed(), layers[1]._packed(), self.m_output_act.weight.detach(),
-                                  None if self.m_output_act.bias is None else self.m_output_act.bias.detach())
+        # (the Parameter itself, not a detached alias: lcnn_tail caches w / T on the tensor object it is handed)
+        return lcnn_ops.lcnn_tail(hidden4, layers[0]._packed(), layers[1]._packed(), self.m_output_act.weight,
+                                  self.m_output_act.bias)
 
     def _compute_embedding(self, x):
         batch_size = x.shape[0]
