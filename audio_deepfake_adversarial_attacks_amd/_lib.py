@@ -125,6 +125,8 @@ SIGNATURES = {
     "advstep_maxpool2_backward_f32": (ctypes.c_int, [_p, _p, _p, _i64, _i64, _i64, _i64, _p]),
     "advstep_add_maxpool1d_forward_f32": (ctypes.c_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _p]),
     "advstep_maxpool1d_backward_f32": (ctypes.c_int, [_p, _p, _p, _i64, _i64, _i64, _i64, _p]),
+    "advstep_gate_fc_forward_f32": (ctypes.c_int, [_p, _p, _p, _p, _i64, _i64, _p]),
+    "advstep_gate_fc_backward_f32": (ctypes.c_int, [_p, _i64, _p, _p, _f32, _p, _i64, _i64, _p]),
     "advstep_gate_maxpool2_blocks": (_sz, [_i64, _i64]),
     "advstep_gate_maxpool2_forward_f32": (ctypes.c_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _p]),
     "advstep_gate_maxpool2_backward_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p]),

@@ -585,6 +585,44 @@ inline bool pool_dims_ok(int64_t N, int64_t C, int64_t H, int64_t W) {
     return N >= 0 && C >= 0 && H >= 0 && W >= 0 && N * C <= 0x7fffffffLL && H * ((W + 3) / 4) <= 65535LL * kBlock;
 }
 
+
+// ---- SpecRNet's attention gate on (N, C): the Linear + sigmoid forward and its whole backward as one launch each (round 3) ----
+// (specrnet.py:145-149: gate = sigmoid(fc(mean_hw x)); around it autograd ran addmm + sigmoid forward and sum, mul, rsub, mul,
+// mm, div backward — nine launches of 2-5 us on (128, 20..64) tensors, three times per iteration.)  One workgroup per sample,
+// thread c = output channel; C <= 256.
+__global__ __launch_bounds__(256) void gate_fc_forward_kernel(const float *__restrict__ mean, const float *__restrict__ w,
+                                                              const float *__restrict__ bias, float *__restrict__ gate, int C) {
+    __shared__ float m_s[256];
+    const int n = blockIdx.x, c = threadIdx.x;
+    if (c < C) m_s[c] = mean[(int64_t)n * C + c];
+    __syncthreads();
+    if (c >= C) return;
+    float acc = bias ? bias[c] : 0.0f;
+    const float *wr = w + (int64_t)c * C;
+    for (int k = 0; k < C; ++k) acc = fmaf(wr[k], m_s[k], acc);
+    gate[(int64_t)n * C + c] = 1.0f / (1.0f + expf(-acc));
+}
+
+// g_mean[n][k] = inv_hw * sum_c (ggate[n][c] * gate (1 - gate)) * w[c][k],  ggate[n][c] = sum over the partial blocks (fixed order)
+__global__ __launch_bounds__(256) void gate_fc_backward_kernel(const float *__restrict__ partial, int blocks,
+                                                               const float *__restrict__ gate, const float *__restrict__ w,
+                                                               float inv_hw, float *__restrict__ g_mean, int C) {
+    __shared__ float t_s[256];
+    const int n = blockIdx.x, c = threadIdx.x;
+    if (c < C) {
+        const float *pr = partial + ((int64_t)n * C + c) * blocks;
+        float s = 0.0f;
+        for (int b = 0; b < blocks; ++b) s += pr[b];
+        const float g = gate[(int64_t)n * C + c];
+        t_s[c] = s * g * (1.0f - g);
+    }
+    __syncthreads();
+    if (c >= C) return;
+    float acc = 0.0f;
+    for (int k = 0; k < C; ++k) acc = fmaf(t_s[k], w[(int64_t)k * C + c], acc);
+    g_mean[(int64_t)n * C + c] = acc * inv_hw;
+}
+
 }  // namespace
 
 extern "C" {
@@ -800,6 +838,25 @@ int advstep_gate_maxpool2_backward_f32(const float *gy, const uint8_t *sel, cons
     const dim3 grid((unsigned)(N * C), (unsigned)blocks), block(kBlock);
     hipLaunchKernelGGL(pool2_backward_kernel<true>, grid, block, 0, as_stream(stream), gy, sel, x, gate, gx, ggate_partial, (int)H,
                        (int)W, blocks, (const float *)nullptr);
+    return status_after_launch();
+}
+
+int advstep_gate_fc_forward_f32(const float *mean, const float *w, const float *bias, float *gate, int64_t N, int64_t C,
+                                advstep_stream_t stream) {
+    if (N < 0 || C < 1 || C > 256 || N > 0x7fffffffLL) return ADVSTEP_EINVAL;
+    if (N == 0) return ADVSTEP_OK;
+    if (!mean || !w || !gate) return ADVSTEP_EINVAL;
+    hipLaunchKernelGGL(gate_fc_forward_kernel, dim3((unsigned)N), dim3(256), 0, as_stream(stream), mean, w, bias, gate, (int)C);
+    return status_after_launch();
+}
+
+int advstep_gate_fc_backward_f32(const float *ggate_partial, int64_t blocks, const float *gate, const float *w, float inv_hw,
+                                 float *g_mean, int64_t N, int64_t C, advstep_stream_t stream) {
+    if (N < 0 || C < 1 || C > 256 || blocks < 1 || blocks > 0x7fffffffLL || N > 0x7fffffffLL) return ADVSTEP_EINVAL;
+    if (N == 0) return ADVSTEP_OK;
+    if (!ggate_partial || !gate || !w || !g_mean) return ADVSTEP_EINVAL;
+    hipLaunchKernelGGL(gate_fc_backward_kernel, dim3((unsigned)N), dim3(256), 0, as_stream(stream), ggate_partial, (int)blocks, gate, w,
+                       inv_hw, g_mean, (int)C);
     return status_after_launch();
 }
 

@@ -417,7 +417,14 @@ class _AttendPool(torch.autograd.Function):
         N, C, H, W = x.shape
         mean = torch.empty((N, C), dtype=x.dtype, device=x.device)
         _afms_row(0, x, None, None, None, None, mean, N * C, C, H * W)
-        gate = torch.sigmoid(torch.addmm(bias, mean, weight.t()) if bias is not None else mean @ weight.t()).contiguous()
+        lib = _lib.load()
+        if C <= 256 and tuple(weight.shape) == (C, C) and weight.is_contiguous():
+            gate = torch.empty((N, C), dtype=x.dtype, device=x.device)
+            st = lib.advstep_gate_fc_forward_f32(mean.data_ptr(), weight.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                                 gate.data_ptr(), N, C, _stream(x.device))
+            _lib.check(st, "advstep_gate_fc_forward_f32")
+        else:
+            gate = torch.sigmoid(torch.addmm(bias, mean, weight.t()) if bias is not None else mean @ weight.t()).contiguous()
         y = torch.empty((N, C, H // 2, W // 2), dtype=x.dtype, device=x.device)
         sel = torch.empty(max(y.numel(), 1), dtype=torch.uint8, device=x.device)
         st = _lib.load().advstep_gate_maxpool2_forward_f32(x.data_ptr(), gate.data_ptr(), y.data_ptr(), sel.data_ptr(), N, C, H, W,
@@ -437,8 +444,14 @@ class _AttendPool(torch.autograd.Function):
         st = lib.advstep_gate_maxpool2_backward_gate_f32(gy.data_ptr(), sel.data_ptr(), x.data_ptr(), partial.data_ptr(), N, C, H, W,
                                                          _stream(x.device))
         _lib.check(st, "advstep_gate_maxpool2_backward_gate_f32")
-        ggate = partial.sum(dim=1).view(N, C)
-        g_mean = (((ggate * gate * (1.0 - gate)) @ weight) / float(H * W)).contiguous()
+        if C <= 256 and tuple(weight.shape) == (C, C) and weight.is_contiguous():
+            g_mean = torch.empty((N, C), dtype=x.dtype, device=x.device)
+            st = lib.advstep_gate_fc_backward_f32(partial.data_ptr(), blocks, gate.data_ptr(), weight.data_ptr(), 1.0 / float(H * W),
+                                                  g_mean.data_ptr(), N, C, _stream(x.device))
+            _lib.check(st, "advstep_gate_fc_backward_f32")
+        else:
+            ggate = partial.sum(dim=1).view(N, C)
+            g_mean = (((ggate * gate * (1.0 - gate)) @ weight) / float(H * W)).contiguous()
         gx = torch.empty_like(x)
         st = lib.advstep_gate_maxpool2_backward_input_f32(gy.data_ptr(), sel.data_ptr(), gate.data_ptr(), g_mean.data_ptr(),
                                                           gx.data_ptr(), N, C, H, W, _stream(x.device))

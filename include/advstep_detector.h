@@ -116,6 +116,14 @@ int advstep_tail_pool1d_forward_f32(const float *h, const float *res, const floa
 int advstep_tail_pool1d_backward_f32(const float *gy, const uint8_t *sel, const float *h, const float *scale, const float *pre,
                                      float *g_h, float *g_res, int64_t N, int64_t C, int64_t L, int64_t k, advstep_stream_t stream);
 
+/* The attention gate itself on (N, C), C <= 256 (specrnet.py:145-149 with a frozen fc):
+ *   forward:  gate = sigmoid(mean (N, C) . w^T (C, C) + bias)                       — addmm + sigmoid in one launch
+ *   backward: g_mean (N, C) = inv_hw * ((sum_blocks ggate_partial) * gate * (1 - gate)) . w   — the partial sums' reduction,
+ *             sigmoid', fc^T and the mean's 1 / (H W) in one launch (six ATen launches before). */
+int advstep_gate_fc_forward_f32(const float *mean, const float *w, const float *bias, float *gate, int64_t N, int64_t C,
+                                advstep_stream_t stream);
+int advstep_gate_fc_backward_f32(const float *ggate_partial, int64_t blocks, const float *gate, const float *w, float inv_hw,
+                                 float *g_mean, int64_t N, int64_t C, advstep_stream_t stream);
 /* ---- channel gate + MaxPool2d(2) --------------------------------------------------------------------------------------
  * y = MaxPool2d(2)(x * gate[n, c] + gate[n, c]) (src/models/specrnet.py:145-149 followed by `self.pool`, :163-172).
  * Backward: gx = gate * scatter(gy); ggate_partial (N * C, blocks) holds per-workgroup partial sums of
