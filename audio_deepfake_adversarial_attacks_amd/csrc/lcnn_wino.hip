@@ -529,12 +529,12 @@ __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restri
 #pragma unroll 1
             for (int s = 2; s < steps; s += 2) {
                 da = db;
-                if (s + 2 < steps) load_patch(db, (s + 2) >> 1);
                 if (STREAM && (s & 3) == 0) {
-                    dma_landed();
+                    dma_landed();           // vmcnt(0): BEFORE the next pair's patch is requested, or it would wait for that too
                     __syncthreads();        // chunk s/4 is complete in its buffer; chunk s/4 - 1 is free
                     if (s / 4 + 1 < chunks) copy_chunk(s / 4 + 1, (s / 4 + 1) & 1);
                 }
+                if (s + 2 < steps) load_patch(db, (s + 2) >> 1);
                 const int buf = STREAM ? ((s >> 2) & 1) : (s >> 2);
                 step(da, s, a_ptr(s, buf), std::false_type{});
                 step(da, s + 1, a_ptr(s + 1, buf), std::false_type{});
