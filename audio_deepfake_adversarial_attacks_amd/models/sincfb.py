@@ -6,7 +6,8 @@ published algorithm (SincNet, Ravanelli & Bengio 2018, with the odd "sin" filter
 learnable low cut-offs and bandwidths initialised on a mel grid, Hamming-windowed even (cos) and odd (sin)
 band-pass pairs, applied as a strided Conv1d without padding.
 
-PARITY UNPINNED (no golden vector exists for it in the reference).  Parameter / buffer names
+PARITY UNPINNED (no golden vector exists for it in the reference; see DESIGN.md section 5 — the even filters are
+cross-checked against scipy.signal.firwin and the pair against the one-sided-spectrum property in tests/test_models.py).  Parameter / buffer names
 follow asteroid's (`filterbank.low_hz_`, `filterbank.band_hz_`, `filterbank.window_`, `filterbank.n_`)."""
 import numpy as np
 import torch

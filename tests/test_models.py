@@ -1,6 +1,7 @@
 """CPU: the detector restatements against logits / input-gradients produced by the reference's own BaseLCNN,
 BaseSpecRNet and RawNet3-after-its-first-layer (tests/golden/*_body.npz), plus structure checks for RawNet3's sinc
 encoder (third-party, parity-unpinned)."""
+import numpy as np
 import pytest
 import torch
 
@@ -126,6 +127,25 @@ def test_sinc_filterbank_properties():
     assert (cos[k] * inside).sum().abs() > 10 * (cos[k] * outside).sum().abs()
     enc = sincfb.Encoder(fb)
     assert enc(torch.rand(2, 64_600)).shape == (2, 256, 6435)
+
+
+def test_sinc_filterbank_against_scipy_firwin():
+    """Independent anchor for the restated asteroid filterbank: its even filters are scipy's Hamming-windowed ideal band-pass
+    (`firwin(scale=False)`) rescaled by fs / (2 band), and even + i odd is an analytic band-pass (one-sided spectrum)."""
+    from scipy.signal import firwin
+    fb = sincfb.ParamSincFB(256, 251, stride=10)
+    filt = fb.filters().detach().double().numpy()[:, 0]
+    low = (50 + fb.low_hz_.abs()).detach().double().numpy()[:, 0]
+    high = np.minimum(low + 50 + fb.band_hz_.abs().detach().double().numpy()[:, 0], 8000.0)
+    for k in range(128):
+        ref = firwin(251, [low[k], min(high[k], 8000.0 - 1e-3)], pass_zero=False, window="hamming", scale=False, fs=16000.0)
+        ref = ref * 16000.0 / (2 * (high[k] - low[k]))
+        assert np.abs(ref - filt[k]).max() < 5e-5, k                  # float32 evaluation of the closed form
+    spectrum = np.fft.fft(filt[:128] + 1j * filt[128:], 4096, axis=1)
+    positive = (np.abs(spectrum[:, 1:2048]) ** 2).sum(1)
+    negative = (np.abs(spectrum[:, 2049:]) ** 2).sum(1)
+    ratio = negative / positive
+    assert ratio[:-1].max() < 1e-3 and ratio[-1] < 0.05               # the last band touches Nyquist and wraps
 
 
 def test_rawnet3_structure_and_forward():
