@@ -87,6 +87,9 @@ SIGNATURES = {
     "advstep_resconv_prepare_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _i64, _i64, ctypes.c_int, _p]),
     "advstep_resconv_forward_f32": (ctypes.c_int, [_p, _p, _p, _p, ctypes.c_float, _p, _i64, _i64, _i64, _i64, _i64, _i64, _p]),
     "advstep_resconv_pooled_grad_f32": (ctypes.c_int, [_p, _p, _p, _p, ctypes.c_float, _p, _i64, _i64, _i64, _i64, _i64, _p]),
+    "advstep_resconv_forward_act_f32": (ctypes.c_int, [_p, _p, _p, _p, ctypes.c_float, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _p]),
+    "advstep_resconv_pooled_grad_act_f32": (ctypes.c_int, [_p, _p, _p, _p, ctypes.c_float, _p, _i64, _i64, _i64, _i64, _i64, _p]),
+    "advstep_conv3x3_fewin_forward_act_f32": (ctypes.c_int, [_p, _p, _p, ctypes.c_float, _p, _p, _i64, _i64, _i64, _i64, _i64, _p]),
     "advstep_conv3x3_fewin_supported": (ctypes.c_int, [_i64]),
     "advstep_conv3x3_fewin_forward_f32": (ctypes.c_int, [_p, _p, _p, ctypes.c_float, _p, _i64, _i64, _i64, _i64, _i64, _p]),
     "advstep_conv3x3_fewout_grad_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p]),

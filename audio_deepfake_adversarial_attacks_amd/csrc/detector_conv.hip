@@ -46,7 +46,8 @@ __device__ __forceinline__ void window_offsets(int th, int tw, int H, int W, boo
 template <int CIN>
 __global__ __launch_bounds__(kBlock) void fewin_forward_kernel(const float *__restrict__ x, const float *__restrict__ w,
                                                                const float *__restrict__ shift, float slope,
-                                                               float *__restrict__ y, int Cout, int H, int W) {
+                                                               float *__restrict__ y, uint8_t *__restrict__ act, int Cout, int H,
+                                                               int W) {
     const int TH = (H + 1) >> 1, TW = (W + 1) >> 1;
     const int64_t n = blockIdx.y;
     const int t = blockIdx.x * kBlock + threadIdx.x;
@@ -92,6 +93,11 @@ __global__ __launch_bounds__(kBlock) void fewin_forward_kernel(const float *__re
         const float sh = shift ? shift[co] : 0.0f;
         r0 += (f32x2){sh, sh};
         r1 += (f32x2){sh, sh};
+        // the activation's sign bytes (N, Cout, TH, TW), bit 2 i + j = output (i, j) of this 2x2 block > 0: what the input
+        // gradient of the NEXT convolution multiplies by (lcnn_wino.hip EPI 6) instead of reading y again; 0 outside an odd-sized plane
+        if (act)
+            act[((n * Cout + co) * TH + th) * (int64_t)TW + tw] =
+                (uint8_t)((r0.x > 0.0f) | ((w1 && r0.y > 0.0f) << 1) | ((h1 && r1.x > 0.0f) << 2) | ((h1 && w1 && r1.y > 0.0f) << 3));
         r0.x = r0.x > 0.0f ? r0.x : r0.x * slope;
         r0.y = r0.y > 0.0f ? r0.y : r0.y * slope;
         r1.x = r1.x > 0.0f ? r1.x : r1.x * slope;
@@ -327,17 +333,23 @@ extern "C" {
 
 int advstep_conv3x3_fewin_supported(int64_t Cin) { return Cin == 1 || Cin == 2; }
 
-int advstep_conv3x3_fewin_forward_f32(const float *x, const float *w, const float *shift, float slope, float *y, int64_t N,
-                                      int64_t Cin, int64_t Cout, int64_t H, int64_t W, advstep_stream_t stream) {
+int advstep_conv3x3_fewin_forward_act_f32(const float *x, const float *w, const float *shift, float slope, float *y,
+                                          uint8_t *act, int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W,
+                                          advstep_stream_t stream) {
     if (!advstep_conv3x3_fewin_supported(Cin) || !dims_ok(N, Cout, H, W)) return ADVSTEP_EINVAL;
     if (N * H * W == 0) return ADVSTEP_OK;
     if (!x || !w || !y) return ADVSTEP_EINVAL;
     const dim3 grid((unsigned)ceil_div(((H + 1) / 2) * ((W + 1) / 2), kBlock), (unsigned)N), block(kBlock);
     if (Cin == 1)
-        hipLaunchKernelGGL(fewin_forward_kernel<1>, grid, block, 0, as_stream(stream), x, w, shift, slope, y, (int)Cout, (int)H, (int)W);
+        hipLaunchKernelGGL(fewin_forward_kernel<1>, grid, block, 0, as_stream(stream), x, w, shift, slope, y, act, (int)Cout, (int)H, (int)W);
     else
-        hipLaunchKernelGGL(fewin_forward_kernel<2>, grid, block, 0, as_stream(stream), x, w, shift, slope, y, (int)Cout, (int)H, (int)W);
+        hipLaunchKernelGGL(fewin_forward_kernel<2>, grid, block, 0, as_stream(stream), x, w, shift, slope, y, act, (int)Cout, (int)H, (int)W);
     return status_after_launch();
+}
+
+int advstep_conv3x3_fewin_forward_f32(const float *x, const float *w, const float *shift, float slope, float *y, int64_t N,
+                                      int64_t Cin, int64_t Cout, int64_t H, int64_t W, advstep_stream_t stream) {
+    return advstep_conv3x3_fewin_forward_act_f32(x, w, shift, slope, y, nullptr, N, Cin, Cout, H, W, stream);
 }
 
 int advstep_conv3x3_fewout_grad_f32(const float *g1, const float *w3, const float *gp, const uint8_t *sel, const float *wd,

@@ -230,6 +230,9 @@ __global__ void wino_prepare_plain_kernel(const float *__restrict__ w3, const fl
 // EPI 4: + bias[ch], MaxPool2d(2) with ATen's selection byte (detector_elem.hip::pool4): the conv output never exists.
 // EPI 5: * (h > 0 ? 1 : slope) with h (N, Cout, H, W) passed in `bn_mean` — LeakyReLU's backward from its OUTPUT (same sign as
 //        its input for slope > 0) — plain store.
+// EPI 6: the same from the activation's SIGN BYTES passed in `idx` (read only): one byte per (n, channel, 2x2 tile), bit 2 i + j =
+//        h > 0 at tile position (i, j), (N, Cout, TH, TW) — what EPI 3 writes next to h when it is given an `idx` to fill.  At
+//        SpecRNet's first block that is 21 MB in the epilogue instead of 331 MB of h: 476 -> 3xx us (round 3).
 // NT: accumulator tiles a wave computes — 2, or 1 for a convolution's LAST slice when only its first 16 rows exist
 //     (Cout % 32 in 1..16, LCNN's 128 -> 48 input gradient): that slice is launched on its own with half the matrix
 //     instructions instead of multiplying 16 zero rows.  slice0: first slice of this launch.
@@ -254,7 +257,7 @@ __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restri
                                                            const float *__restrict__ bn_invstd, float *__restrict__ y,
                                                            uint8_t *__restrict__ idx, int N, int K, int H, int W, int Cout,
                                                            int slices, int ranges, int slice0, GenArgs ga) {
-    static_assert(NT == 2 || EPI == 0 || EPI == 3 || EPI == 5, "one accumulator tile only for the plain-store epilogues");
+    static_assert(NT == 2 || EPI == 0 || EPI == 3 || EPI == 5 || EPI == 6, "one accumulator tile only for the plain-store epilogues");
     static_assert(!GEN || SRC != 1, "the general reduction reads dense tensors or a plain pooled gradient");
     extern __shared__ __attribute__((aligned(16))) float u_s[];
     int slice_i = blockIdx.x % slices, range = blockIdx.x / slices;
@@ -612,6 +615,17 @@ __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restri
                     }
                 }
         }
+        uint32_t hb6[EPI == 6 ? 4 : 1][EPI == 6 ? NT : 1];      // EPI 6: the same moment, one byte per (row, tile)
+        if constexpr (EPI == 6) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int m = 0; m < NT; ++m) {
+                    const int ch = slice * 32 + m * 16 + 4 * g + r;
+                    const bool live = valid && ch < Cout;
+                    hb6[r][m] = live ? idx[(((size_t)n * Cout + ch) * TH + th) * TW + tw] : 0u;
+                }
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float yy[2][2][2];
@@ -692,10 +706,19 @@ __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restri
                     const int ch = slice * 32 + m * 16 + 4 * g + r;
                     if (!(valid && ch < Cout)) continue;
                     if (EPI == 3) {
+                        uint32_t bits = 0;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const float v = yy[m][e >> 1][e & 1];
+                            bits |= (uint32_t)(v > 0.0f) << e;
                             yy[m][e >> 1][e & 1] = v > 0.0f ? v : v * ga.slope;
+                        }
+                        // the activation's sign bytes for EPI 6 (v > 0 and output > 0 are the same statement for slope > 0);
+                        // positions outside an odd-sized plane read 0
+                        if (idx) {
+                            if (2 * tw + 1 >= W) bits &= 0x5u;
+                            if (2 * th + 1 >= H) bits &= 0x3u;
+                            idx[(((size_t)n * Cout + ch) * TH + th) * TW + tw] = (uint8_t)bits;
                         }
                     }
                     float *o = y + (((size_t)n * Cout + ch) * H + 2 * th) * W + 2 * tw;
@@ -703,6 +726,10 @@ __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restri
                     if (EPI == 5) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) yy[m][e >> 1][e & 1] *= hv5[r][m][e >> 1][e & 1] > 0.0f ? 1.0f : ga.slope;
+                    }
+                    if (EPI == 6) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) yy[m][e >> 1][e & 1] *= (hb6[r][m] >> e) & 1u ? 1.0f : ga.slope;
                     }
                     if ((W & 1) == 0) {   // rows are 8-byte aligned: one 64-bit store per tile row
                         *reinterpret_cast<f32x2 *>(o) = (f32x2){yy[m][0][0], yy[m][0][1]};
@@ -779,7 +806,7 @@ int launch_wino(const float *x, const uint8_t *xsel, const float *U, const float
     };
     // plain-store epilogues with a half-empty last slice (Cout % 32 in 1..16): that slice on its own, one accumulator tile
     int full = slices;
-    if constexpr (EPI == 0 || EPI == 3 || EPI == 5) {
+    if constexpr (EPI == 0 || EPI == 3 || EPI == 5 || EPI == 6) {
         const int live_last = (int)(Cout - (int64_t)(slices - 1) * 32);
         if (live_last <= 16 && half_slice_enabled()) {
             full = slices - 1;
@@ -918,15 +945,21 @@ static int resconv_check(const float *x1, const float *x2, const float *U, const
     return ADVSTEP_OK;
 }
 
-int advstep_resconv_forward_f32(const float *x1, const float *x2, const float *U, const float *shift, float slope, float *y,
-                                int64_t N, int64_t K1, int64_t K2, int64_t rows, int64_t H, int64_t W,
-                                advstep_stream_t stream) {
+int advstep_resconv_forward_act_f32(const float *x1, const float *x2, const float *U, const float *shift, float slope, float *y,
+                                    uint8_t *act, int64_t N, int64_t K1, int64_t K2, int64_t rows, int64_t H, int64_t W,
+                                    advstep_stream_t stream) {
     WINO_REQUIRE(N >= 0 && H >= 0 && W >= 0 && advstep_resconv_supported(K1, K2, rows));
     if (N == 0 || H == 0 || W == 0) return ADVSTEP_OK;
     if (const int st = resconv_check(x1, x2, U, y, N, K1, K2, rows, H, W)) return st;
     const int64_t K = (K1 + K2 <= 8) ? 8 : ceil_div(K1 + K2, 4) * 4;      // at least two k-steps; an odd count is fine
-    return launch_wino<3, 0, true>(x1, nullptr, U, shift, nullptr, nullptr, y, nullptr, N, K, H, W, rows, (int)ceil_div(rows, 32),
+    return launch_wino<3, 0, true>(x1, nullptr, U, shift, nullptr, nullptr, y, act, N, K, H, W, rows, (int)ceil_div(rows, 32),
                                    as_stream(stream), GenArgs{x2, (int)K1, (int)(K1 + K2), slope, 0});
+}
+
+int advstep_resconv_forward_f32(const float *x1, const float *x2, const float *U, const float *shift, float slope, float *y,
+                                int64_t N, int64_t K1, int64_t K2, int64_t rows, int64_t H, int64_t W,
+                                advstep_stream_t stream) {
+    return advstep_resconv_forward_act_f32(x1, x2, U, shift, slope, y, nullptr, N, K1, K2, rows, H, W, stream);
 }
 
 int advstep_resconv_pool2_forward_f32(const float *x1, const float *x2, const float *U, const float *bias, float *y,
@@ -941,8 +974,8 @@ int advstep_resconv_pool2_forward_f32(const float *x1, const float *x2, const fl
                                    as_stream(stream), GenArgs{x2, (int)K1, (int)(K1 + K2), 1.0f, 0});
 }
 
-int advstep_resconv_pooled_grad_f32(const float *gy, const uint8_t *sel, const float *U, const float *h, float slope, float *g,
-                                    int64_t N, int64_t K, int64_t rows, int64_t H, int64_t W, advstep_stream_t stream) {
+static int pooled_grad(const float *gy, const uint8_t *sel, const float *U, const float *h, const uint8_t *act, float slope,
+                       float *g, int64_t N, int64_t K, int64_t rows, int64_t H, int64_t W, advstep_stream_t stream) {
     WINO_REQUIRE(N >= 0 && H >= 0 && W >= 0 && advstep_resconv_supported(K, 0, rows));
     if (N == 0 || H == 0 || W == 0) return ADVSTEP_OK;
     WINO_REQUIRE(g);
@@ -954,11 +987,26 @@ int advstep_resconv_pooled_grad_f32(const float *gy, const uint8_t *sel, const f
                  (uint64_t)N * ((H + 1) / 2) * ((W + 1) / 2) < (1ull << 31));
     const int64_t Kp = K <= 8 ? 8 : ceil_div(K, 4) * 4;
     const GenArgs ga{nullptr, (int)K, (int)K, slope, 0};
+    if (act)
+        return launch_wino<6, 2, true>(gy, sel, U, nullptr, nullptr, nullptr, g, const_cast<uint8_t *>(act), N, Kp, H, W, rows,
+                                       (int)ceil_div(rows, 32), as_stream(stream), ga);
     if (h)
         return launch_wino<5, 2, true>(gy, sel, U, nullptr, h, nullptr, g, nullptr, N, Kp, H, W, rows, (int)ceil_div(rows, 32),
                                        as_stream(stream), ga);
     return launch_wino<0, 2, true>(gy, sel, U, nullptr, nullptr, nullptr, g, nullptr, N, Kp, H, W, rows, (int)ceil_div(rows, 32),
                                    as_stream(stream), ga);
+}
+
+int advstep_resconv_pooled_grad_f32(const float *gy, const uint8_t *sel, const float *U, const float *h, float slope, float *g,
+                                    int64_t N, int64_t K, int64_t rows, int64_t H, int64_t W, advstep_stream_t stream) {
+    return pooled_grad(gy, sel, U, h, nullptr, slope, g, N, K, rows, H, W, stream);
+}
+
+int advstep_resconv_pooled_grad_act_f32(const float *gy, const uint8_t *sel, const float *U, const uint8_t *act, float slope,
+                                        float *g, int64_t N, int64_t K, int64_t rows, int64_t H, int64_t W,
+                                        advstep_stream_t stream) {
+    if (!act) return ADVSTEP_EINVAL;
+    return pooled_grad(gy, sel, U, nullptr, act, slope, g, N, K, rows, H, W, stream);
 }
 
 }  // extern "C"

@@ -497,9 +497,15 @@ def resconv_prepare(w3: torch.Tensor, w1: Optional[torch.Tensor] = None, rscale:
     return U
 
 
+def _sign_bytes(N: int, rows: int, H: int, W: int, device) -> torch.Tensor:
+    """Room for an activation's sign bytes: one per (sample, channel, 2x2 tile), bit 2 i + j = output > 0 at tile position (i, j)."""
+    return torch.empty((N, rows, (H + 1) // 2, (W + 1) // 2), dtype=torch.uint8, device=device)
+
+
 def resconv(x1: torch.Tensor, x2: Optional[torch.Tensor], U: torch.Tensor, rows: int, shift: Optional[torch.Tensor] = None,
-            slope: float = 1.0) -> torch.Tensor:
-    """leaky_relu(conv3x3(x1) + conv1x1(x2) + shift[row], slope) with prepared weights U — no autograd (building block)."""
+            slope: float = 1.0, with_act: bool = False):
+    """leaky_relu(conv3x3(x1) + conv1x1(x2) + shift[row], slope) with prepared weights U — no autograd (building block).
+    with_act: returns (y, act) with the sign bytes of y (see `_sign_bytes`) for `resconv_pooled_grad(act=...)`."""
     _require(x1, "x1")
     N, K1, H, W = x1.shape
     K2 = 0 if x2 is None else x2.shape[1]
@@ -508,12 +514,14 @@ def resconv(x1: torch.Tensor, x2: Optional[torch.Tensor], U: torch.Tensor, rows:
         if x2.shape[0] != N or tuple(x2.shape[2:]) != (H, W):
             raise ValueError("x1 and x2 must share batch and spatial dimensions")
     y = torch.empty((N, rows, H, W), dtype=x1.dtype, device=x1.device)
+    act = _sign_bytes(N, rows, H, W, x1.device) if with_act else None
     with _Launch("resconv_forward", x1.device, work=8.0 * N * rows * (K1 + K2) * H * W):
-        st = _lib.load().advstep_resconv_forward_f32(x1.data_ptr(), None if x2 is None else x2.data_ptr(), U.data_ptr(),
-                                                     None if shift is None else shift.data_ptr(), float(slope), y.data_ptr(), N,
-                                                     K1, K2, rows, H, W, _stream(x1.device))
-    _lib.check(st, "advstep_resconv_forward_f32")
-    return y
+        st = _lib.load().advstep_resconv_forward_act_f32(x1.data_ptr(), None if x2 is None else x2.data_ptr(), U.data_ptr(),
+                                                         None if shift is None else shift.data_ptr(), float(slope), y.data_ptr(),
+                                                         None if act is None else act.data_ptr(), N, K1, K2, rows, H, W,
+                                                         _stream(x1.device))
+    _lib.check(st, "advstep_resconv_forward_act_f32")
+    return (y, act) if with_act else y
 
 
 def resconv_pool2(x1: torch.Tensor, x2: Optional[torch.Tensor], U: torch.Tensor, rows: int,
@@ -535,9 +543,10 @@ def resconv_pool2(x1: torch.Tensor, x2: Optional[torch.Tensor], U: torch.Tensor,
 
 
 def resconv_pooled_grad(gy: torch.Tensor, sel: torch.Tensor, U: torch.Tensor, rows: int, H: int, W: int,
-                        h: Optional[torch.Tensor] = None, slope: float = 1.0) -> torch.Tensor:
+                        h: Optional[torch.Tensor] = None, slope: float = 1.0, act: Optional[torch.Tensor] = None) -> torch.Tensor:
     """conv3x3(unpool(gy, sel)) [* leaky_relu'(h)] with U prepared with transpose=True: the input gradient of a convolution whose
-    output went through MaxPool2d(2), straight from the pooled gradient (N, K, H//2, W//2) — no autograd (building block)."""
+    output went through MaxPool2d(2), straight from the pooled gradient (N, K, H//2, W//2) — no autograd (building block).
+    The activation is given as its output h or as the sign bytes `act` a forward kernel wrote next to h (`with_act=True`)."""
     _require(gy, "gy")
     N, K = gy.shape[0], gy.shape[1]
     if tuple(gy.shape[2:]) != (H // 2, W // 2) or sel.numel() < gy.numel() or sel.dtype != torch.uint8:
@@ -546,11 +555,20 @@ def resconv_pooled_grad(gy: torch.Tensor, sel: torch.Tensor, U: torch.Tensor, ro
         _require(h, "h")
         if tuple(h.shape) != (N, rows, H, W):
             raise ValueError("h must have the output's shape")
+    if act is not None:
+        if h is not None:
+            raise ValueError("give the activation as h or as act, not both")
+        if act.dtype != torch.uint8 or not act.is_contiguous() or tuple(act.shape) != (N, rows, (H + 1) // 2, (W + 1) // 2):
+            raise ValueError("act must be the contiguous (N, rows, ceil(H/2), ceil(W/2)) sign bytes of the activation")
     g = torch.empty((N, rows, H, W), dtype=gy.dtype, device=gy.device)
     with _Launch("resconv_pooled_grad", gy.device, work=8.0 * N * rows * K * H * W):
-        st = _lib.load().advstep_resconv_pooled_grad_f32(gy.data_ptr(), sel.data_ptr(), U.data_ptr(),
-                                                         None if h is None else h.data_ptr(), float(slope), g.data_ptr(), N, K, rows,
-                                                         H, W, _stream(gy.device))
+        if act is not None:
+            st = _lib.load().advstep_resconv_pooled_grad_act_f32(gy.data_ptr(), sel.data_ptr(), U.data_ptr(), act.data_ptr(),
+                                                                 float(slope), g.data_ptr(), N, K, rows, H, W, _stream(gy.device))
+        else:
+            st = _lib.load().advstep_resconv_pooled_grad_f32(gy.data_ptr(), sel.data_ptr(), U.data_ptr(),
+                                                             None if h is None else h.data_ptr(), float(slope), g.data_ptr(), N, K,
+                                                             rows, H, W, _stream(gy.device))
     _lib.check(st, "advstep_resconv_pooled_grad_f32")
     return g
 
@@ -559,17 +577,20 @@ def conv3x3_fewin_supported(channels: int) -> bool:
     return bool(_lib.load().advstep_conv3x3_fewin_supported(channels))
 
 
-def conv3x3_fewin(x: torch.Tensor, w: torch.Tensor, shift: Optional[torch.Tensor], slope: float) -> torch.Tensor:
-    """leaky_relu(conv3x3(x, w, pad 1) + shift[co], slope) for 1-2 input channels (vector-ALU kernel) — no autograd."""
+def conv3x3_fewin(x: torch.Tensor, w: torch.Tensor, shift: Optional[torch.Tensor], slope: float, with_act: bool = False):
+    """leaky_relu(conv3x3(x, w, pad 1) + shift[co], slope) for 1-2 input channels (vector-ALU kernel) — no autograd.
+    with_act: returns (y, act) with the sign bytes of y (see `_sign_bytes`)."""
     _require(x, "x"), _require(w, "w")
     N, Cin, H, W = x.shape
     Cout = w.shape[0]
     y = torch.empty((N, Cout, H, W), dtype=x.dtype, device=x.device)
+    act = _sign_bytes(N, Cout, H, W, x.device) if with_act else None
     with _Launch("conv3x3_fewin_forward", x.device):
-        st = _lib.load().advstep_conv3x3_fewin_forward_f32(x.data_ptr(), w.data_ptr(), None if shift is None else shift.data_ptr(),
-                                                           float(slope), y.data_ptr(), N, Cin, Cout, H, W, _stream(x.device))
-    _lib.check(st, "advstep_conv3x3_fewin_forward_f32")
-    return y
+        st = _lib.load().advstep_conv3x3_fewin_forward_act_f32(x.data_ptr(), w.data_ptr(), None if shift is None else shift.data_ptr(),
+                                                               float(slope), y.data_ptr(), None if act is None else act.data_ptr(),
+                                                               N, Cin, Cout, H, W, _stream(x.device))
+    _lib.check(st, "advstep_conv3x3_fewin_forward_act_f32")
+    return (y, act) if with_act else y
 
 
 def conv3x3_fewout_grad(g1: torch.Tensor, w3: torch.Tensor, gp: Optional[torch.Tensor] = None, sel: Optional[torch.Tensor] = None,
@@ -660,6 +681,12 @@ def res_block_plan(block, conv1, bn2, conv2, down, slope: float) -> ResBlockPlan
     return block._advstep_plan
 
 
+def _act_bytes_enabled() -> bool:
+    """ADVSTEP_RESBLOCK_ACT=0 (read per call): the residual blocks save h1 itself for backward (A/B measurements)."""
+    import os
+    return os.environ.get("ADVSTEP_RESBLOCK_ACT", "1") != "0"
+
+
 class _ResBlock(torch.autograd.Function):
     """MaxPool2d(2)(conv2(leaky_relu(bn2(conv1(x)))) + identity) of SpecRNet's Residual_block2D (src/models/specrnet.py:73-91),
     identity = conv_downsample(x) or x; input gradient only.  The downsample convolution is part of conv2's reduction and the
@@ -669,16 +696,20 @@ class _ResBlock(torch.autograd.Function):
     def forward(ctx, x, plan):
         _require(x, "x")
         p = plan
+        # backward needs only the SIGN of h1 (LeakyReLU's derivative): the kernel that writes h1 also writes one byte per 2x2
+        # tile with the four signs, and that — 1/16 of h1's bytes — is what is saved and read back (ADVSTEP_RESBLOCK_ACT=0: h1)
+        compact = p.slope > 0 and _act_bytes_enabled()
         if p.fewin:
-            h1 = conv3x3_fewin(x, p.w1_scaled, p.shift, p.slope)
+            h1 = conv3x3_fewin(x, p.w1_scaled, p.shift, p.slope, with_act=compact)
         else:
-            h1 = resconv(x, None, p.U1, p.cout, p.shift, p.slope)
+            h1 = resconv(x, None, p.U1, p.cout, p.shift, p.slope, with_act=compact)
+        h1, act = h1 if compact else (h1, None)
         if p.downsample:
             y, sel = resconv_pool2(h1, x, p.U2, p.cout, p.bias)
         else:
             y, sel = _add_maxpool2_raw(resconv(h1, None, p.U2, p.cout), x, p.bias)
-        ctx.plan = p
-        ctx.save_for_backward(x, h1, sel)
+        ctx.plan, ctx.compact = p, compact
+        ctx.save_for_backward(x, act if compact else h1, sel)
         return y
 
     @staticmethod
@@ -689,7 +720,10 @@ class _ResBlock(torch.autograd.Function):
         gy = gy.contiguous()
         lib = _lib.load()
         # d(conv1 out) / bn2 scale = conv2^T(unpool(gy)) * lrelu'(h1): unpooling in the operand load, lrelu' in the epilogue
-        g_pre = resconv_pooled_grad(gy, sel, p.U2T, p.cout, H, W, h1, p.slope)
+        if ctx.compact:
+            g_pre = resconv_pooled_grad(gy, sel, p.U2T, p.cout, H, W, None, p.slope, act=h1)
+        else:
+            g_pre = resconv_pooled_grad(gy, sel, p.U2T, p.cout, H, W, h1, p.slope)
         if p.fewin:
             return conv3x3_fewout_grad(g_pre, p.w1_scaled, gy, sel, p.wd), None
         g_h2 = torch.empty((N, p.cout, H, W), dtype=gy.dtype, device=gy.device)       # the identity path's gradient

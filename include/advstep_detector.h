@@ -155,6 +155,12 @@ int advstep_resconv_prepare_f32(const float *w3, const float *w1, const float *r
 int advstep_resconv_forward_f32(const float *x1, const float *x2, const float *U, const float *shift, float slope, float *y,
                                 int64_t N, int64_t K1, int64_t K2, int64_t rows, int64_t H, int64_t W,
                                 advstep_stream_t stream);
+/* The same, also writing the activation's SIGN BYTES act (N, rows, ceil(H/2), ceil(W/2)): bit 2 i + j of the byte of a 2x2
+ * tile = y > 0 at tile position (i, j) — all advstep_resconv_pooled_grad_act_f32 needs of y (1/16 of its bytes).  act may be
+ * NULL (= advstep_resconv_forward_f32). */
+int advstep_resconv_forward_act_f32(const float *x1, const float *x2, const float *U, const float *shift, float slope, float *y,
+                                    uint8_t *act, int64_t N, int64_t K1, int64_t K2, int64_t rows, int64_t H, int64_t W,
+                                    advstep_stream_t stream);
 /* y (N, rows, H/2, W/2) = MaxPool2d(2)(conv + bias[row]) with the selection bytes of advstep_add_maxpool2_forward_f32
  * (consumed by advstep_maxpool2_backward_f32): the full-resolution convolution output is never written. */
 int advstep_resconv_pool2_forward_f32(const float *x1, const float *x2, const float *U, const float *bias, float *y,
@@ -169,6 +175,13 @@ int advstep_resconv_pool2_forward_f32(const float *x1, const float *x2, const fl
 int advstep_resconv_pooled_grad_f32(const float *gy, const uint8_t *sel, const float *U, const float *h, float slope, float *g,
                                     int64_t N, int64_t K, int64_t rows, int64_t H, int64_t W, advstep_stream_t stream);
 
+/* The same with the activation given as sign bytes (advstep_resconv_forward_act_f32 / advstep_conv3x3_fewin_forward_act_f32):
+ * g = conv3x3(unpool(gy, sel)) * (bit ? 1 : slope).  Bit-identical to the h form for slope > 0; the epilogue reads 1 byte per
+ * 2x2 tile and row instead of 16 (SpecRNet block0, B = 128: 21 MB instead of 331 MB). */
+int advstep_resconv_pooled_grad_act_f32(const float *gy, const uint8_t *sel, const float *U, const uint8_t *act, float slope,
+                                        float *g, int64_t N, int64_t K, int64_t rows, int64_t H, int64_t W,
+                                        advstep_stream_t stream);
+
 /* ---- the spectrogram end of SpecRNet's first block: 3x3 convolutions with 1-2 channels on one side (csrc/detector_conv.hip) --
  * Vector-ALU kernels (a matrix tile would be mostly padding), thread = one 2x2 block of positions.
  * forward:  y (N, Cout, H, W) = leaky_relu(conv3x3(x (N, Cin, H, W), w (Cout, Cin, 3, 3), pad 1) + shift[co], slope), Cin in {1, 2};
@@ -180,6 +193,11 @@ int advstep_resconv_pooled_grad_f32(const float *gy, const uint8_t *sel, const f
 int advstep_conv3x3_fewin_supported(int64_t channels);
 int advstep_conv3x3_fewin_forward_f32(const float *x, const float *w, const float *shift, float slope, float *y, int64_t N,
                                       int64_t Cin, int64_t Cout, int64_t H, int64_t W, advstep_stream_t stream);
+/* forward that also writes the sign bytes act (N, Cout, ceil(H/2), ceil(W/2)) of its output (see advstep_resconv_forward_act_f32);
+ * act may be NULL. */
+int advstep_conv3x3_fewin_forward_act_f32(const float *x, const float *w, const float *shift, float slope, float *y,
+                                          uint8_t *act, int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W,
+                                          advstep_stream_t stream);
 int advstep_conv3x3_fewout_grad_f32(const float *g1, const float *w3, const float *gp, const uint8_t *sel, const float *wd,
                                     float *gx, int64_t N, int64_t K, int64_t rows, int64_t H, int64_t W,
                                     advstep_stream_t stream);

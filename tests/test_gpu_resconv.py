@@ -234,6 +234,87 @@ def test_residual_block_matches_plain_modules(D, cuda, monkeypatch, parity_recor
     assert fig["grad_rel_l2"] <= 2e-3, fig
 
 
+def sign_bytes(y):
+    """(N, C, ceil(H/2), ceil(W/2)) bytes, bit 2 i + j = y > 0 at position (i, j) of the 2x2 tile (0 outside the plane)."""
+    N, C, H, W = y.shape
+    pos = F.pad((y > 0).to(torch.uint8), (0, W % 2, 0, H % 2))
+    t = pos.view(N, C, (H + 1) // 2, 2, (W + 1) // 2, 2)
+    return t[:, :, :, 0, :, 0] | (t[:, :, :, 0, :, 1] << 1) | (t[:, :, :, 1, :, 0] << 2) | (t[:, :, :, 1, :, 1] << 3)
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_forward_sign_bytes_are_the_signs_of_the_output_it_wrote(D, cuda, shape):
+    """with_act=True: the same y as without, and one byte per 2x2 tile whose bits are exactly y > 0 (odd sizes: 0 outside)."""
+    N, K1, K2, R, H, W = shape
+    x1, w3 = rnd((N, K1, H, W), 1, cuda), rnd((R, K1, 3, 3), 2, cuda, 0.2)
+    x2, w1 = (rnd((N, K2, H, W), 3, cuda), rnd((R, K2), 4, cuda, 0.3)) if K2 else (None, None)
+    shift, U = rnd((R,), 5, cuda), None
+    U = D.resconv_prepare(w3, w1)
+    y0 = D.resconv(x1, x2, U, R, shift, 0.3)
+    y, act = D.resconv(x1, x2, U, R, shift, 0.3, with_act=True)
+    assert torch.equal(y, y0) and act.dtype == torch.uint8 and act.shape == (N, R, (H + 1) // 2, (W + 1) // 2)
+    assert torch.equal(act, sign_bytes(y))
+
+
+@pytest.mark.parametrize("shape", [(2, 2, 20, 16, 24), (2, 1, 20, 7, 9), (1, 2, 5, 1, 1), (2, 2, 20, 80, 404), (3, 1, 3, 2, 3), (1, 2, 7, 5, 4)])
+def test_few_input_channel_forward_sign_bytes(D, cuda, shape):
+    N, Cin, Cout, H, W = shape
+    x, w, shift = rnd((N, Cin, H, W), 1, cuda), rnd((Cout, Cin, 3, 3), 2, cuda, 0.3), rnd((Cout,), 3, cuda)
+    y0 = D.conv3x3_fewin(x, w, shift, 0.3)
+    y, act = D.conv3x3_fewin(x, w, shift, 0.3, with_act=True)
+    assert torch.equal(y, y0) and torch.equal(act, sign_bytes(y))
+
+
+@pytest.mark.parametrize("shape", [(2, 20, 20, 16, 24), (3, 64, 64, 20, 101), (2, 64, 64, 5, 25), (1, 20, 20, 7, 9), (2, 12, 40, 2, 2),
+                                   (1, 8, 3, 1, 6), (2, 4, 2, 6, 8), (2, 128, 48, 9, 11)])
+def test_pooled_gradient_from_sign_bytes_equals_the_one_from_the_activation(D, cuda, shape):
+    """advstep_resconv_pooled_grad_act_f32 == advstep_resconv_pooled_grad_f32 given h, bit for bit (zeros and negative zeros of h
+    take the slope in both)."""
+    N, K, R, H, W = shape
+    full = rnd((N, K, H, W), 1, cuda)
+    U = D.resconv_prepare(rnd((K, R, 3, 3), 2, cuda, 0.2), transpose=True)
+    h = rnd((N, R, H, W), 3, cuda)
+    h.view(-1)[::7] = 0.0
+    h.view(-1)[3::11] = -0.0
+    act = sign_bytes(h).contiguous()
+    if H // 2 == 0 or W // 2 == 0:
+        gy = torch.zeros((N, K, H // 2, W // 2), device=cuda)
+        assert not D.resconv_pooled_grad(gy, torch.zeros(1, dtype=torch.uint8, device=cuda), U, R, H, W, None, 0.3, act=act).any()
+        return
+    _, sel = D._add_maxpool2_raw(full, None, None)
+    gy = rnd((N, K, H // 2, W // 2), 4, cuda)
+    assert torch.equal(D.resconv_pooled_grad(gy, sel, U, R, H, W, None, 0.3, act=act), D.resconv_pooled_grad(gy, sel, U, R, H, W, h, 0.3))
+    with pytest.raises(ValueError):
+        D.resconv_pooled_grad(gy, sel, U, R, H, W, h, 0.3, act=act)
+    with pytest.raises(ValueError):
+        D.resconv_pooled_grad(gy, sel, U, R, H, W, None, 0.3, act=act.view(-1))
+
+
+@pytest.mark.parametrize("cin,cout,first,hw", [(2, 20, True, (16, 24)), (20, 64, False, (20, 101)), (64, 64, False, (5, 25)),
+                                               (1, 20, True, (9, 13))])
+def test_residual_block_saving_sign_bytes_equals_the_one_saving_the_activation(D, cuda, monkeypatch, cin, cout, first, hw):
+    blk = make_block(cin, cout, first, cuda, 11)
+    x = rnd((2, cin) + hw, 7, cuda)
+    gy = rnd((2, cout, hw[0] // 2, hw[1] // 2), 8, cuda)
+    monkeypatch.setenv("ADVSTEP_SPECRNET_CONV", "1")
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("ADVSTEP_RESBLOCK_ACT", mode)
+        a = x.clone().requires_grad_(True)
+        y = blk(a)
+        saved, stack = [], [y.grad_fn]
+        while stack:
+            fn = stack.pop()
+            if fn is None:
+                continue
+            saved += list(getattr(fn, "saved_tensors", ()))
+            stack += [nf for nf, _ in fn.next_functions]
+        (g,) = torch.autograd.grad(y, a, gy)
+        out[mode] = (y.detach(), g, sorted(t.dtype == torch.uint8 and t.dim() == 4 for t in saved))
+    assert torch.equal(out["1"][0], out["0"][0]) and torch.equal(out["1"][1], out["0"][1])
+    assert any(out["1"][2]) and not any(out["0"][2])        # the byte tensor replaced the activation among the saved tensors
+
+
 def test_plan_is_rebuilt_when_a_parameter_changes(D, cuda, monkeypatch):
     monkeypatch.setenv("ADVSTEP_SPECRNET_CONV", "1")
     blk = make_block(20, 64, False, cuda, 5)

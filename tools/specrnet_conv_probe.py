@@ -91,7 +91,34 @@ def direct(B):
     print(f"direct  block0 conv1^T + down^T (20 + pooled 20 -> 2)          {t:7.1f} us ({(20 + 5.25 + 2) * B * H * W * 4 / t / 1e3:6.0f} GB/s)", flush=True)
 
 
+def pooled(B):
+    """The input gradients that start from a pooled gradient + selection bytes (what an attack iteration runs)."""
+    from audio_deepfake_adversarial_attacks_amd import detector_ops as D
+    dev = "cuda"
+    for name, K, rows, H, W in [("block0 conv2^T from pooled gy * lrelu'", 20, 20, 80, 404),
+                                ("block2 conv2^T from pooled gy * lrelu'", 64, 64, 20, 101),
+                                ("block4 conv2^T from pooled gy * lrelu'", 64, 64, 5, 25)]:
+        full = torch.randn(B, K, H, W, device=dev)
+        _, sel = D._add_maxpool2_raw(full, None, None)
+        gy = torch.randn(B, K, H // 2, W // 2, device=dev)
+        h = torch.randn(B, rows, H, W, device=dev)
+        U = D.resconv_prepare(torch.randn(K, rows, 3, 3, device=dev) * 0.1, transpose=True)
+        t = timed(lambda: D.resconv_pooled_grad(gy, sel, U, rows, H, W, h, 0.3))
+        t0 = timed(lambda: D.resconv_pooled_grad(gy, sel, U, rows, H, W))
+        act = torch.randint(0, 16, (B, rows, (H + 1) // 2, (W + 1) // 2), dtype=torch.uint8, device=dev)
+        ta = timed(lambda: D.resconv_pooled_grad(gy, sel, U, rows, H, W, None, 0.3, act=act))
+        gflop = 2 * 9 * K * rows * B * H * W / 1e9
+        mb = (K * (H // 2) * (W // 2) * 5 + 2 * rows * H * W * 4) * B / 1e6
+        print(f"pooled  {name} K {K:3d} -> {rows:3d} {H}x{W}  {t:7.1f} us ({gflop / t * 1e3:6.1f} TF/s direct-equivalent, "
+              f"{mb / t * 1e3:6.0f} GB/s)   from sign bytes {ta:7.1f} us   without lrelu' {t0:7.1f} us", flush=True)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[2] == "pooled":
+        pooled(int(sys.argv[1]))
+        resconv(int(sys.argv[1]))
+        sys.exit(0)
     main()
+    pooled(int(sys.argv[1]) if len(sys.argv) > 1 else 128)
     resconv(int(sys.argv[1]) if len(sys.argv) > 1 else 128)
     direct(int(sys.argv[1]) if len(sys.argv) > 1 else 128)
