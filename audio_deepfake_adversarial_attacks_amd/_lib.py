@@ -132,6 +132,8 @@ SIGNATURES = {
     "advstep_gate_fc_backward_f32": (ctypes.c_int, [_p, _i64, _p, _p, _f32, _p, _i64, _i64, _p]),
     "advstep_gate_maxpool2_blocks": (_sz, [_i64, _i64]),
     "advstep_gate_maxpool2_forward_f32": (ctypes.c_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _p]),
+    "advstep_gate_maxpool2_forward_xw_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p]),
+    "advstep_gate_maxpool2_backward_gate_pooled_f32": (ctypes.c_int, [_p, _p, _p, _i64, _i64, _i64, _i64, _p]),
     "advstep_gate_maxpool2_backward_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p]),
 }
 

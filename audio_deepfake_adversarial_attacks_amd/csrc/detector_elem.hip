@@ -261,7 +261,7 @@ template <int KIND>
 __global__ __launch_bounds__(kBlock) void pool2_forward_kernel(const float *__restrict__ a, const float *__restrict__ b,
                                                                const float *__restrict__ bias, const float *__restrict__ gate,
                                                                float *__restrict__ y, uint8_t *__restrict__ sel, int64_t C,
-                                                               int H, int W) {
+                                                               int H, int W, float *__restrict__ xw) {
     const int64_t nc = blockIdx.x;
     const int Ho = H >> 1, Wo = W >> 1, Wp = (Wo + 1) >> 1;      // Wp pairs of pooled outputs per row
     const int64_t idx = (int64_t)blockIdx.y * kBlock + threadIdx.x;
@@ -290,8 +290,10 @@ __global__ __launch_bounds__(kBlock) void pool2_forward_kernel(const float *__re
             r1[e] = in ? ap[W + e] + (bp ? bp[W + e] : 0.0f) : 0.0f;
         }
     }
+    float raw[KIND == 1 ? 8 : 1];                                 // KIND 1: the un-gated inputs, for `xw`
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
+        if (KIND == 1) { raw[e] = r0[e]; raw[4 + e] = r1[e]; }
         if (KIND == 0) { r0[e] += add; r1[e] += add; }
         else { r0[e] = r0[e] * mul + add; r1[e] = r1[e] * mul + add; }
     }
@@ -304,6 +306,29 @@ __global__ __launch_bounds__(kBlock) void pool2_forward_kernel(const float *__re
         y[o + 1] = v1;
         sel[o + 1] = (uint8_t)c1;
     }
+    if (KIND == 1 && xw) {
+        // the winner's un-gated input: all the gate's gradient needs of x (sum gy * (x_winner + 1)), at a quarter of x's size
+        const float w0 = c0 == 0 ? raw[0] : c0 == 1 ? raw[1] : c0 == 2 ? raw[4] : raw[5];
+        const float w1 = c1 == 0 ? raw[2] : c1 == 1 ? raw[3] : c1 == 2 ? raw[6] : raw[7];
+        xw[o] = w0;
+        if (two) xw[o + 1] = w1;
+    }
+}
+
+// ggate[row] = sum_j gy[row][j] * (xw[row][j] + 1) over one pooled plane per workgroup, fixed order (thread-strided partial sums,
+// wave butterfly, the 4 wave sums in index order)
+__global__ __launch_bounds__(kBlock) void gate_grad_pooled_kernel(const float *__restrict__ gy, const float *__restrict__ xw,
+                                                                  float *__restrict__ ggate, int64_t L) {
+    const int64_t row = blockIdx.x;
+    const float *a = gy + row * L, *b = xw + row * L;
+    float acc = 0.0f;
+    for (int64_t j = threadIdx.x; j < L; j += kBlock) acc += a[j] * (b[j] + 1.0f);
+    __shared__ float ws[kBlock / 64];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) ggate[row] = ((ws[0] + ws[1]) + ws[2]) + ws[3];
 }
 
 // thread = one input row segment of 4 floats (2 pooled outputs); writes the full-resolution gradient incl. odd tails
@@ -664,7 +689,7 @@ int advstep_add_maxpool2_forward_f32(const float *a, const float *b, const float
     if (!a || !y || !sel) return ADVSTEP_EINVAL;
     const dim3 grid((unsigned)(N * C), (unsigned)ceil_div(Ho * ((Wo + 1) / 2), kBlock)), block(kBlock);
     hipLaunchKernelGGL(pool2_forward_kernel<0>, grid, block, 0, as_stream(stream), a, b, bias, (const float *)nullptr, y, sel, C,
-                       (int)H, (int)W);
+                       (int)H, (int)W, (float *)nullptr);
     return status_after_launch();
 }
 
@@ -816,15 +841,30 @@ size_t advstep_gate_maxpool2_blocks(int64_t H, int64_t W) {
     return (size_t)ceil_div(H * ((W + 3) / 4), kBlock);
 }
 
-int advstep_gate_maxpool2_forward_f32(const float *x, const float *gate, float *y, uint8_t *sel, int64_t N, int64_t C,
-                                      int64_t H, int64_t W, advstep_stream_t stream) {
+int advstep_gate_maxpool2_forward_xw_f32(const float *x, const float *gate, float *y, uint8_t *sel, float *xw, int64_t N,
+                                         int64_t C, int64_t H, int64_t W, advstep_stream_t stream) {
     if (!pool_dims_ok(N, C, H, W)) return ADVSTEP_EINVAL;
     const int64_t Ho = H / 2, Wo = W / 2;
     if (N * C * Ho * Wo == 0) return ADVSTEP_OK;
     if (!x || !gate || !y || !sel) return ADVSTEP_EINVAL;
     const dim3 grid((unsigned)(N * C), (unsigned)ceil_div(Ho * ((Wo + 1) / 2), kBlock)), block(kBlock);
     hipLaunchKernelGGL(pool2_forward_kernel<1>, grid, block, 0, as_stream(stream), x, (const float *)nullptr,
-                       (const float *)nullptr, gate, y, sel, C, (int)H, (int)W);
+                       (const float *)nullptr, gate, y, sel, C, (int)H, (int)W, xw);
+    return status_after_launch();
+}
+
+int advstep_gate_maxpool2_forward_f32(const float *x, const float *gate, float *y, uint8_t *sel, int64_t N, int64_t C,
+                                      int64_t H, int64_t W, advstep_stream_t stream) {
+    return advstep_gate_maxpool2_forward_xw_f32(x, gate, y, sel, nullptr, N, C, H, W, stream);
+}
+
+int advstep_gate_maxpool2_backward_gate_pooled_f32(const float *gy, const float *xw, float *ggate, int64_t N, int64_t C, int64_t H,
+                                                   int64_t W, advstep_stream_t stream) {
+    if (!pool_dims_ok(N, C, H, W)) return ADVSTEP_EINVAL;
+    if (N * C == 0) return ADVSTEP_OK;
+    const int64_t L = (H / 2) * (W / 2);
+    if (!ggate || (L > 0 && (!gy || !xw))) return ADVSTEP_EINVAL;
+    hipLaunchKernelGGL(gate_grad_pooled_kernel, dim3((unsigned)(N * C)), dim3(kBlock), 0, as_stream(stream), gy, xw, ggate, L);
     return status_after_launch();
 }
 

@@ -405,6 +405,11 @@ class _GateMaxPool2(torch.autograd.Function):
         return gx, partial.sum(dim=1).view_as(gate)
 
 
+def _attend_xw_enabled() -> bool:
+    import os
+    return os.environ.get("ADVSTEP_ATTEND_XW", "1") != "0"
+
+
 class _AttendPool(torch.autograd.Function):
     """MaxPool2d(2)(x * g + g), g = sigmoid(fc(mean_hw x)) — SpecRNet's attention + pooling after a block (specrnet.py:145-149,
     163-172) with a frozen fc; input gradient only.  Backward: the gate's partial sums, sigmoid' and fc^T on (N, C), then ONE
@@ -427,23 +432,35 @@ class _AttendPool(torch.autograd.Function):
             gate = torch.sigmoid(torch.addmm(bias, mean, weight.t()) if bias is not None else mean @ weight.t()).contiguous()
         y = torch.empty((N, C, H // 2, W // 2), dtype=x.dtype, device=x.device)
         sel = torch.empty(max(y.numel(), 1), dtype=torch.uint8, device=x.device)
-        st = _lib.load().advstep_gate_maxpool2_forward_f32(x.data_ptr(), gate.data_ptr(), y.data_ptr(), sel.data_ptr(), N, C, H, W,
-                                                           _stream(x.device))
-        _lib.check(st, "advstep_gate_maxpool2_forward_f32")
-        ctx.save_for_backward(x, sel, gate, weight)
+        # the gate's gradient needs x only at the pooling winners: the forward writes them next to y (pooled size) and x itself
+        # is not kept for backward (ADVSTEP_ATTEND_XW=0: gather them out of x in backward, A/B)
+        compact = _attend_xw_enabled()
+        xw = torch.empty_like(y) if compact else None
+        st = _lib.load().advstep_gate_maxpool2_forward_xw_f32(x.data_ptr(), gate.data_ptr(), y.data_ptr(), sel.data_ptr(),
+                                                              None if xw is None else xw.data_ptr(), N, C, H, W, _stream(x.device))
+        _lib.check(st, "advstep_gate_maxpool2_forward_xw_f32")
+        ctx.compact, ctx.shape = compact, (N, C, H, W)
+        ctx.save_for_backward(xw if compact else x, sel, gate, weight)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x, sel, gate, weight = ctx.saved_tensors
-        N, C, H, W = x.shape
+        N, C, H, W = ctx.shape
         gy = gy.contiguous()
         lib = _lib.load()
-        blocks = max(lib.advstep_gate_maxpool2_blocks(H, W), 1)
-        partial = torch.empty((N * C, blocks), dtype=x.dtype, device=x.device)
-        st = lib.advstep_gate_maxpool2_backward_gate_f32(gy.data_ptr(), sel.data_ptr(), x.data_ptr(), partial.data_ptr(), N, C, H, W,
-                                                         _stream(x.device))
-        _lib.check(st, "advstep_gate_maxpool2_backward_gate_f32")
+        if ctx.compact:
+            blocks = 1
+            partial = torch.empty((N * C, 1), dtype=gy.dtype, device=gy.device)
+            st = lib.advstep_gate_maxpool2_backward_gate_pooled_f32(gy.data_ptr(), x.data_ptr(), partial.data_ptr(), N, C, H, W,
+                                                                    _stream(gy.device))
+            _lib.check(st, "advstep_gate_maxpool2_backward_gate_pooled_f32")
+        else:
+            blocks = max(lib.advstep_gate_maxpool2_blocks(H, W), 1)
+            partial = torch.empty((N * C, blocks), dtype=x.dtype, device=x.device)
+            st = lib.advstep_gate_maxpool2_backward_gate_f32(gy.data_ptr(), sel.data_ptr(), x.data_ptr(), partial.data_ptr(), N, C, H,
+                                                             W, _stream(x.device))
+            _lib.check(st, "advstep_gate_maxpool2_backward_gate_f32")
         if C <= 256 and tuple(weight.shape) == (C, C) and weight.is_contiguous():
             g_mean = torch.empty((N, C), dtype=x.dtype, device=x.device)
             st = lib.advstep_gate_fc_backward_f32(partial.data_ptr(), blocks, gate.data_ptr(), weight.data_ptr(), 1.0 / float(H * W),
@@ -452,7 +469,7 @@ class _AttendPool(torch.autograd.Function):
         else:
             ggate = partial.sum(dim=1).view(N, C)
             g_mean = (((ggate * gate * (1.0 - gate)) @ weight) / float(H * W)).contiguous()
-        gx = torch.empty_like(x)
+        gx = torch.empty((N, C, H, W), dtype=gy.dtype, device=gy.device)
         st = lib.advstep_gate_maxpool2_backward_input_f32(gy.data_ptr(), sel.data_ptr(), gate.data_ptr(), g_mean.data_ptr(),
                                                           gx.data_ptr(), N, C, H, W, _stream(x.device))
         _lib.check(st, "advstep_gate_maxpool2_backward_input_f32")

@@ -134,6 +134,13 @@ int advstep_gate_maxpool2_forward_f32(const float *x, const float *gate, float *
 int advstep_gate_maxpool2_backward_f32(const float *gy, const uint8_t *sel, const float *x, const float *gate, float *gx,
                                        float *ggate_partial, int64_t N, int64_t C, int64_t H, int64_t W,
                                        advstep_stream_t stream);
+/* The forward that also writes xw (N, C, H/2, W/2) = the winner's UN-gated input (may be NULL), and the gate's gradient from it:
+ * ggate (N * C) = sum over the pooled plane of gy * (xw + 1), fixed order — reads two pooled-size tensors instead of gathering
+ * the winners out of x (a quarter of the bytes; x need not be kept for backward). */
+int advstep_gate_maxpool2_forward_xw_f32(const float *x, const float *gate, float *y, uint8_t *sel, float *xw, int64_t N,
+                                         int64_t C, int64_t H, int64_t W, advstep_stream_t stream);
+int advstep_gate_maxpool2_backward_gate_pooled_f32(const float *gy, const float *xw, float *ggate, int64_t N, int64_t C, int64_t H,
+                                                   int64_t W, advstep_stream_t stream);
 
 /* ---- 3x3 convolutions of SpecRNet's residual blocks on the fp32 matrix cores (csrc/lcnn_wino.hip) ------------------------
  * Replaces the ATen / MIOpen calls behind `Residual_block2D.forward` (src/models/specrnet.py:73-91: conv1 -> bn2 -> lrelu ->
