@@ -445,33 +445,33 @@ class _AttendPool(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy):
-        x, sel, gate, weight = ctx.saved_tensors
+        kept, sel, gate, weight = ctx.saved_tensors          # kept: the pooling winners xw (compact) or x itself
         N, C, H, W = ctx.shape
         gy = gy.contiguous()
-        lib = _lib.load()
+        dev, lib = gy.device, _lib.load()
         if ctx.compact:
             blocks = 1
-            partial = torch.empty((N * C, 1), dtype=gy.dtype, device=gy.device)
-            st = lib.advstep_gate_maxpool2_backward_gate_pooled_f32(gy.data_ptr(), x.data_ptr(), partial.data_ptr(), N, C, H, W,
-                                                                    _stream(gy.device))
+            partial = torch.empty((N * C, 1), dtype=gy.dtype, device=dev)
+            st = lib.advstep_gate_maxpool2_backward_gate_pooled_f32(gy.data_ptr(), kept.data_ptr(), partial.data_ptr(), N, C, H, W,
+                                                                    _stream(dev))
             _lib.check(st, "advstep_gate_maxpool2_backward_gate_pooled_f32")
         else:
             blocks = max(lib.advstep_gate_maxpool2_blocks(H, W), 1)
-            partial = torch.empty((N * C, blocks), dtype=x.dtype, device=x.device)
-            st = lib.advstep_gate_maxpool2_backward_gate_f32(gy.data_ptr(), sel.data_ptr(), x.data_ptr(), partial.data_ptr(), N, C, H,
-                                                             W, _stream(x.device))
+            partial = torch.empty((N * C, blocks), dtype=gy.dtype, device=dev)
+            st = lib.advstep_gate_maxpool2_backward_gate_f32(gy.data_ptr(), sel.data_ptr(), kept.data_ptr(), partial.data_ptr(), N, C,
+                                                             H, W, _stream(dev))
             _lib.check(st, "advstep_gate_maxpool2_backward_gate_f32")
         if C <= 256 and tuple(weight.shape) == (C, C) and weight.is_contiguous():
-            g_mean = torch.empty((N, C), dtype=x.dtype, device=x.device)
+            g_mean = torch.empty((N, C), dtype=gy.dtype, device=dev)
             st = lib.advstep_gate_fc_backward_f32(partial.data_ptr(), blocks, gate.data_ptr(), weight.data_ptr(), 1.0 / float(H * W),
-                                                  g_mean.data_ptr(), N, C, _stream(x.device))
+                                                  g_mean.data_ptr(), N, C, _stream(dev))
             _lib.check(st, "advstep_gate_fc_backward_f32")
         else:
             ggate = partial.sum(dim=1).view(N, C)
             g_mean = (((ggate * gate * (1.0 - gate)) @ weight) / float(H * W)).contiguous()
-        gx = torch.empty((N, C, H, W), dtype=gy.dtype, device=gy.device)
+        gx = torch.empty((N, C, H, W), dtype=gy.dtype, device=dev)
         st = lib.advstep_gate_maxpool2_backward_input_f32(gy.data_ptr(), sel.data_ptr(), gate.data_ptr(), g_mean.data_ptr(),
-                                                          gx.data_ptr(), N, C, H, W, _stream(x.device))
+                                                          gx.data_ptr(), N, C, H, W, _stream(dev))
         _lib.check(st, "advstep_gate_maxpool2_backward_input_f32")
         return gx, None, None
 
@@ -732,15 +732,15 @@ class _ResBlock(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         p = ctx.plan
-        x, h1, sel = ctx.saved_tensors
+        x, kept, sel = ctx.saved_tensors                     # kept: h1's sign bytes (compact) or h1 itself
         N, _, H, W = x.shape
         gy = gy.contiguous()
         lib = _lib.load()
         # d(conv1 out) / bn2 scale = conv2^T(unpool(gy)) * lrelu'(h1): unpooling in the operand load, lrelu' in the epilogue
         if ctx.compact:
-            g_pre = resconv_pooled_grad(gy, sel, p.U2T, p.cout, H, W, None, p.slope, act=h1)
+            g_pre = resconv_pooled_grad(gy, sel, p.U2T, p.cout, H, W, None, p.slope, act=kept)
         else:
-            g_pre = resconv_pooled_grad(gy, sel, p.U2T, p.cout, H, W, h1, p.slope)
+            g_pre = resconv_pooled_grad(gy, sel, p.U2T, p.cout, H, W, kept, p.slope)
         if p.fewin:
             return conv3x3_fewout_grad(g_pre, p.w1_scaled, gy, sel, p.wd), None
         g_h2 = torch.empty((N, p.cout, H, W), dtype=gy.dtype, device=gy.device)       # the identity path's gradient
