@@ -93,6 +93,7 @@ SIGNATURES = {
     "advstep_conv3x3_fewin_supported": (ctypes.c_int, [_i64]),
     "advstep_conv3x3_fewin_forward_f32": (ctypes.c_int, [_p, _p, _p, ctypes.c_float, _p, _i64, _i64, _i64, _i64, _i64, _p]),
     "advstep_conv3x3_fewout_grad_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p]),
+    "advstep_resconv_pool2_forward_few_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _p]),
     "advstep_resconv_pool2_forward_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _p]),
     # include/advstep_frontend.h
     "advstep_lfcc_block_count": (_sz, [_i64, _i64, _i64]),

@@ -233,6 +233,10 @@ __global__ void wino_prepare_plain_kernel(const float *__restrict__ w3, const fl
 // EPI 6: the same from the activation's SIGN BYTES passed in `idx` (read only): one byte per (n, channel, 2x2 tile), bit 2 i + j =
 //        h > 0 at tile position (i, j), (N, Cout, TH, TW) — what EPI 3 writes next to h when it is given an `idx` to fill.  At
 //        SpecRNet's first block that is 21 MB in the epilogue instead of 331 MB of h: 476 -> 3xx us (round 3).
+// EPI 7: EPI 4 plus a 1x1 convolution over the ga.few (1 or 2) channels of ga.x2 added to the convolution output on the vector
+//        ALUs before the pool, weights (Cout, few) in `bn_mean`: SpecRNet's block0, whose downsample convolution has two input
+//        channels — as part of the reduction (GEN's x2) those two channels cost a whole k-step of six, 32 matrix instructions per
+//        wave and tile group for 8 useful rows of K; here they are 64 fused multiply-adds per lane.
 // NT: accumulator tiles a wave computes — 2, or 1 for a convolution's LAST slice when only its first 16 rows exist
 //     (Cout % 32 in 1..16, LCNN's 128 -> 48 input gradient): that slice is launched on its own with half the matrix
 //     instructions instead of multiplying 16 zero rows.  slice0: first slice of this launch.
@@ -245,6 +249,7 @@ struct GenArgs {
     int K1, Kreal;
     float slope;
     int xcd;          // 1: workgroups b, b + 8, b + 16, ... (one XCD, one L2) take the slices of the same tile ranges
+    int few;          // EPI 7: channels of x2 (1 or 2) whose 1x1 convolution is added in the epilogue
 };
 
 // WODD (SRC 0): the plane width is odd, so the last tile of a row has no second column and its pair load's second element must
@@ -303,8 +308,13 @@ __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restri
     // per-channel shift), EPI 3's shift, EPI 4's bias; cst[32..47] = the BatchNorm's 1 / std (EPI 1 / 2).  The additive part
     // enters through the matrix instruction's C operand: position (1, 1) of M reaches all four outputs of A^T M A with weight
     // +1, so its accumulator starts at the constant instead of 0 and the epilogue has no bias adds.
-    constexpr bool kHasConst = EPI == 1 || EPI == 2 || EPI == 3 || EPI == 4;
+    constexpr bool kHasConst = EPI == 1 || EPI == 2 || EPI == 3 || EPI == 4 || EPI == 7;
     __shared__ __attribute__((aligned(16))) float cst[48];
+    __shared__ float few_w[EPI == 7 ? 64 : 1];               // EPI 7: the 1x1 weights of this slice's 32 rows, [row][channel]
+    if (EPI == 7 && threadIdx.x >= 64 && threadIdx.x < 128) {
+        const int i = threadIdx.x - 64, row = i >> 1, c = i & 1, ch = slice * 32 + row;
+        few_w[i] = (ch < Cout && c < ga.few) ? bn_mean[ch * ga.few + c] : 0.0f;
+    }
     if (kHasConst && threadIdx.x < 48) {
         const int q = threadIdx.x >> 4, j = threadIdx.x & 15;
         float v = q == 2 ? 1.0f : 0.0f;
@@ -626,6 +636,22 @@ __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restri
                     hb6[r][m] = live ? idx[(((size_t)n * Cout + ch) * TH + th) * TW + tw] : 0u;
                 }
         }
+        float xf[EPI == 7 ? 2 : 1][2][2];       // EPI 7: x2 at the tile's 2x2 positions, requested before the output transform
+        if constexpr (EPI == 7) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                xf[c][0][0] = xf[c][0][1] = xf[c][1][0] = xf[c][1][1] = 0.0f;
+                if (valid && c < ga.few && th < (H >> 1) && tw < (W >> 1)) {     // pooled outputs only: both rows / columns exist
+                    const float *xp = ga.x2 + (((size_t)n * ga.few + c) * H + 2 * th) * W + 2 * tw;
+                    if ((W & 1) == 0) {
+                        const f32x2 a = *reinterpret_cast<const f32x2 *>(xp), b2 = *reinterpret_cast<const f32x2 *>(xp + W);
+                        xf[c][0][0] = a.x, xf[c][0][1] = a.y, xf[c][1][0] = b2.x, xf[c][1][1] = b2.y;
+                    } else {
+                        xf[c][0][0] = xp[0], xf[c][0][1] = xp[1], xf[c][1][0] = xp[W], xf[c][1][1] = xp[W + 1];
+                    }
+                }
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float yy[2][2][2];
@@ -682,11 +708,17 @@ __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restri
                     }
                     idx[((size_t)n * Cout + ch) * TH * TW + (size_t)th * TW + tw] = (uint8_t)bits;
                 }
-            } else if (EPI == 4) {
+            } else if (EPI == 4 || EPI == 7) {
 #pragma unroll
                 for (int m = 0; m < NT; ++m) {
                     const int ch = slice * 32 + m * 16 + 4 * g + r;
                     const bool live = ch < Cout;
+                    if (EPI == 7) {
+                        const float w0 = few_w[(m * 16 + 4 * g + r) * 2], w1 = few_w[(m * 16 + 4 * g + r) * 2 + 1];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            yy[m][e >> 1][e & 1] = fmaf(w1, xf[1][e >> 1][e & 1], fmaf(w0, xf[0][e >> 1][e & 1], yy[m][e >> 1][e & 1]));
+                    }
                     float best = -INFINITY;
                     int code = 0;
 #pragma unroll
@@ -777,7 +809,7 @@ inline bool half_slice_enabled() {
 template <int EPI, int SRC, bool GEN = false>
 int launch_wino(const float *x, const uint8_t *xsel, const float *U, const float *bias, const float *bn_mean,
                 const float *bn_invstd, float *y, uint8_t *idx, int64_t N, int64_t K, int64_t H, int64_t W, int64_t Cout,
-                int slices, hipStream_t st, GenArgs ga = GenArgs{nullptr, 0, 0, 1.0f, 0}) {
+                int slices, hipStream_t st, GenArgs ga = GenArgs{nullptr, 0, 0, 1.0f, 0, 0}) {
     const int cus = 256;
     const int chunks = (int)ceil_div(K, kChunkCin);
     const bool stream = chunks > kMaxResident;
@@ -953,7 +985,7 @@ int advstep_resconv_forward_act_f32(const float *x1, const float *x2, const floa
     if (const int st = resconv_check(x1, x2, U, y, N, K1, K2, rows, H, W)) return st;
     const int64_t K = (K1 + K2 <= 8) ? 8 : ceil_div(K1 + K2, 4) * 4;      // at least two k-steps; an odd count is fine
     return launch_wino<3, 0, true>(x1, nullptr, U, shift, nullptr, nullptr, y, act, N, K, H, W, rows, (int)ceil_div(rows, 32),
-                                   as_stream(stream), GenArgs{x2, (int)K1, (int)(K1 + K2), slope, 0});
+                                   as_stream(stream), GenArgs{x2, (int)K1, (int)(K1 + K2), slope, 0, 0});
 }
 
 int advstep_resconv_forward_f32(const float *x1, const float *x2, const float *U, const float *shift, float slope, float *y,
@@ -971,7 +1003,7 @@ int advstep_resconv_pool2_forward_f32(const float *x1, const float *x2, const fl
     if (const int st = resconv_check(x1, x2, U, y, N, K1, K2, rows, H, W)) return st;
     const int64_t K = (K1 + K2 <= 8) ? 8 : ceil_div(K1 + K2, 4) * 4;      // at least two k-steps; an odd count is fine
     return launch_wino<4, 0, true>(x1, nullptr, U, bias, nullptr, nullptr, y, sel, N, K, H, W, rows, (int)ceil_div(rows, 32),
-                                   as_stream(stream), GenArgs{x2, (int)K1, (int)(K1 + K2), 1.0f, 0});
+                                   as_stream(stream), GenArgs{x2, (int)K1, (int)(K1 + K2), 1.0f, 0, 0});
 }
 
 static int pooled_grad(const float *gy, const uint8_t *sel, const float *U, const float *h, const uint8_t *act, float slope,
@@ -986,7 +1018,7 @@ static int pooled_grad(const float *gy, const uint8_t *sel, const float *U, cons
     WINO_REQUIRE((uint64_t)N * K * (H / 2) * (W / 2) < (1ull << 29) && (uint64_t)N * rows * H * W * 4 < (1ull << 33) &&
                  (uint64_t)N * ((H + 1) / 2) * ((W + 1) / 2) < (1ull << 31));
     const int64_t Kp = K <= 8 ? 8 : ceil_div(K, 4) * 4;
-    const GenArgs ga{nullptr, (int)K, (int)K, slope, 0};
+    const GenArgs ga{nullptr, (int)K, (int)K, slope, 0, 0};
     if (act)
         return launch_wino<6, 2, true>(gy, sel, U, nullptr, nullptr, nullptr, g, const_cast<uint8_t *>(act), N, Kp, H, W, rows,
                                        (int)ceil_div(rows, 32), as_stream(stream), ga);
@@ -995,6 +1027,18 @@ static int pooled_grad(const float *gy, const uint8_t *sel, const float *U, cons
                                        as_stream(stream), ga);
     return launch_wino<0, 2, true>(gy, sel, U, nullptr, nullptr, nullptr, g, nullptr, N, Kp, H, W, rows, (int)ceil_div(rows, 32),
                                    as_stream(stream), ga);
+}
+
+int advstep_resconv_pool2_forward_few_f32(const float *x1, const float *x2, const float *U, const float *wd, const float *bias,
+                                          float *y, uint8_t *sel, int64_t N, int64_t K1, int64_t K2, int64_t rows, int64_t H,
+                                          int64_t W, advstep_stream_t stream) {
+    WINO_REQUIRE(N >= 0 && H >= 0 && W >= 0 && (K2 == 1 || K2 == 2) && advstep_resconv_supported(K1, 0, rows));
+    if (N == 0 || H / 2 == 0 || W / 2 == 0) return ADVSTEP_OK;
+    WINO_REQUIRE(sel && x2 && wd);
+    if (const int st = resconv_check(x1, nullptr, U, y, N, K1, 0, rows, H, W)) return st;
+    const int64_t K = K1 <= 8 ? 8 : ceil_div(K1, 4) * 4;
+    return launch_wino<7, 0, true>(x1, nullptr, U, bias, wd, nullptr, y, sel, N, K, H, W, rows, (int)ceil_div(rows, 32),
+                                   as_stream(stream), GenArgs{x2, (int)K1, (int)K1, 1.0f, 0, (int)K2});
 }
 
 int advstep_resconv_pooled_grad_f32(const float *gy, const uint8_t *sel, const float *U, const float *h, float slope, float *g,

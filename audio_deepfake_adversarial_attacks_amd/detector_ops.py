@@ -559,6 +559,25 @@ def resconv_pool2(x1: torch.Tensor, x2: Optional[torch.Tensor], U: torch.Tensor,
     return y, sel
 
 
+def resconv_pool2_few(x1: torch.Tensor, x2: torch.Tensor, U: torch.Tensor, wd: torch.Tensor, rows: int,
+                      bias: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(MaxPool2d(2)(conv3x3(x1) + conv1x1(x2; wd) + bias[row]), selection bytes) for an x2 of 1-2 channels: U prepared from the
+    3x3 weights alone, the 1x1 part wd (rows, K2) applied in the kernel's epilogue — no autograd (building block)."""
+    _require(x1, "x1"), _require(x2, "x2"), _require(wd, "wd")
+    N, K1, H, W = x1.shape
+    K2 = x2.shape[1]
+    if K2 not in (1, 2) or x2.shape[0] != N or tuple(x2.shape[2:]) != (H, W) or tuple(wd.shape) != (rows, K2) or not wd.is_contiguous():
+        raise ValueError("x2 must be (N, 1-2, H, W) and wd a contiguous (rows, K2)")
+    y = torch.empty((N, rows, H // 2, W // 2), dtype=x1.dtype, device=x1.device)
+    sel = torch.empty(max(y.numel(), 1), dtype=torch.uint8, device=x1.device)
+    with _Launch("resconv_pool2_forward", x1.device, work=8.0 * N * rows * K1 * H * W):
+        st = _lib.load().advstep_resconv_pool2_forward_few_f32(x1.data_ptr(), x2.data_ptr(), U.data_ptr(), wd.data_ptr(),
+                                                               None if bias is None else bias.data_ptr(), y.data_ptr(),
+                                                               sel.data_ptr(), N, K1, K2, rows, H, W, _stream(x1.device))
+    _lib.check(st, "advstep_resconv_pool2_forward_few_f32")
+    return y, sel
+
+
 def resconv_pooled_grad(gy: torch.Tensor, sel: torch.Tensor, U: torch.Tensor, rows: int, H: int, W: int,
                         h: Optional[torch.Tensor] = None, slope: float = 1.0, act: Optional[torch.Tensor] = None) -> torch.Tensor:
     """conv3x3(unpool(gy, sel)) [* leaky_relu'(h)] with U prepared with transpose=True: the input gradient of a convolution whose
@@ -657,7 +676,10 @@ class ResBlockPlan:
             self.w1_scaled = (w1 * self.scale.view(-1, 1, 1, 1)).contiguous() if self.fewin else None
             self.wd = wd
             self.U1 = None if self.fewin else resconv_prepare(w1, rscale=self.scale)
-            self.U2 = resconv_prepare(w2, wd)
+            # block0 (1-2 input channels): the downsample's channels would pad a whole k-step of conv2's reduction — they are
+            # applied in the kernel's epilogue instead (ADVSTEP_RESBLOCK_FEW=0: as reduction channels)
+            self.few = self.fewin and _few_epilogue_enabled()
+            self.U2 = resconv_prepare(w2, None if self.few else wd)
             # input gradients: d h1 from d h2; d x from d(conv1 out) [+ d h2 through the downsample]
             self.U2T = resconv_prepare(w2, transpose=True)
             self.U1T = None if self.fewin else resconv_prepare(w1, wd, kscale=self.scale, transpose=True)
@@ -692,10 +714,16 @@ def res_block_shape_supported(x_shape, cout: int) -> bool:
 
 def res_block_plan(block, conv1, bn2, conv2, down, slope: float) -> ResBlockPlan:
     tensors = [t for m in (conv1, bn2, conv2, down) if m is not None for t in list(m.parameters()) + list(m.buffers())]
-    key = tuple((t.data_ptr(), t._version) for t in tensors)
+    key = tuple((t.data_ptr(), t._version) for t in tensors) + (_few_epilogue_enabled(),)
     if getattr(block, "_advstep_plan_key", None) != key:
         block._advstep_plan_key, block._advstep_plan = key, ResBlockPlan(conv1, bn2, conv2, down, slope)
     return block._advstep_plan
+
+
+def _few_epilogue_enabled() -> bool:
+    """ADVSTEP_RESBLOCK_FEW=0 (read when a block's plan is built): block0's downsample as reduction channels (A/B measurements)."""
+    import os
+    return os.environ.get("ADVSTEP_RESBLOCK_FEW", "1") != "0"
 
 
 def _act_bytes_enabled() -> bool:
@@ -721,7 +749,9 @@ class _ResBlock(torch.autograd.Function):
         else:
             h1 = resconv(x, None, p.U1, p.cout, p.shift, p.slope, with_act=compact)
         h1, act = h1 if compact else (h1, None)
-        if p.downsample:
+        if p.downsample and p.few:
+            y, sel = resconv_pool2_few(h1, x, p.U2, p.wd, p.cout, p.bias)
+        elif p.downsample:
             y, sel = resconv_pool2(h1, x, p.U2, p.cout, p.bias)
         else:
             y, sel = _add_maxpool2_raw(resconv(h1, None, p.U2, p.cout), x, p.bias)

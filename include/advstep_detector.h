@@ -173,6 +173,13 @@ int advstep_resconv_forward_act_f32(const float *x1, const float *x2, const floa
 int advstep_resconv_pool2_forward_f32(const float *x1, const float *x2, const float *U, const float *bias, float *y,
                                       uint8_t *sel, int64_t N, int64_t K1, int64_t K2, int64_t rows, int64_t H, int64_t W,
                                       advstep_stream_t stream);
+/* The same with the 1x1 part over FEW channels (K2 = 1 or 2: the downsample convolution of SpecRNet's first block, whose input
+ * is the 1- or 2-channel spectrogram): U is prepared from the 3x3 weights alone (K2 = 0) and the 1x1 weights wd (rows, K2) are
+ * applied in the epilogue on the vector ALUs — as reduction channels they would pad a whole k-step (4 channels) of matrix
+ * instructions.  Sums in another order than advstep_resconv_pool2_forward_f32 (fp32 rounding differences only). */
+int advstep_resconv_pool2_forward_few_f32(const float *x1, const float *x2, const float *U, const float *wd, const float *bias,
+                                          float *y, uint8_t *sel, int64_t N, int64_t K1, int64_t K2, int64_t rows, int64_t H,
+                                          int64_t W, advstep_stream_t stream);
 
 /* g (N, rows, H, W) = conv3x3(unpool(gy, sel)) [* (h > 0 ? 1 : slope)]: the input gradient of a convolution whose OUTPUT went
  * through MaxPool2d(2), from the pooled gradient gy (N, K, H/2, W/2) and the selection bytes — the full-resolution

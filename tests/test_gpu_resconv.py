@@ -234,6 +234,37 @@ def test_residual_block_matches_plain_modules(D, cuda, monkeypatch, parity_recor
     assert fig["grad_rel_l2"] <= 2e-3, fig
 
 
+@pytest.mark.parametrize("shape", [(2, 20, 2, 20, 16, 24), (2, 20, 1, 20, 7, 9), (1, 20, 2, 20, 80, 404), (2, 8, 2, 5, 6, 10), (1, 64, 1, 33, 5, 25),
+                                   (2, 20, 2, 20, 1, 6)])
+def test_few_channel_downsample_in_the_epilogue_matches_the_reference(D, cuda, shape):
+    """advstep_resconv_pool2_forward_few_f32: the 1x1 convolution over 1-2 channels applied in the epilogue (vector ALUs) instead of
+    as reduction channels — same pooled values to REL of the convolution's scale, same selections away from near ties, and the same
+    values as the all-matrix form (advstep_resconv_pool2_forward_f32) to fp32 rounding."""
+    N, K1, K2, R, H, W = shape
+    x1, w3 = rnd((N, K1, H, W), 1, cuda), rnd((R, K1, 3, 3), 2, cuda, 0.2)
+    x2, w1 = rnd((N, K2, H, W), 3, cuda), rnd((R, K2), 4, cuda, 0.3)
+    bias = rnd((R,), 5, cuda)
+    y, sel = D.resconv_pool2_few(x1, x2, D.resconv_prepare(w3), w1.contiguous(), R, bias)
+    Ho, Wo = H // 2, W // 2
+    assert y.shape == (N, R, Ho, Wo)
+    if Ho * Wo == 0:
+        return
+    full = reference(x1, x2, w3, w1, bias, 1.0)
+    ref, ref_idx = F.max_pool2d(full, 2, return_indices=True)
+    tol = REL * full.abs().max().item()
+    assert (y.double() - ref).abs().max().item() <= tol
+    win = full[:, :, :2 * Ho, :2 * Wo].reshape(N, R, Ho, 2, Wo, 2).permute(0, 1, 2, 4, 3, 5).reshape(N, R, Ho, Wo, 4)
+    top = win.topk(2, dim=-1).values
+    clear = (top[..., 0] - top[..., 1]) > 2 * tol
+    ref_code = (((ref_idx // W) % 2) * 2 + (ref_idx % W) % 2).to(torch.uint8)
+    got = sel[:N * R * Ho * Wo].view(N, R, Ho, Wo)
+    assert torch.equal(got[clear], ref_code[clear]) and (got < 4).all()
+    y_all, _ = D.resconv_pool2(x1, x2, D.resconv_prepare(w3, w1), R, bias)
+    assert (y - y_all).abs().max().item() <= tol
+    with pytest.raises(ValueError):
+        D.resconv_pool2_few(x1, rnd((N, 3, H, W), 3, cuda), D.resconv_prepare(w3), rnd((R, 3), 4, cuda), R, bias)
+
+
 def sign_bytes(y):
     """(N, C, ceil(H/2), ceil(W/2)) bytes, bit 2 i + j = y > 0 at position (i, j) of the 2x2 tile (0 outside the plane)."""
     N, C, H, W = y.shape
@@ -288,6 +319,24 @@ def test_pooled_gradient_from_sign_bytes_equals_the_one_from_the_activation(D, c
         D.resconv_pooled_grad(gy, sel, U, R, H, W, h, 0.3, act=act)
     with pytest.raises(ValueError):
         D.resconv_pooled_grad(gy, sel, U, R, H, W, None, 0.3, act=act.view(-1))
+
+
+def test_first_block_with_the_downsample_in_the_epilogue_matches_the_all_matrix_block(D, cuda, monkeypatch):
+    """ADVSTEP_RESBLOCK_FEW=1 (default) vs 0 on a 2-channel first block: the two forms differ by fp32 summation order only."""
+    monkeypatch.setenv("ADVSTEP_SPECRNET_CONV", "1")
+    blk = make_block(2, 20, True, cuda, 11)
+    x = rnd((2, 2, 16, 24), 7, cuda)
+    gy = rnd((2, 20, 8, 12), 8, cuda)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("ADVSTEP_RESBLOCK_FEW", mode)
+        a = x.clone().requires_grad_(True)
+        y = blk(a)
+        assert blk._advstep_plan.few == (mode == "1")
+        (g,) = torch.autograd.grad(y, a, gy)
+        out[mode] = (y.detach(), g)
+    assert (out["1"][0] - out["0"][0]).abs().max().item() <= 2e-6 * out["0"][0].abs().max().item()
+    assert (out["1"][1] - out["0"][1]).norm().item() <= 1e-4 * out["0"][1].norm().item()       # a near-tie winner may move
 
 
 @pytest.mark.parametrize("cin,cout,first,hw", [(2, 20, True, (16, 24)), (20, 64, False, (20, 101)), (64, 64, False, (5, 25)),
