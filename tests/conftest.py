@@ -39,7 +39,7 @@ def cuda():
 @pytest.fixture(scope="session")
 def parity_record():
     """Measured parity figures of the `-m gpu` run (agreement rates, max-abs errors, flip counts ...), written to
-    gpurun_out/parity_record.json at the end of the session; the copy judged is profiles/r03_parity.json (r02_parity.json: round 2)."""
+    gpurun_out/parity_record.json at the end of the session; the copy judged is profiles/r04_parity.json (r03_parity.json, r02_parity.json: earlier rounds)."""
     import json
     record = {}
     yield record

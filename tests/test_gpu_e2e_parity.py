@@ -14,7 +14,7 @@ is moved by one float32 ulp (`*_one_ulp` figures, recorded next to the product's
 TEACHER-FORCED (the product's gradient and update at the oracle's own iterates, every 4th iteration of the real
 trajectory), and the free-running runs are bound by what the attack is for: loss per iteration, logits, the target's
 scores, predicted labels, accuracy, EER, the eps-ball / box invariants, and a divergence of the same order as the oracle's
-own.  Every bound is <= 10x the figure measured on MI355X (profiles/r03_parity.json)."""
+own.  Every bound is <= 3x the figure measured on MI355X (profiles/r03_parity.json / r04_parity.json; round 3: 10x)."""
 import pytest
 import torch
 
@@ -60,20 +60,23 @@ def test_pgd40_on_lcnn_lfcc_matches_cpu_oracle(cuda, hip, lcnn, parity_record):
     # iteration (agreement >= 0.9997), every flip at |grad| <= 2.9 % of its utterance's largest entry; gradient relative L2
     # 1e-6 where no max-feature-map / pooling winner re-routes (iteration 32) and 1e-3 .. 7e-3 where some do (the fused LFCC
     # differs from the CPU chain by ~1e-6 of scale, enough to turn a near-tie)
-    assert tf["grad_sign_agreement_worst"] >= 0.998, tf
-    assert tf["flip_rel_worst"] <= 0.1, tf                        # flips only where |grad| is small for its utterance
-    assert tf["grad_rel_l2_worst"] <= 3e-2, tf
+    # Round 4 (tests/parity_attribution.py, profiles/r04_parity_attribution.txt): every one of these flips sits behind a
+    # re-routed max-feature-map / pool winner, and the shipped kernels re-route no more winners against this oracle than the
+    # oracle's float32 does against its own float64 run; bounds = 3x the measured figures (0.9998, 1.7 %, 5.2e-3, 8.6e-8, 6e-8)
+    assert tf["grad_sign_agreement_worst"] >= 0.9994, tf
+    assert tf["flip_rel_worst"] <= 0.052, tf                      # flips only where |grad| is small for its utterance
+    assert tf["grad_rel_l2_worst"] <= 1.6e-2, tf
     assert tf["update_max_abs_on_agreeing_worst"] == 0.0, tf      # the step kernel is exact given the gradient's sign
-    assert tf["loss_rel_worst"] <= 1e-6 and tf["logit_max_abs_worst"] <= 4e-7, tf
+    assert tf["loss_rel_worst"] <= 3e-7 and tf["logit_max_abs_worst"] <= 2e-7, tf
     # free-running.  The sign pattern itself is chaotic (measured: 75 % of the final samples identical; the oracle started one
     # ulp away from itself ends 3 % different after the same 40 iterations and is still diverging), so it is recorded and only
     # loosely bounded; the loss per iteration (measured <= 3.3e-4 relative), the logits (<= 7.9e-4) and what the target makes
     # of the result (scores <= 6.5e-5, same labels, same EER) are the stated tolerance
     assert fin["box_ok"] and fin["linf_product"] <= hyper["eps"] + 1e-7, fin
-    assert fr["loss_rel_worst"] <= 2e-3 and fr["logit_max_abs_worst"] <= 5e-3, fr
+    assert fr["loss_rel_worst"] <= 1.6e-3 and fr["logit_max_abs_worst"] <= 2.6e-3, fr          # measured 5.1e-4, 8.4e-4
     assert fin["identical_samples"] >= 0.6 and fin["max_abs"] <= 2 * hyper["eps"] * (1 + 1e-4), fin
     assert tg["labels_equal"] and tg["accuracy_product"] == tg["accuracy_oracle"], tg
-    assert tg["score_max_abs"] <= 5e-4 and tg["eer_abs_diff"] <= 1e-9, tg
+    assert tg["score_max_abs"] <= 2e-4 and tg["eer_abs_diff"] <= 1e-9, tg                        # measured 6.5e-5
 
 
 def test_pgdl2_40_on_specrnet_mel_matches_cpu_oracle(cuda, hip, parity_record):
@@ -89,18 +92,19 @@ def test_pgdl2_40_on_specrnet_mel_matches_cpu_oracle(cuda, hip, parity_record):
     # teacher-forced.  The update kernel given the ORACLE's gradient: the row-norm tolerance of DESIGN.md section 5 (3e-7).
     # The product's own gradient at the oracle's iterate: relative L2 <= 4.9e-3 measured (MaxPool / LeakyReLU / |.|, angle
     # routing at near ties, as for LCNN), which moves the update by alpha * that (8.6e-5 measured)
-    assert tf["update_given_oracle_grad_max_abs_worst"] <= 3e-7, tf
-    assert tf["grad_rel_l2_worst"] <= 2e-2 and tf["grad_sign_agreement_worst"] >= 0.998 and tf["flip_rel_worst"] <= 0.1, tf
-    assert tf["update_max_abs_on_agreeing_worst"] <= 5e-4, tf
-    assert tf["loss_rel_worst"] <= 1e-6 and tf["logit_max_abs_worst"] <= 5e-6, tf
+    # bounds = 3x measured (6e-8; 4.9e-3, 0.9997, 2.2 %; 8.6e-5; 1.7e-7, 8.4e-7)
+    assert tf["update_given_oracle_grad_max_abs_worst"] <= 2e-7, tf
+    assert tf["grad_rel_l2_worst"] <= 1.5e-2 and tf["grad_sign_agreement_worst"] >= 0.9991 and tf["flip_rel_worst"] <= 0.066, tf
+    assert tf["update_max_abs_on_agreeing_worst"] <= 2.6e-4, tf
+    assert tf["loss_rel_worst"] <= 5.2e-7 and tf["logit_max_abs_worst"] <= 2.6e-6, tf
     # free-running: the iterates themselves end 0.48 of the perturbation's norm apart in the worst utterance — exactly the
     # oracle's distance from ITSELF started one ulp away (`divergence_oracle_vs_oracle_one_ulp`, same 0.48); bound: what
     # the attack optimises and what the target sees
     assert fin["box_ok"] and fin["l2_product_max"] <= hyper["eps"] * (1 + 1e-4), fin
-    assert fin["l2_rel_diff_worst"] <= 2e-5, fin
-    assert fr["loss_rel_worst"] <= 2e-3 and fr["logit_max_abs_worst"] <= 5e-3, fr
+    assert fin["l2_rel_diff_worst"] <= 7e-6, fin                                                  # measured 2.2e-6
+    assert fr["loss_rel_worst"] <= 2.6e-4 and fr["logit_max_abs_worst"] <= 1.9e-3, fr          # measured 8.5e-5, 6.2e-4
     assert tg["labels_equal"] and tg["accuracy_product"] == tg["accuracy_oracle"], tg
-    assert tg["score_max_abs"] <= 1.5e-4 and tg["eer_abs_diff"] <= 1e-9, tg
+    assert tg["score_max_abs"] <= 1e-5 and tg["eer_abs_diff"] <= 1e-9, tg                        # measured 3.1e-6
 
 
 def test_cw_transfer_rawnet3_to_lcnn_matches_cpu_oracle(cuda, hip, lcnn, parity_record):
