@@ -217,7 +217,8 @@ __global__ void wino_prepare_plain_kernel(const float *__restrict__ w3, const fl
 // EPI 0: plain store of min(32, Cout - slice * 32) channels per slice (the input-gradient convolution).
 // EPI 1: bias + max-feature-map + 2x2 pool [+ BatchNorm]; Cout = number of max-feature-map channels C.
 // EPI 2: bias + max-feature-map [+ BatchNorm] without the pool; one selection byte per 2x2 tile.
-// STREAM: K > 64, U chunks double-buffered through LDS (one barrier per chunk); otherwise all chunks stay resident.
+// STREAM: K > 64, U chunks streamed through LDS (two buffers and a barrier per chunk; SRC 1: four buffers, a barrier per two
+//         chunks, one stream across tile groups); otherwise all chunks stay resident.
 // grid = slices * ranges workgroups; workgroup b: slice b % slices, tile range b / slices.
 // SRC 0: the input is a dense tensor x (N, K, H, W).
 // SRC 1: the input is d(conv out) of a max-feature-map + 2x2 pool block, given in its compact form — the pooled gradient
@@ -353,6 +354,10 @@ __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restri
         __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(SRC != 0 ? xsel : reinterpret_cast<const uint8_t *>(x)), 0,
                                           (int)src_elems, 0x00020000);
 
+    if (STREAM && SRC == 1) {       // the U stream's first two chunks (see the k loop of SRC 1)
+        copy_chunk(0, 0);
+        copy_chunk(1, 1);
+    }
     for (int it = 0; it < iters; ++it) {
         const int grp = (it * ranges + range) * kWaves + wave;
         const int t = grp * 16 + nl;
@@ -528,27 +533,36 @@ __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restri
             // these kernels' loads come from the Infinity Cache / HBM (62 MB of pooled gradients + bytes per layer) and the one
             // k-step of distance they had did not cover them.  The loop body stays two k-steps long (a four-step body that
             // alternates two buffers without the moves spills 39 registers: 281 -> 310 us).
+            // Round 4: with a streamed U (K > 64) the chunks run through FOUR LDS buffers as ONE stream across tile groups —
+            // chunk q of the stream (q = it * chunks + c) lives in buffer q & 3 — with one workgroup barrier per TWO chunks: at
+            // the barrier before an even q, chunks q and q + 1 (requested one barrier earlier) have landed for every wave, chunks
+            // q - 2 and q - 1 have no reader left, and q + 2, q + 3 are requested into their buffers — the next tile group's
+            // first two chunks when this one is ending.  Round 3 had two buffers, a barrier per chunk, and started every tile
+            // group with an exposed request-wait-barrier for its chunk 0.  Timing-only builds without the per-chunk barrier ran
+            // 6 - 9 % faster (8 waves, two per SIMD and deliberately out of phase, meet 6 - 8 times per tile group); half of the
+            // meetings and the exposed start are what this removes.
             load_patch(da, 0);
             load_patch(db, 1);
-            if (STREAM) {
-                __syncthreads();            // previous iteration's readers are done with both buffers
-                copy_chunk(0, 0);
-                dma_landed();
+            const int q0 = it * chunks;                     // even: K % 32 == 0 for these sources
+            auto stream_point = [&](int c) {                // before chunk c (even) of this tile group
+                dma_landed();           // vmcnt(0): BEFORE the next pair's patch is requested, or it would wait for that too
                 __syncthreads();
-                copy_chunk(1, 1);           // chunks >= 2 always here
-            }
-            step(da, 0, a_ptr(0, 0), std::true_type{});
-            step(da, 1, a_ptr(1, 0), std::false_type{});
+#pragma unroll
+                for (int d = 2; d < 4; ++d) {
+                    const int cn = c + d;
+                    if (cn < chunks) copy_chunk(cn, (q0 + cn) & 3);
+                    else if (it + 1 < iters) copy_chunk(cn - chunks, (q0 + cn) & 3);
+                }
+            };
+            if (STREAM) stream_point(0);
+            step(da, 0, a_ptr(0, STREAM ? (q0 & 3) : 0), std::true_type{});
+            step(da, 1, a_ptr(1, STREAM ? (q0 & 3) : 0), std::false_type{});
 #pragma unroll 1
             for (int s = 2; s < steps; s += 2) {
                 da = db;
-                if (STREAM && (s & 3) == 0) {
-                    dma_landed();           // vmcnt(0): BEFORE the next pair's patch is requested, or it would wait for that too
-                    __syncthreads();        // chunk s/4 is complete in its buffer; chunk s/4 - 1 is free
-                    if (s / 4 + 1 < chunks) copy_chunk(s / 4 + 1, (s / 4 + 1) & 1);
-                }
+                if (STREAM && (s & 7) == 0) stream_point(s >> 2);
                 if (s + 2 < steps) load_patch(db, (s + 2) >> 1);
-                const int buf = STREAM ? ((s >> 2) & 1) : (s >> 2);
+                const int buf = STREAM ? ((q0 + (s >> 2)) & 3) : (s >> 2);
                 step(da, s, a_ptr(s, buf), std::false_type{});
                 step(da, s + 1, a_ptr(s + 1, buf), std::false_type{});
             }
@@ -814,7 +828,7 @@ int launch_wino(const float *x, const uint8_t *xsel, const float *U, const float
     const int chunks = (int)ceil_div(K, kChunkCin);
     const bool stream = chunks > kMaxResident;
     const int64_t groups = ceil_div(N * ((H + 1) / 2) * ((W + 1) / 2), 16);
-    const size_t lds = (size_t)(stream ? 2 : chunks) * kChunkFloats * sizeof(float);
+    const size_t lds = (size_t)(stream ? (SRC == 1 ? 4 : 2) : chunks) * kChunkFloats * sizeof(float);
     const bool wodd = SRC == 0 && (W & 1);
     auto go = [&](auto kernel, int n_slices, int slice0) {
         int ranges = cus / n_slices;
