@@ -45,7 +45,7 @@ class _AffineAct(torch.autograd.Function):
         if scale.numel() != C or shift.numel() != C or (pre is not None and pre.numel() != C):
             raise ValueError("per-channel constants must have one entry per channel")
         y = torch.empty_like(x)
-        with _Launch("affine_act_forward", x.device):
+        with _Launch("affine_act_forward", x.device, tensors=(x, y)):
             st = _lib.load().advstep_affine_act_forward_f32(x.data_ptr(), scale.data_ptr(), shift.data_ptr(),
                                                             pre.data_ptr() if pre is not None else None, y.data_ptr(), N, C, P,
                                                             mode, slope, _stream(x.device))
@@ -60,7 +60,7 @@ class _AffineAct(torch.autograd.Function):
         N, C, P, mode, slope = ctx.meta
         gy = gy.contiguous()
         gx = torch.empty_like(x)
-        with _Launch("affine_act_backward", x.device):
+        with _Launch("affine_act_backward", x.device, tensors=(gy, x, gx)):
             st = _lib.load().advstep_affine_act_backward_f32(gy.data_ptr(), x.data_ptr(), scale.data_ptr(), shift.data_ptr(),
                                                              pre[0].data_ptr() if pre else None, gx.data_ptr(), N, C, P, mode,
                                                              slope, _stream(x.device))
@@ -95,7 +95,7 @@ def _add_maxpool2_raw(a, b, bias):
     N, C, H, W = a.shape
     y = torch.empty((N, C, H // 2, W // 2), dtype=a.dtype, device=a.device)
     sel = torch.empty(max(y.numel(), 1), dtype=torch.uint8, device=a.device)
-    with _Launch("add_maxpool2_forward", a.device):
+    with _Launch("add_maxpool2_forward", a.device, tensors=(a, b, y, sel)):
         st = _lib.load().advstep_add_maxpool2_forward_f32(a.data_ptr(), b.data_ptr() if b is not None else None,
                                                           bias.data_ptr() if bias is not None else None, y.data_ptr(),
                                                           sel.data_ptr(), N, C, H, W, _stream(a.device))
@@ -119,7 +119,7 @@ class _AddMaxPool2(torch.autograd.Function):
         N, C, H, W = ctx.shape
         gy = gy.contiguous()
         g = torch.empty((N, C, H, W), dtype=gy.dtype, device=gy.device)
-        with _Launch("maxpool2_backward", gy.device):
+        with _Launch("maxpool2_backward", gy.device, tensors=(gy, sel, g)):
             st = _lib.load().advstep_maxpool2_backward_f32(gy.data_ptr(), sel.data_ptr(), g.data_ptr(), N, C, H, W,
                                                            _stream(gy.device))
         _lib.check(st, "advstep_maxpool2_backward_f32")
@@ -188,7 +188,7 @@ class _AddMaxPool1d(torch.autograd.Function):
         N, C, L = a.shape
         y = torch.empty((N, C, L // k), dtype=a.dtype, device=a.device)
         sel = torch.empty(max(y.numel(), 1), dtype=torch.uint8, device=a.device)
-        with _Launch("add_maxpool1d_forward", a.device):
+        with _Launch("add_maxpool1d_forward", a.device, tensors=(a, b, y, sel)):
             st = _lib.load().advstep_add_maxpool1d_forward_f32(a.data_ptr(), b.data_ptr() if b is not None else None, y.data_ptr(),
                                                                sel.data_ptr(), N, C, L, k, _stream(a.device))
         _lib.check(st, "advstep_add_maxpool1d_forward_f32")
@@ -202,7 +202,7 @@ class _AddMaxPool1d(torch.autograd.Function):
         N, C, L, k, two = ctx.meta
         gy = gy.contiguous()
         g = torch.empty((N, C, L), dtype=gy.dtype, device=gy.device)
-        with _Launch("maxpool1d_backward", gy.device):
+        with _Launch("maxpool1d_backward", gy.device, tensors=(gy, sel, g)):
             st = _lib.load().advstep_maxpool1d_backward_f32(gy.data_ptr(), sel.data_ptr(), g.data_ptr(), N, C, L, k,
                                                             _stream(gy.device))
         _lib.check(st, "advstep_maxpool1d_backward_f32")
@@ -263,7 +263,7 @@ class _WeightedStats(torch.autograd.Function):
         N, C, L = x.shape
         mu = torch.empty((N, C), dtype=x.dtype, device=x.device)
         m2 = torch.empty_like(mu)
-        with _Launch("weighted_stats_forward", x.device):
+        with _Launch("weighted_stats_forward", x.device, tensors=(x, w)):
             st = _lib.load().advstep_weighted_stats_forward_f32(x.data_ptr(), w.data_ptr(), mu.data_ptr(), m2.data_ptr(), N * C, L,
                                                                 _stream(x.device))
         _lib.check(st, "advstep_weighted_stats_forward_f32")
@@ -275,7 +275,7 @@ class _WeightedStats(torch.autograd.Function):
         x, w = ctx.saved_tensors
         N, C, L = x.shape
         gx, gw = torch.empty_like(x), torch.empty_like(w)
-        with _Launch("weighted_stats_backward", x.device):
+        with _Launch("weighted_stats_backward", x.device, tensors=(x, w, gx, gw)):
             st = _lib.load().advstep_weighted_stats_backward_f32(x.data_ptr(), w.data_ptr(), gmu.contiguous().data_ptr(),
                                                                  gm2.contiguous().data_ptr(), gx.data_ptr(), gw.data_ptr(), N * C, L,
                                                                  _stream(x.device))
@@ -294,7 +294,7 @@ class _LogMeanNorm(torch.autograd.Function):
         _require(y, "y")
         L = y.shape[-1]
         x = torch.empty_like(y)
-        with _Launch("log_meannorm_forward", y.device):
+        with _Launch("log_meannorm_forward", y.device, tensors=(y, x)):
             st = _lib.load().advstep_log_meannorm_forward_f32(y.data_ptr(), eps, x.data_ptr(), y.numel() // max(L, 1), L,
                                                               _stream(y.device))
         _lib.check(st, "advstep_log_meannorm_forward_f32")
@@ -308,7 +308,7 @@ class _LogMeanNorm(torch.autograd.Function):
         L = y.shape[-1]
         gx = gx.contiguous()
         gy = torch.empty_like(y)
-        with _Launch("log_meannorm_backward", y.device):
+        with _Launch("log_meannorm_backward", y.device, tensors=(gx, y, gy)):
             st = _lib.load().advstep_log_meannorm_backward_f32(gx.data_ptr(), y.data_ptr(), ctx.eps, gy.data_ptr(),
                                                                y.numel() // max(L, 1), L, _stream(y.device))
         _lib.check(st, "advstep_log_meannorm_backward_f32")
@@ -333,7 +333,7 @@ class _TailPool1d(torch.autograd.Function):
         N, C, L = h.shape
         y = torch.empty((N, C, L // k), dtype=h.dtype, device=h.device)
         sel = torch.empty(max(y.numel(), 1), dtype=torch.uint8, device=h.device)
-        with _Launch("tail_pool1d_forward", h.device):
+        with _Launch("tail_pool1d_forward", h.device, tensors=(h, res, y, sel)):
             st = _lib.load().advstep_tail_pool1d_forward_f32(h.data_ptr(), res.data_ptr(), scale.data_ptr(), shift.data_ptr(),
                                                              None if pre is None else pre.data_ptr(), y.data_ptr(), sel.data_ptr(),
                                                              N, C, L, k, _stream(h.device))
@@ -348,7 +348,7 @@ class _TailPool1d(torch.autograd.Function):
         N, C, L = h.shape
         gy = gy.contiguous()
         g_h, g_res = torch.empty_like(h), torch.empty_like(h)
-        with _Launch("tail_pool1d_backward", h.device):
+        with _Launch("tail_pool1d_backward", h.device, tensors=(gy, sel, h, g_h, g_res)):
             st = _lib.load().advstep_tail_pool1d_backward_f32(gy.data_ptr(), sel.data_ptr(), h.data_ptr(), scale.data_ptr(),
                                                               pre[0].data_ptr() if pre else None, g_h.data_ptr(), g_res.data_ptr(),
                                                               N, C, L, ctx.k, _stream(h.device))
@@ -381,7 +381,7 @@ class _GateMaxPool2(torch.autograd.Function):
             raise ValueError("gate must hold one value per (sample, channel)")
         y = torch.empty((N, C, H // 2, W // 2), dtype=x.dtype, device=x.device)
         sel = torch.empty(max(y.numel(), 1), dtype=torch.uint8, device=x.device)
-        with _Launch("gate_maxpool2_forward", x.device):
+        with _Launch("gate_maxpool2_forward", x.device, tensors=(x, y, sel)):
             st = _lib.load().advstep_gate_maxpool2_forward_f32(x.data_ptr(), gate.data_ptr(), y.data_ptr(), sel.data_ptr(), N, C,
                                                                H, W, _stream(x.device))
         _lib.check(st, "advstep_gate_maxpool2_forward_f32")
@@ -398,7 +398,7 @@ class _GateMaxPool2(torch.autograd.Function):
         blocks = max(lib.advstep_gate_maxpool2_blocks(H, W), 1)
         gx = torch.empty_like(x)
         partial = torch.empty((N * C, blocks), dtype=x.dtype, device=x.device)
-        with _Launch("gate_maxpool2_backward", x.device):
+        with _Launch("gate_maxpool2_backward", x.device, tensors=(gy, sel, gx)):
             st = lib.advstep_gate_maxpool2_backward_f32(gy.data_ptr(), sel.data_ptr(), x.data_ptr(), gate.data_ptr(),
                                                         gx.data_ptr(), partial.data_ptr(), N, C, H, W, _stream(x.device))
         _lib.check(st, "advstep_gate_maxpool2_backward_f32")
@@ -621,7 +621,7 @@ def conv3x3_fewin(x: torch.Tensor, w: torch.Tensor, shift: Optional[torch.Tensor
     Cout = w.shape[0]
     y = torch.empty((N, Cout, H, W), dtype=x.dtype, device=x.device)
     act = _sign_bytes(N, Cout, H, W, x.device) if with_act else None
-    with _Launch("conv3x3_fewin_forward", x.device):
+    with _Launch("conv3x3_fewin_forward", x.device, work=18.0 * N * Cout * x.shape[1] * H * W, tensors=(x, y, act)):
         st = _lib.load().advstep_conv3x3_fewin_forward_act_f32(x.data_ptr(), w.data_ptr(), None if shift is None else shift.data_ptr(),
                                                                float(slope), y.data_ptr(), None if act is None else act.data_ptr(),
                                                                N, Cin, Cout, H, W, _stream(x.device))
@@ -643,7 +643,7 @@ def conv3x3_fewout_grad(g1: torch.Tensor, w3: torch.Tensor, gp: Optional[torch.T
         if gp.numel() == 0:                    # nothing was pooled (H or W < 2): the identity path carries no gradient
             gp = None
     gx = torch.empty((N, rows, H, W), dtype=g1.dtype, device=g1.device)
-    with _Launch("conv3x3_fewout_grad", g1.device):
+    with _Launch("conv3x3_fewout_grad", g1.device, work=18.0 * N * K * rows * H * W, tensors=(g1, gp, gx)):
         st = _lib.load().advstep_conv3x3_fewout_grad_f32(g1.data_ptr(), w3.data_ptr(), None if gp is None else gp.data_ptr(),
                                                          None if gp is None else sel.data_ptr(), None if gp is None else wd.data_ptr(),
                                                          gx.data_ptr(), N, K, rows, H, W, _stream(g1.device))
@@ -774,7 +774,7 @@ class _ResBlock(torch.autograd.Function):
         if p.fewin:
             return conv3x3_fewout_grad(g_pre, p.w1_scaled, gy, sel, p.wd), None
         g_h2 = torch.empty((N, p.cout, H, W), dtype=gy.dtype, device=gy.device)       # the identity path's gradient
-        with _Launch("maxpool2_backward", gy.device):
+        with _Launch("maxpool2_backward", gy.device, tensors=(gy, sel, g_h2)):
             st = lib.advstep_maxpool2_backward_f32(gy.data_ptr(), sel.data_ptr(), g_h2.data_ptr(), N, p.cout, H, W, _stream(gy.device))
         _lib.check(st, "advstep_maxpool2_backward_f32")
         gx = resconv(g_pre, g_h2 if p.downsample else None, p.U1T, p.cin)

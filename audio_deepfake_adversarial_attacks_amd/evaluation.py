@@ -211,6 +211,7 @@ def generate_attacks(
     device_pad: bool = True,
     wave_fake_trim: Optional[bool] = None,
     return_scores: bool = False,
+    on_batch_queued: Optional[Callable[[int], None]] = None,
 ) -> Dict[str, float]:
     """Reference signature (:146-157) plus additive keywords: `dataset` (a ready Dataset yielding the reference's
     4-tuple; without it the `DetectionDataset` over `datasets_paths` is built as in the reference's `get_dataset`,
@@ -219,7 +220,8 @@ def generate_attacks(
     so collation belongs in worker processes),
     `device_pad` (real corpora: ship undecoded payloads and pad on the device) and `wave_fake_trim` (None = the
     reference's default, the SoX silence trim, which needs a registered backend) and `return_scores` (adds the whole job's
-    per-utterance `y_pred`, `y_pred_label`, `y` arrays, in rank order, to the returned report under "scores").
+    per-utterance `y_pred`, `y_pred_label`, `y` arrays, in rank order, to the returned report under "scores") and
+    `on_batch_queued(i)` (called when batch i's kernels have been queued — no synchronisation, no extra work: measurements).
     `batch_size` is the GLOBAL batch."""
     rank, world = rank_and_world()
     LOGGER.info("Loading data...")
@@ -294,6 +296,8 @@ def generate_attacks(
         y_pred.append(batch_preds)
         y_pred_label.append(batch_preds_label)
         y.append(batch_y)
+        if on_batch_queued is not None:
+            on_batch_queued(len(y) - 1)
 
     if not y:
         raise ValueError(f"no complete batch: {len(data_val)} items < global batch {batch_size} (drop_last=True)")

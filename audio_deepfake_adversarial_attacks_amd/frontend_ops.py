@@ -206,7 +206,7 @@ class _LfccFromWaveformFused(torch.autograd.Function):
         block_max = torch.empty(max(nblk, 1), dtype=torch.float32, device=dev)
         stats = torch.empty(4, dtype=torch.float32, device=dev)
         out = torch.empty((B, NF, K), dtype=torch.float32, device=dev)
-        with _Launch("lfcc_forward", dev):
+        with _Launch("lfcc_forward", dev, tensors=(x, band_db, band_db, out)):     # waveform in, band rows out + back in, cepstra out
             st = lib.advstep_stft_bands_f32(x.data_ptr(), window.data_ptr(), tables.fb_start.data_ptr(), tables.fb_w.data_ptr(),
                                             tables.span, band_db.data_ptr(), block_max.data_ptr(), B, T, NF, hop, nfft, M,
                                             _stream(dev))
@@ -229,7 +229,7 @@ class _LfccFromWaveformFused(torch.autograd.Function):
         lib = _lib.load()
         dband = torch.empty((B, NF, M), dtype=torch.float32, device=dev)
         dx = torch.empty((B, T), dtype=torch.float32, device=dev)
-        with _Launch("lfcc_backward", dev):
+        with _Launch("lfcc_backward", dev, tensors=(go, band_db, dband, dband, x, dx, dx)):
             st = lib.advstep_lfcc_project_backward_f32(go.data_ptr(), dct.data_ptr(), band_db.data_ptr(), stats.data_ptr(),
                                                        top_db, dband.data_ptr(), B, M, NF, K, _stream(dev))
             _lib.check(st, "advstep_lfcc_project_backward_f32")
@@ -264,7 +264,7 @@ class _MelSpecFromWaveform(torch.autograd.Function):
         M = tables.fb_start.numel()
         dev = x.device
         out = torch.empty((B, 2, M, NF), dtype=torch.float32, device=dev)
-        with _Launch("stft_mel", dev):
+        with _Launch("stft_mel", dev, tensors=(x, out)):
             st = _lib.load().advstep_stft_mel_f32(x.data_ptr(), window.data_ptr(), tables.fb_start.data_ptr(),
                                                   tables.fb_w.data_ptr(), tables.span, out.data_ptr(), B, T, NF, hop, nfft, M,
                                                   _stream(dev))
@@ -283,13 +283,13 @@ class _MelSpecFromWaveform(torch.autograd.Function):
         dx = torch.empty((B, T), dtype=torch.float32, device=dev)
         if ctx.from_output:
             # d x from d out and out alone (Y = |Y| e^{i phase} is all the gradient needs): no spectrum is recomputed
-            with _Launch("stft_mel_backward", dev):
+            with _Launch("stft_mel_backward", dev, tensors=(go, x, dx, dx)):
                 st = _lib.load().advstep_stft_mel_backward_from_output_f32(window.data_ptr(), go.data_ptr(), x.data_ptr(),
                                                                            fbt_start.data_ptr(), fbt_w.data_ptr(), span_t,
                                                                            dx.data_ptr(), B, T, NF, hop, nfft, M, _stream(dev))
             _lib.check(st, "advstep_stft_mel_backward_from_output_f32")
             return dx, None, None, None
-        with _Launch("stft_mel_backward", dev):
+        with _Launch("stft_mel_backward", dev, tensors=(go, x, dx, dx)):
             st = _lib.load().advstep_stft_mel_backward_f32(x.data_ptr(), window.data_ptr(), go.data_ptr(), fb_start.data_ptr(),
                                                            fb_w.data_ptr(), span, fbt_start.data_ptr(), fbt_w.data_ptr(), span_t,
                                                            dx.data_ptr(), B, T, NF, hop, nfft, M, _stream(dev))

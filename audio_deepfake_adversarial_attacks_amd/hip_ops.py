@@ -31,6 +31,8 @@ NAME = "hip"
 _workspaces: Dict[Tuple[int, int], torch.Tensor] = {}
 _profile: Optional[Dict[str, List[Tuple[torch.cuda.Event, torch.cuda.Event]]]] = None
 _profile_work: Dict[str, List[float]] = {}      # per bracketed launch: the arithmetic the caller says it did (flop), or 0
+_profile_bytes: Dict[str, List[float]] = {}     # per bracketed launch: the bytes of the operands the caller named, or 0
+_profile_all = False                            # start_profile("*"): every entry point
 
 
 def _require(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
@@ -86,18 +88,20 @@ def _out_like(ref: torch.Tensor, out: Optional[torch.Tensor], name: str = "out")
 
 class _Launch:
     """Device guard + optional HIP-event bracket around one C-ABI call (events sit on the launch stream).  `work` = the
-    floating-point operations the launch must put through the matrix cores (Winograd F(2x2, 3x3) kernels: 2 x 16 products per
-    2x2 output tile, output row and reduction channel = a direct 3x3 convolution's count / 2.25; unpadded), kept next to the
-    bracket's duration for bench.py's model-side roofline."""
+    floating-point operations the launch must do — for the Winograd F(2x2, 3x3) kernels what goes through the matrix cores: 2 x 16
+    products per 2x2 output tile, output row and reduction channel = a direct 3x3 convolution's count / 2.25, unpadded;
+    `tensors` = the operands the launch reads or writes once (its algorithmic HBM bytes = the sum of their sizes).  Both are
+    kept next to the bracket's duration for bench.py's rooflines (`roofline_model`, `roofline_step`)."""
 
-    def __init__(self, name: str, device: torch.device, work: float = 0.0):
+    def __init__(self, name: str, device: torch.device, work: float = 0.0, tensors=()):
         self.name, self.device, self.work = name, device, work
+        self.nbytes = float(sum(t.numel() * t.element_size() for t in tensors if t is not None)) if tensors else 0.0
         self.guard = torch.cuda.device(device)
 
     def __enter__(self):
         self.guard.__enter__()
         self.pair = None
-        if _profile is not None and self.name in _profile:
+        if _profile is not None and (_profile_all or self.name in _profile):
             self.pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             self.pair[0].record(torch.cuda.current_stream(self.device))
         return self
@@ -105,24 +109,31 @@ class _Launch:
     def __exit__(self, *exc):
         if self.pair is not None:
             self.pair[1].record(torch.cuda.current_stream(self.device))
-            _profile[self.name].append(self.pair)
+            _profile.setdefault(self.name, []).append(self.pair)
             _profile_work.setdefault(self.name, []).append(self.work)
+            _profile_bytes.setdefault(self.name, []).append(self.nbytes)
         return self.guard.__exit__(*exc)
 
 
 def start_profile(*entry_points: str) -> None:
-    """Bracket every later launch of the named entry points with HIP events on their launch stream."""
-    global _profile
-    _profile = {n: [] for n in entry_points}
+    """Bracket every later launch of the named entry points ("*": of every entry point) with HIP events on their launch
+    stream."""
+    global _profile, _profile_all
+    _profile_all = "*" in entry_points
+    _profile = {n: [] for n in entry_points if n != "*"}
     _profile_work.clear()
+    _profile_bytes.clear()
 
 
-def stop_profile(with_work: bool = False):
-    """Synchronise and return {entry point: [milliseconds per launch]} (with_work: also {entry point: [flop per launch]})."""
-    global _profile
-    prof, _profile = _profile or {}, None
+def stop_profile(with_work=False):
+    """Synchronise and return {entry point: [milliseconds per launch]}; with_work: also {entry point: [flop per launch]};
+    with_work="bytes": also {entry point: [algorithmic bytes per launch]} as a third result."""
+    global _profile, _profile_all
+    prof, _profile, _profile_all = _profile or {}, None, False
     torch.cuda.synchronize()
     ms = {n: [a.elapsed_time(b) for a, b in pairs] for n, pairs in prof.items()}
+    if with_work == "bytes":
+        return (ms, {n: list(_profile_work.get(n, [])) for n in prof}, {n: list(_profile_bytes.get(n, [])) for n in prof})
     if with_work:
         return ms, {n: list(_profile_work.get(n, [])) for n in prof}
     return ms
@@ -139,7 +150,7 @@ def to_minmax(batch_x: torch.Tensor):
     x01 = torch.empty_like(x)
     mn = torch.empty((B, 1), dtype=torch.float32, device=x.device)
     mx = torch.empty((B, 1), dtype=torch.float32, device=x.device)
-    with _Launch("minmax_normalize", x.device):
+    with _Launch("minmax_normalize", x.device, tensors=(x, x, x01)):
         ws, ws_bytes = _workspace(x.device, B, T)
         st = _lib.load().advstep_minmax_normalize_f32(x.data_ptr(), x01.data_ptr(), mn.data_ptr(), mx.data_ptr(), B, T,
                                                       ws, ws_bytes, _stream(x.device))
@@ -155,7 +166,7 @@ def revert_minmax(batch_x: torch.Tensor, mn: torch.Tensor, mx: torch.Tensor, out
     if mn.numel() != B or mx.numel() != B:
         raise ValueError(f"mn/mx must hold one value per row ({B}), got {mn.numel()} / {mx.numel()}")
     out = _out_like(x, out)
-    with _Launch("minmax_revert", x.device):
+    with _Launch("minmax_revert", x.device, tensors=(x, out)):
         st = _lib.load().advstep_minmax_revert_f32(x.data_ptr(), mn.data_ptr(), mx.data_ptr(), out.data_ptr(), B, T,
                                                    _stream(x.device))
     _lib.check(st, "advstep_minmax_revert_f32")
@@ -170,7 +181,7 @@ def fgsm_step(x, grad, eps: float, lo: float = 0.0, hi: float = 1.0, out=None):
     _require(x, "x"), _require(grad, "grad")
     _same_shape(("x", x), ("grad", grad))
     out = _out_like(x, out)
-    with _Launch("fgsm_step", x.device):
+    with _Launch("fgsm_step", x.device, tensors=(x, grad, out)):
         st = _lib.load().advstep_fgsm_step_f32(x.data_ptr(), grad.data_ptr(), out.data_ptr(), x.numel(), eps, lo, hi,
                                                _stream(x.device))
     _lib.check(st, "advstep_fgsm_step_f32")
@@ -185,14 +196,14 @@ def pgd_linf_init(x, eps: float, noise=None, seed: Optional[int] = None, offset:
     if noise is not None:
         _require(noise, "noise")
         _same_shape(("x", x), ("noise", noise))
-        with _Launch("pgd_linf_init", x.device):
+        with _Launch("pgd_linf_init", x.device, tensors=(x, noise, out)):
             st = _lib.load().advstep_pgd_linf_init_noise_f32(x.data_ptr(), noise.data_ptr(), out.data_ptr(), x.numel(),
                                                              lo, hi, _stream(x.device))
         _lib.check(st, "advstep_pgd_linf_init_noise_f32")
     else:
         if seed is None:
             raise ValueError("pgd_linf_init needs either `noise` or a Philox `seed`")
-        with _Launch("pgd_linf_init", x.device):
+        with _Launch("pgd_linf_init", x.device, tensors=(x, out)):
             st = _lib.load().advstep_pgd_linf_init_philox_f32(x.data_ptr(), out.data_ptr(), x.numel(), eps, lo, hi,
                                                               seed, offset, _stream(x.device))
         _lib.check(st, "advstep_pgd_linf_init_philox_f32")
@@ -203,7 +214,7 @@ def pgd_linf_step(adv, grad, orig, alpha: float, eps: float, lo: float = 0.0, hi
     _require(adv, "adv"), _require(grad, "grad"), _require(orig, "orig")
     _same_shape(("adv", adv), ("grad", grad), ("orig", orig))
     out = _out_like(adv, out)
-    with _Launch("pgd_linf_step", adv.device):
+    with _Launch("pgd_linf_step", adv.device, tensors=(adv, grad, orig, out)):
         st = _lib.load().advstep_pgd_linf_step_f32(adv.data_ptr(), grad.data_ptr(), orig.data_ptr(), out.data_ptr(),
                                                    adv.numel(), alpha, eps, lo, hi, _stream(adv.device))
     _lib.check(st, "advstep_pgd_linf_step_f32")
@@ -220,7 +231,7 @@ def pgd_l2_init(x, eps: float, draws=None, seed: Optional[int] = None, offset: i
     _require(x, "x")
     B, T = _rows(x, "x")
     out = _out_like(x, out)
-    with _Launch("pgd_l2_init", x.device):
+    with _Launch("pgd_l2_init", x.device, tensors=(x, out)):
         ws, ws_bytes = _workspace(x.device, B, T)
         if draws is not None:
             normal, r = draws
@@ -251,7 +262,7 @@ def pgd_l2_step(adv, grad, orig, alpha: float, eps: float, eps_div: float = 1e-1
     if return_norms:
         gn = torch.empty(B, dtype=torch.float32, device=adv.device)
         dn = torch.empty(B, dtype=torch.float32, device=adv.device)
-    with _Launch("pgd_l2_step", adv.device):
+    with _Launch("pgd_l2_step", adv.device, tensors=(adv, grad, orig, out)):
         ws, ws_bytes = _workspace(adv.device, B, T)
         st = _lib.load().advstep_pgd_l2_step_f32(adv.data_ptr(), grad.data_ptr(), orig.data_ptr(), out.data_ptr(), B, T,
                                                  alpha, eps, eps_div, lo, hi, gn.data_ptr() if return_norms else None,
@@ -281,7 +292,7 @@ def pgd_l2_repaired_rows(like: torch.Tensor) -> int:
 def cw_init_w(x, out=None):
     _require(x, "x")
     out = _out_like(x, out)
-    with _Launch("cw_init_w", x.device):
+    with _Launch("cw_init_w", x.device, tensors=(x, out)):
         st = _lib.load().advstep_cw_init_w_f32(x.data_ptr(), out.data_ptr(), x.numel(), _stream(x.device))
     _lib.check(st, "advstep_cw_init_w_f32")
     return out
@@ -294,7 +305,7 @@ def cw_tanh_sqdist(w, x, adv_out=None):
     B, T = _rows(w, "w")
     adv = _out_like(w, adv_out, "adv_out")
     l2 = torch.empty(B, dtype=torch.float32, device=w.device)
-    with _Launch("cw_tanh_sqdist", w.device):
+    with _Launch("cw_tanh_sqdist", w.device, tensors=(w, x, adv)):
         ws, ws_bytes = _workspace(w.device, B, T)
         st = _lib.load().advstep_cw_tanh_sqdist_f32(w.data_ptr(), x.data_ptr(), adv.data_ptr(), l2.data_ptr(), B, T, ws,
                                                     ws_bytes, _stream(w.device))
@@ -308,7 +319,7 @@ def cw_adam_step(w, m, v, x, grad_adv, step: int, lr: float = 0.01, beta1: float
     for name, t in (("w", w), ("m", m), ("v", v), ("x", x), ("grad_adv", grad_adv)):
         _require(t, name)
     _same_shape(("w", w), ("m", m), ("v", v), ("x", x), ("grad_adv", grad_adv))
-    with _Launch("cw_adam_step", w.device):
+    with _Launch("cw_adam_step", w.device, tensors=(w, w, m, m, v, v, x, grad_adv)):
         st = _lib.load().advstep_cw_adam_step_f32(w.data_ptr(), m.data_ptr(), v.data_ptr(), x.data_ptr(),
                                                   grad_adv.data_ptr(), w.numel(), step, lr, beta1, beta2, adam_eps,
                                                   _stream(w.device))
@@ -322,7 +333,7 @@ def cw_best_update(adv, mask, best) -> None:
     B, T = _rows(adv, "adv")
     if mask.numel() != B:
         raise ValueError(f"mask must hold one value per row ({B}), got {mask.numel()}")
-    with _Launch("cw_best_update", adv.device):
+    with _Launch("cw_best_update", adv.device, tensors=(adv, best, best)):
         st = _lib.load().advstep_cw_best_update_f32(adv.data_ptr(), mask.data_ptr(), best.data_ptr(), B, T,
                                                     _stream(adv.device))
     _lib.check(st, "advstep_cw_best_update_f32")

@@ -50,7 +50,7 @@ class _Mfm(torch.autograd.Function):
         y = torch.empty((N, C, H, W), dtype=x.dtype, device=x.device)
         lib = _lib.load()
         sel = torch.empty(max(lib.advstep_mfm_sel_bytes(N, C, HW), 1), dtype=torch.uint8, device=x.device)
-        with _Launch("mfm_forward", x.device):
+        with _Launch("mfm_forward", x.device, tensors=(x, y, sel)):
             st = lib.advstep_mfm_forward_f32(x.data_ptr(), bias.data_ptr() if bias is not None else None, bn_mean,
                                              bn_invstd, y.data_ptr(), sel.data_ptr(), N, C, HW, _stream(x.device))
         _lib.check(st, "advstep_mfm_forward_f32")
@@ -65,7 +65,7 @@ class _Mfm(torch.autograd.Function):
         N, C, H, W = ctx.shape
         gy = gy.contiguous()
         gx = torch.empty((N, 2 * C, H, W), dtype=gy.dtype, device=gy.device)
-        with _Launch("mfm_backward", gy.device):
+        with _Launch("mfm_backward", gy.device, tensors=(gy, sel, gx)):
             st = _lib.load().advstep_mfm_backward_f32(gy.data_ptr(), sel.data_ptr(), scale[0].data_ptr() if scale else None,
                                                       gx.data_ptr(), N, C, H * W, _stream(gy.device))
         _lib.check(st, "advstep_mfm_backward_f32")
@@ -81,7 +81,7 @@ class _MfmPool2(torch.autograd.Function):
         C = C2 // 2
         y = torch.empty((N, C, H // 2, W // 2), dtype=x.dtype, device=x.device)
         idx = torch.empty(max(y.numel(), 2), dtype=torch.uint8, device=x.device)
-        with _Launch("mfm_pool2_forward", x.device):
+        with _Launch("mfm_pool2_forward", x.device, tensors=(x, y, idx)):
             st = _lib.load().advstep_mfm_pool2_forward_f32(x.data_ptr(), bias.data_ptr() if bias is not None else None,
                                                            bn_mean, bn_invstd, y.data_ptr(), idx.data_ptr(), N, C, H, W,
                                                            _stream(x.device))
@@ -97,7 +97,7 @@ class _MfmPool2(torch.autograd.Function):
         N, C, H, W = ctx.shape
         gy = gy.contiguous()
         gx = torch.empty((N, 2 * C, H, W), dtype=gy.dtype, device=gy.device)
-        with _Launch("mfm_pool2_backward", gy.device):
+        with _Launch("mfm_pool2_backward", gy.device, tensors=(gy, idx, gx)):
             st = _lib.load().advstep_mfm_pool2_backward_f32(gy.data_ptr(), idx.data_ptr(),
                                                             scale[0].data_ptr() if scale else None, gx.data_ptr(), N, C, H,
                                                             W, _stream(gy.device))
@@ -121,7 +121,7 @@ class _Conv5MfmPool2(torch.autograd.Function):
         C = weight.shape[0] // 2
         y = torch.empty((N, C, H // 2, W // 2), dtype=x.dtype, device=x.device)
         idx = torch.empty(max(y.numel(), 1), dtype=torch.uint8, device=x.device)
-        with _Launch("conv5_mfm_pool2_forward", x.device):
+        with _Launch("conv5_mfm_pool2_forward", x.device, work=100.0 * N * C * H * W, tensors=(x, y, idx)):
             st = _lib.load().advstep_conv5_mfm_pool2_forward_f32(
                 x.data_ptr(), weight.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(),
                 idx.data_ptr(), N, C, H, W, _stream(x.device))
@@ -139,7 +139,7 @@ class _Conv5MfmPool2(torch.autograd.Function):
         N, C, H, W = ctx.shape
         gy = gy.contiguous()
         gx = torch.empty((N, 1, H, W), dtype=gy.dtype, device=gy.device)
-        with _Launch("conv5_mfm_pool2_backward", gy.device):
+        with _Launch("conv5_mfm_pool2_backward", gy.device, work=100.0 * N * C * H * W, tensors=(gy, idx, gx)):
             st = _lib.load().advstep_conv5_mfm_pool2_backward_f32(gy.data_ptr(), idx.data_ptr(), weight.data_ptr(),
                                                                   gx.data_ptr(), N, C, H, W, _stream(gy.device))
         _lib.check(st, "advstep_conv5_mfm_pool2_backward_f32")
@@ -171,7 +171,7 @@ class _Conv1x1Mfm(torch.autograd.Function):
             raise ValueError(f"conv1x1_mfm supports Cin in (32, 48, 64), got {Cin}")
         y = torch.empty((N, C, H, W), dtype=x.dtype, device=x.device)
         sel = torch.empty(max(lib.advstep_conv1x1_mfm_sel_bytes(N, C, P), 4), dtype=torch.uint8, device=x.device)
-        with _Launch("conv1x1_mfm_forward", x.device):
+        with _Launch("conv1x1_mfm_forward", x.device, work=4.0 * N * Cin * C * P, tensors=(x, y, sel)):
             st = lib.advstep_conv1x1_mfm_forward_f32(x.data_ptr(), weight.data_ptr(),
                                                      bias.data_ptr() if bias is not None else None, bn_mean, bn_invstd,
                                                      y.data_ptr(), sel.data_ptr(), N, Cin, C, P, _stream(x.device))
@@ -189,7 +189,7 @@ class _Conv1x1Mfm(torch.autograd.Function):
         N, Cin, C, H, W = ctx.shape
         gy = gy.contiguous()
         gx = torch.empty((N, Cin, H, W), dtype=gy.dtype, device=gy.device)
-        with _Launch("conv1x1_mfm_backward", gy.device):
+        with _Launch("conv1x1_mfm_backward", gy.device, work=4.0 * N * Cin * C * H * W, tensors=(gy, sel, gx)):
             st = _lib.load().advstep_conv1x1_mfm_backward_f32(gy.data_ptr(), sel.data_ptr(), weight.data_ptr(),
                                                               scale[0].data_ptr() if scale else None, gx.data_ptr(), N, Cin,
                                                               C, H * W, _stream(gy.device))
@@ -319,7 +319,7 @@ class _Conv3x3Mfm(torch.autograd.Function):
         gy = gy.contiguous()
         lib = _lib.load()
         gconv = torch.empty((N, 2 * C, H, W), dtype=gy.dtype, device=gy.device)
-        with _Launch("conv3x3_mfm_backward", gy.device):
+        with _Launch("conv3x3_mfm_backward", gy.device, tensors=(gy, sel, gconv)):
             st = lib.advstep_conv3x3_mfm_backward_f32(gy.data_ptr(), sel.data_ptr(), scale[0].data_ptr() if scale else None,
                                                       gconv.data_ptr(), N, C, H, W, _stream(gy.device))
         _lib.check(st, "advstep_conv3x3_mfm_backward_f32")
@@ -365,7 +365,7 @@ class _LstmLayer(torch.autograd.Function):
         out = torch.empty((T, B, D * H), dtype=x.dtype, device=x.device)
         gates = torch.empty((T, B, D, H4), dtype=x.dtype, device=x.device)
         cell = torch.empty((T, B, D, H), dtype=x.dtype, device=x.device)
-        with _Launch("lstm_forward", x.device):
+        with _Launch("lstm_forward", x.device, tensors=(gx, out, gates, cell)):
             st = _lib.load().advstep_lstm_forward_f32(gx.data_ptr(), w_hh.data_ptr(), out.data_ptr(), gates.data_ptr(),
                                                       cell.data_ptr(), T, B, D, H, _stream(x.device))
         _lib.check(st, "advstep_lstm_forward_f32")
@@ -382,7 +382,7 @@ class _LstmLayer(torch.autograd.Function):
         T, B, I, D, H = ctx.dims
         dout = dout.contiguous()
         dgx = torch.empty((T, B, D, 4 * H), dtype=dout.dtype, device=dout.device)
-        with _Launch("lstm_backward", dout.device):
+        with _Launch("lstm_backward", dout.device, tensors=(dout, gates, cell, dgx)):
             st = _lib.load().advstep_lstm_backward_f32(dout.data_ptr(), w_hh.data_ptr(), gates.data_ptr(),
                                                        cell.data_ptr(), dgx.data_ptr(), T, B, D, H, _stream(dout.device))
         _lib.check(st, "advstep_lstm_backward_f32")
@@ -417,20 +417,20 @@ class _LcnnTail(torch.autograd.Function):
             out = torch.empty((T, B, D * H), dtype=x4.dtype, device=dev)
             gates = torch.empty((T, B, D, H4), dtype=x4.dtype, device=dev)
             cell = torch.empty((T, B, D, H), dtype=x4.dtype, device=dev)
-            with _Launch("lstm_forward", dev):
+            with _Launch("lstm_forward", dev, tensors=(gx, out, gates, cell)):
                 s_ = lib.advstep_lstm_forward_f32(gx.data_ptr(), w_hh.data_ptr(), out.data_ptr(), gates.data_ptr(), cell.data_ptr(),
                                                   T, B, D, H, st)
             _lib.check(s_, "advstep_lstm_forward_f32")
             return out, gates, cell
 
         xt = torch.empty((T, B, F), dtype=x4.dtype, device=dev)
-        with _Launch("lcnn_tail_pack", dev):
+        with _Launch("lcnn_tail_pack", dev, tensors=(x4, xt)):
             s_ = lib.advstep_lcnn_tail_pack_f32(x4.data_ptr(), xt.data_ptr(), B, C, T, W, st)
         _lib.check(s_, "advstep_lcnn_tail_pack_f32")
         out1, gates1, cell1 = layer(xt, w_ih1, w_hh1, b1)
         out2, gates2, cell2 = layer(out1, w_ih2, w_hh2, b2)
         z = torch.empty((B, 1), dtype=x4.dtype, device=dev)
-        with _Launch("lcnn_tail_forward", dev):
+        with _Launch("lcnn_tail_forward", dev, tensors=(out2, xt)):
             s_ = lib.advstep_lcnn_tail_forward_f32(out2.data_ptr(), xt.data_ptr(), w_out.data_ptr(),
                                                    b_out.data_ptr() if b_out is not None else None, z.data_ptr(), T, B, F, st)
         _lib.check(s_, "advstep_lcnn_tail_forward_f32")
@@ -459,19 +459,19 @@ class _LcnnTail(torch.autograd.Function):
         # the mean's gradient: the same row for every frame — of the second layer's output and of the skip connection
         g0 = dz.reshape(B, 1) * w_over_t
         dgx2 = torch.empty((T, B, D, 4 * H), dtype=dz.dtype, device=dev)
-        with _Launch("lstm_backward", dev):
+        with _Launch("lstm_backward", dev, tensors=(gates2, cell2, dgx2)):
             s_ = lib.advstep_lstm_backward_bcast_f32(g0.data_ptr(), w_hh2.data_ptr(), gates2.data_ptr(), cell2.data_ptr(),
                                                      dgx2.data_ptr(), T, B, D, H, st)
         _lib.check(s_, "advstep_lstm_backward_bcast_f32")
         dout1 = torch.mm(dgx2.view(T * B, D * 4 * H), w_ih2)                     # (T B, F) = d(first layer's output)
         dgx1 = torch.empty((T, B, D, 4 * H), dtype=dz.dtype, device=dev)
-        with _Launch("lstm_backward", dev):
+        with _Launch("lstm_backward", dev, tensors=(dout1, gates1, cell1, dgx1)):
             s_ = lib.advstep_lstm_backward_f32(dout1.data_ptr(), w_hh1.data_ptr(), gates1.data_ptr(), cell1.data_ptr(),
                                                dgx1.data_ptr(), T, B, D, H, st)
         _lib.check(s_, "advstep_lstm_backward_f32")
         dxt = torch.mm(dgx1.view(T * B, D * 4 * H), w_ih1)
         dx4 = torch.empty((B, C, T, W), dtype=dz.dtype, device=dev)
-        with _Launch("lcnn_tail_unpack_add", dev):
+        with _Launch("lcnn_tail_unpack_add", dev, tensors=(dxt, dx4)):
             s_ = lib.advstep_lcnn_tail_unpack_add_f32(dxt.data_ptr(), g0.data_ptr(), dx4.data_ptr(), B, C, T, W, st)
         _lib.check(s_, "advstep_lcnn_tail_unpack_add_f32")
         return (dx4,) + (None,) * 8
@@ -503,7 +503,7 @@ class _GruLayer(torch.autograd.Function):
         gx = torch.addmm(b_ih, x.reshape(T * B, I), w_ih.t())            # one GEMM for all steps and directions
         out = torch.empty((T, B, D * H), dtype=x.dtype, device=x.device)
         saved = torch.empty((T, B, D, 4 * H), dtype=x.dtype, device=x.device)
-        with _Launch("gru_forward", x.device):
+        with _Launch("gru_forward", x.device, tensors=(gx, out, saved)):
             st = _lib.load().advstep_gru_forward_f32(gx.data_ptr(), w_hh.data_ptr(), b_hh.data_ptr(), out.data_ptr(),
                                                      saved.data_ptr(), T, B, D, H, _stream(x.device))
         _lib.check(st, "advstep_gru_forward_f32")
@@ -520,7 +520,7 @@ class _GruLayer(torch.autograd.Function):
         T, B, I, D, H = ctx.dims
         dout = dout.contiguous()
         dgx = torch.empty((T, B, D, 3 * H), dtype=dout.dtype, device=dout.device)
-        with _Launch("gru_backward", dout.device):
+        with _Launch("gru_backward", dout.device, tensors=(dout, saved, out, dgx)):
             st = _lib.load().advstep_gru_backward_f32(dout.data_ptr(), w_hh.data_ptr(), saved.data_ptr(), out.data_ptr(),
                                                       dgx.data_ptr(), T, B, D, H, _stream(dout.device))
         _lib.check(st, "advstep_gru_backward_f32")

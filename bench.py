@@ -66,6 +66,31 @@ MODEL_MATRIX_KERNELS = {
     2: ("resconv_forward", "resconv_pool2_forward", "resconv_pooled_grad"),
     3: (),        # RawNet3: library GEMMs (rocBLAS / hipBLASLt), no hand-written matrix-core kernel to price
 }
+# `roofline_step`: every hand-written launch of one step, grouped by what bounds it (entry-point prefixes of hip_ops /
+# lcnn_ops / frontend_ops / detector_ops launch names).  mfma: flop through the fp32 matrix cores; valu: flop on the vector
+# ALUs (packed fp32: the same 256 flop / clock / CU); hbm: the bytes of the operands each launch reads or writes once.
+VALU_F32_PEAK_TFLOPS = 157.3   # 256 CUs x 256 flop / clock (v_pk_fma_f32) x 2.4 GHz: the guide's FP32 vector figure
+STEP_FAMILIES = (
+    ("3x3 convolutions, Winograd F(2x2,3x3) on the matrix cores", "mfma",
+     ("conv3x3_mfm_pool2_forward", "conv3x3_mfm_pool2_backward", "conv3x3_mfm_forward", "conv3x3_backward_data",
+      "resconv_forward", "resconv_pool2_forward", "resconv_pooled_grad")),
+    ("first block 5x5 / few-channel 3x3 convolutions (vector ALU)", "valu",
+     ("conv5_mfm_pool2_forward", "conv5_mfm_pool2_backward", "conv3x3_fewin_forward", "conv3x3_fewout_grad")),
+    ("1x1 convolution + max-feature-map blocks", "hbm", ("conv1x1_mfm_forward", "conv1x1_mfm_backward")),
+    ("frontend: STFT (in-LDS FFT) + filterbank + dB + DCT, both directions", "hbm",
+     ("lfcc_forward", "lfcc_backward", "stft_frames", "stft_overlap_add", "stft_mel", "stft_mel_backward")),
+    ("recurrent layers (one workgroup per utterance and direction) + tail", "hbm",
+     ("lstm_forward", "lstm_backward", "gru_forward", "gru_backward", "lcnn_tail_pack", "lcnn_tail_forward",
+      "lcnn_tail_unpack_add")),
+    ("elementwise / pooling / selection kernels of the detector", "hbm",
+     ("mfm_forward", "mfm_backward", "mfm_pool2_forward", "mfm_pool2_backward", "conv3x3_mfm_backward", "affine_act_forward",
+      "affine_act_backward", "add_maxpool2_forward", "maxpool2_backward", "add_maxpool1d_forward", "maxpool1d_backward",
+      "gate_maxpool2_forward", "gate_maxpool2_backward", "weighted_stats_forward", "weighted_stats_backward",
+      "log_meannorm_forward", "log_meannorm_backward", "tail_pool1d_forward", "tail_pool1d_backward")),
+    ("attack step, random start, min-max, loss gradient", "hbm",
+     ("pgd_linf_step", "pgd_linf_init", "pgd_l2_step", "pgd_l2_init", "fgsm_step", "cw_adam_step", "cw_tanh_sqdist",
+      "cw_best_update", "cw_init_w", "minmax_normalize", "minmax_revert", "ce2_loss_grad")),
+)
 PROFILED = ("pgd_linf_step", "pgd_linf_init", "pgd_l2_step", "pgd_l2_init", "fgsm_step", "cw_adam_step",
             "cw_tanh_sqdist", "cw_best_update", "minmax_normalize", "minmax_revert", "ce2_loss_grad")
 
@@ -132,6 +157,43 @@ def cpu_baseline(config: int, threads: int, iterations: float = 0.0):
         return dict(fail, sample="timed out (900 s)")
 
 
+def through_loop(config: int, spec, B: int, device, warm: int = 4, timed: int = 16, workers: int = 3):
+    """Steady-state rate of the SHIPPED loop (evaluation.generate_attacks: DataLoader with `workers` worker processes,
+    pinned staging + side-stream upload one batch ahead, hipGraph replay of the attack iteration, scores kept on the device)
+    for the workload's first attack: utterances / second between a HIP event recorded when batch `warm` has been queued and
+    one when the last batch has, read after the loop's single end-of-run synchronisation
+    (reference: evaluate_models_on_adversarial_attacks.py:197-265)."""
+    import torch
+    from audio_deepfake_adversarial_attacks_amd.aa.aa_types import AttackEnum
+    from audio_deepfake_adversarial_attacks_amd.datasets.synthetic import SyntheticDetectionDataset
+    from audio_deepfake_adversarial_attacks_amd.evaluation import generate_attacks
+    from audio_deepfake_adversarial_attacks_amd.utils import set_seed
+
+    def cfg(model):
+        return {"data": {"seed": 42}, "checkpoint": {"path": ""}, "model": {"name": model[0], "parameters": dict(model[1])}}
+
+    member = spec["attacks"][0]
+    cls, params = AttackEnum[member].value
+    marks = {}
+
+    def queued(i):
+        if i in (warm - 1, warm + timed - 1):
+            marks[i] = torch.cuda.Event(enable_timing=True)
+            marks[i].record(torch.cuda.current_stream(device))
+
+    set_seed(42)
+    rep = generate_attacks([None, None, None], cfg(spec["target"]), str(device), attack_model_config=cfg(spec["attacked"]),
+                           attack_method=cls, attack_params=params, batch_size=B,
+                           dataset=SyntheticDetectionDataset(B * (warm + timed)), share_weights=spec["white_box"], shuffle=False,
+                           num_workers=workers, on_batch_queued=queued)
+    torch.cuda.synchronize()
+    ms = marks[warm - 1].elapsed_time(marks[warm + timed - 1])
+    return {"value": B * timed / (ms * 1e-3), "unit": "utterances/s", "ms_per_batch": ms / timed, "batches_timed": timed,
+            "batches_warm": warm, "dataloader_workers": workers, "attack": member, "accuracy": rep["adv_eval/accuracy"],
+            "what": "evaluation.generate_attacks end to end (collate in worker processes, H2D through pinned buffers on a side "
+                    "stream, hipGraph replay, one host sync at the end); HIP-event time between batch 4 and the last batch"}
+
+
 def live_traffic(entry_point: str, B: int):
     """HBM bytes per launch of the priced kernel MEASURED IN THIS RUN: two `rocprofv3 --pmc` passes (FETCH_SIZE, WRITE_SIZE:
     they do not fit one pass; --kernel-trace only, no other trace domain) over tools/traffic_probe.py — the same entry
@@ -154,10 +216,21 @@ def live_traffic(entry_point: str, B: int):
                 subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, timeout=150)
             paths = glob.glob(f"{tmp}/*/*/*counter_collection.csv") + glob.glob(f"{tmp}/*/*counter_collection.csv")
             row = hbm_traffic.reduce(paths, batch_override=B).get(entry_point)
+            # the same passes' kernel traces: the priced kernel's own duration by rocprofv3's clock (cold regime)
+            import csv
+            import re
+            pat, durs = hbm_traffic.ENTRY_POINTS[entry_point][0][0], []
+            for kt in glob.glob(f"{tmp}/*/*/*kernel_trace.csv") + glob.glob(f"{tmp}/*/*kernel_trace.csv"):
+                with open(kt, newline="") as f:
+                    durs += [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6 for r in csv.DictReader(f)
+                             if re.search(pat, r["Kernel_Name"])]
+            if row and durs:
+                row["rocprof_avg_launch_ms_cold"] = sum(durs) / len(durs)
     except (subprocess.TimeoutExpired, OSError, SystemExit, KeyError, ValueError) as exc:
         return None, f"live PMC pass failed: {exc!r}"
     if not row:
         return None, "live PMC pass produced no counter rows for this kernel"
+    live_traffic.rocprof_ms_cold = row.get("rocprof_avg_launch_ms_cold")
     return row["hbm_bytes_per_launch"], ("measured in this run: " + hbm_traffic.SOURCE + f"; {row['launches_averaged']} launches "
                                          f"of tools/traffic_probe.py --entry {entry_point} --batch {B}")
 
@@ -402,6 +475,47 @@ def main():
                                                 "tflops": round(sum(work[n]) / (sum(ms[n]) * 1e-3) / 1e12, 2)}
                                             for n in names if ms.get(n)},
                     }
+            # (2b) the WHOLE step by kernel family: one step with HIP events around every hand-written launch; what is not
+            #      bracketed (ATen / rocBLAS / hipFFT launches, gaps between launches) is the last row, by subtraction
+            hip_ops.start_profile("*")
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            timed_loop(args.warmup, args.warmup + 1)
+            e1.record()
+            ms_all, work_all, bytes_all = hip_ops.stop_profile(with_work="bytes")
+            step_ms_all = e0.elapsed_time(e1)
+            rows, covered, seen = [], 0.0, set()
+            for family, bound, names in STEP_FAMILIES:
+                n_launch = sum(len(ms_all.get(n, ())) for n in names)
+                if not n_launch:
+                    continue
+                seen.update(names)
+                raw = sum(sum(ms_all.get(n, ())) for n in names)
+                # an event pair with nothing between its records reads `empty_ms`: most of what a bracket adds to its kernel
+                net = sum(max(v - empty_ms, 0.0) for n in names for v in ms_all.get(n, ()))
+                amount = sum(sum((work_all if bound != "hbm" else bytes_all).get(n, ())) for n in names)
+                peak = {"mfma": MFMA_F32_PEAK_TFLOPS, "valu": VALU_F32_PEAK_TFLOPS, "hbm": HBM_PEAK_GBS}[bound]
+                achieved = amount / (net * 1e-3) / (1e9 if bound == "hbm" else 1e12) if net > 0 else 0.0
+                rows.append({"family": family, "bound": bound, "ms_per_step": round(net, 3), "ms_per_step_bracketed": round(raw, 3),
+                             "share_of_step": round(net / step_ms_all, 4), "launches": n_launch, "achieved": round(achieved, 2),
+                             "peak": peak, "unit": "GB/s" if bound == "hbm" else "TFLOP/s", "frac": round(achieved / peak, 4)})
+                covered += net
+            stray = {n: round(sum(v), 3) for n, v in ms_all.items() if n not in seen and v}
+            rows.append({"family": "not bracketed: ATen / rocBLAS / hipFFT launches, other hand-written launches, gaps between "
+                                   "launches", "bound": None, "ms_per_step": round(step_ms_all - covered, 3),
+                         "share_of_step": round(1.0 - covered / step_ms_all, 4), "other_hand_written_ms": stray})
+            line["roofline_step"] = {
+                "step_ms_profiled": round(step_ms_all, 3), "launches_bracketed": sum(len(v) for v in ms_all.values()),
+                "share_priced": round(covered / step_ms_all, 4),
+                "clock": "HIP events on the launch stream around every hand-written launch of ONE step after the timed region "
+                         "(the brackets cost the step a few percent, so shares are of this step's own duration); a row's "
+                         "ms_per_step = sum over its launches of (bracket - empty_event_pair_ms)",
+                "conventions": "mfma: Winograd products through the matrix cores (direct count / 2.25); valu: 2 flop per "
+                               "multiply-add of the direct convolution; hbm: bytes of the operands a launch reads or writes once",
+                "rows": rows}
+            # (2c) the loop the user runs: generate_attacks over a synthetic dataset with its DataLoader workers, staging stream and
+            #      hipGraph replay — HIP events after batch 4 and after the last batch, ONE host synchronisation at the end
+            line["through_loop"] = through_loop(args.config, spec, B, device)
             # (3) the priced kernel with its operands rotated past the 256 MiB Infinity Cache (the hot figure above runs on a
             #     132 MB working set that the cache holds): same clock, one event pair per launch
             sys.path.insert(0, str(ROOT / "tools"))
@@ -410,6 +524,15 @@ def main():
             line["roofline"]["avg_launch_ms_cold"] = cold_ms
             line["roofline"]["achieved_cold"] = launch_bytes / (cold_ms * 1e-3) / 1e9
             line["roofline"]["frac_cold"] = line["roofline"]["achieved_cold"] / HBM_PEAK_GBS
+            rp = getattr(live_traffic, "rocprof_ms_cold", None)
+            if rp:
+                line["roofline"]["rocprof_avg_launch_ms_cold"] = rp
+                line["roofline"]["frac_rocprof_cold"] = launch_bytes / (rp * 1e-3) / 1e9 / HBM_PEAK_GBS
+            line["roofline"]["which_is_hbm_honest"] = (
+                "frac_cold / frac_rocprof_cold: operands rotated past the 256 MiB Infinity Cache (HIP-event bracket / rocprofv3 "
+                "kernel-trace duration of the same launches).  `frac` is the in-loop event bracket on a 132 MB working set the "
+                "Infinity Cache partly serves; its kernel-trace counterpart (profiles/r04_bench_c*_step_summary.txt) can exceed "
+                "the HBM copy rate for that reason and is not an HBM figure")
         # CW stops early on its own cost (cw.py:107-110): report what it executed, per iteration, and price the CPU leg at the
         # iterations the GPU run executed
         cw_iters = len(kernel_ms.get("cw_adam_step", ())) / args.steps if args.config == 3 else 0.0
