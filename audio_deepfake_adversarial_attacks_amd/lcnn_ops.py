@@ -16,6 +16,13 @@ from . import _lib
 from .hip_ops import _Launch, _require, _stream
 
 
+def _gemm(fn, a2d: torch.Tensor, b2d: torch.Tensor, *lead):
+    """A library GEMM (rocBLAS through torch.addmm / torch.mm) under a launch bracket of its own, so bench.py's `roofline_step`
+    sees the recurrent layers' projections: a2d (M, K) x b2d (K, N), 2 M N K flop."""
+    with _Launch("rnn_projection_gemm", a2d.device, work=2.0 * a2d.shape[0] * a2d.shape[1] * b2d.shape[1]):
+        return fn(*lead, a2d, b2d)
+
+
 def _check_input(x: torch.Tensor, bias: Optional[torch.Tensor]):
     _require(x, "x")
     if x.dim() != 4 or x.shape[1] % 2 != 0:
@@ -361,7 +368,7 @@ class _LstmLayer(torch.autograd.Function):
         D, H4, H = w_hh.shape
         if H4 != 4 * H or tuple(w_ih.shape) != (D * H4, I) or bias.numel() != D * H4:
             raise ValueError("inconsistent LSTM parameter shapes")
-        gx = torch.addmm(bias, x.reshape(T * B, I), w_ih.t())            # one GEMM for all steps and directions
+        gx = _gemm(torch.addmm, x.reshape(T * B, I), w_ih.t(), bias)   # one GEMM for all steps and directions
         out = torch.empty((T, B, D * H), dtype=x.dtype, device=x.device)
         gates = torch.empty((T, B, D, H4), dtype=x.dtype, device=x.device)
         cell = torch.empty((T, B, D, H), dtype=x.dtype, device=x.device)
@@ -386,7 +393,7 @@ class _LstmLayer(torch.autograd.Function):
             st = _lib.load().advstep_lstm_backward_f32(dout.data_ptr(), w_hh.data_ptr(), gates.data_ptr(),
                                                        cell.data_ptr(), dgx.data_ptr(), T, B, D, H, _stream(dout.device))
         _lib.check(st, "advstep_lstm_backward_f32")
-        dx = torch.mm(dgx.view(T * B, D * 4 * H), w_ih).view(T, B, I)
+        dx = _gemm(torch.mm, dgx.view(T * B, D * 4 * H), w_ih).view(T, B, I)
         return dx, None, None, None
 
 
@@ -397,6 +404,25 @@ def lstm_supported(hidden_size: int) -> bool:
 def lstm_layer(x: torch.Tensor, w_ih: torch.Tensor, w_hh: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
     """x (T, B, I) -> (T, B, D*H) for one LSTM layer with D directions (parameters packed per direction)."""
     return _LstmLayer.apply(x.contiguous(), w_ih, w_hh, bias)
+
+class _IdKeyed:
+    """Weak table keyed by tensor IDENTITY (tensors hash by id but compare elementwise: WeakKeyDictionary cannot hold them)."""
+
+    def __init__(self):
+        self._rows = {}
+
+    def get(self, t):
+        row = self._rows.get(id(t))
+        return row[1] if row is not None and row[0]() is t else None
+
+    def __setitem__(self, t, value):
+        import weakref
+        key = id(t)
+        self._rows[key] = (weakref.ref(t, lambda _, k=key: self._rows.pop(k, None)), value)
+
+
+_OVER_T = _IdKeyed()
+
 
 class _LcnnTail(torch.autograd.Function):
     """Everything between LCNN's convolution trunk and its logit (src/models/lcnn.py:196-205) as one autograd node:
@@ -413,7 +439,7 @@ class _LcnnTail(torch.autograd.Function):
         st = _stream(dev)
 
         def layer(xin, w_ih, w_hh, bias):
-            gx = torch.addmm(bias, xin.view(T * B, -1), w_ih.t())
+            gx = _gemm(torch.addmm, xin.view(T * B, -1), w_ih.t(), bias)
             out = torch.empty((T, B, D * H), dtype=x4.dtype, device=dev)
             gates = torch.empty((T, B, D, H4), dtype=x4.dtype, device=dev)
             cell = torch.empty((T, B, D, H), dtype=x4.dtype, device=dev)
@@ -434,15 +460,13 @@ class _LcnnTail(torch.autograd.Function):
             s_ = lib.advstep_lcnn_tail_forward_f32(out2.data_ptr(), xt.data_ptr(), w_out.data_ptr(),
                                                    b_out.data_ptr() if b_out is not None else None, z.data_ptr(), T, B, F, st)
         _lib.check(s_, "advstep_lcnn_tail_forward_f32")
-        # w / T for the mean's gradient row: cached on the weight tensor (one launch per weight version, not per call)
-        cache = getattr(w_out, "_advstep_over_t", None)
+        # w / T for the mean's gradient row: one launch per weight version, not per call.  Kept in a module-level weak table
+        # (an attribute on the Parameter would be pickled by torch.save(model))
+        cache = _OVER_T.get(w_out)
         key = (w_out._version, w_out.data_ptr(), T)
         if cache is None or cache[0] != key:
-            cache = (key, (w_out.reshape(1, F) / T).contiguous())
-            try:
-                w_out._advstep_over_t = cache
-            except AttributeError:
-                pass
+            cache = (key, (w_out.detach().reshape(1, F) / T).contiguous())
+            _OVER_T[w_out] = cache
         ctx.save_for_backward(gates1, cell1, gates2, cell2, w_ih1, w_hh1, w_ih2, w_hh2, cache[1])
         ctx.dims = (B, C, T, W, D, H)
         return z
@@ -463,13 +487,13 @@ class _LcnnTail(torch.autograd.Function):
             s_ = lib.advstep_lstm_backward_bcast_f32(g0.data_ptr(), w_hh2.data_ptr(), gates2.data_ptr(), cell2.data_ptr(),
                                                      dgx2.data_ptr(), T, B, D, H, st)
         _lib.check(s_, "advstep_lstm_backward_bcast_f32")
-        dout1 = torch.mm(dgx2.view(T * B, D * 4 * H), w_ih2)                     # (T B, F) = d(first layer's output)
+        dout1 = _gemm(torch.mm, dgx2.view(T * B, D * 4 * H), w_ih2)                     # (T B, F) = d(first layer's output)
         dgx1 = torch.empty((T, B, D, 4 * H), dtype=dz.dtype, device=dev)
         with _Launch("lstm_backward", dev, tensors=(dout1, gates1, cell1, dgx1)):
             s_ = lib.advstep_lstm_backward_f32(dout1.data_ptr(), w_hh1.data_ptr(), gates1.data_ptr(), cell1.data_ptr(),
                                                dgx1.data_ptr(), T, B, D, H, st)
         _lib.check(s_, "advstep_lstm_backward_f32")
-        dxt = torch.mm(dgx1.view(T * B, D * 4 * H), w_ih1)
+        dxt = _gemm(torch.mm, dgx1.view(T * B, D * 4 * H), w_ih1)
         dx4 = torch.empty((B, C, T, W), dtype=dz.dtype, device=dev)
         with _Launch("lcnn_tail_unpack_add", dev, tensors=(dxt, dx4)):
             s_ = lib.advstep_lcnn_tail_unpack_add_f32(dxt.data_ptr(), g0.data_ptr(), dx4.data_ptr(), B, C, T, W, st)
@@ -500,7 +524,7 @@ class _GruLayer(torch.autograd.Function):
         D, H3, H = w_hh.shape
         if H3 != 3 * H or tuple(w_ih.shape) != (D * H3, I) or b_ih.numel() != D * H3 or b_hh.numel() != D * H3:
             raise ValueError("inconsistent GRU parameter shapes")
-        gx = torch.addmm(b_ih, x.reshape(T * B, I), w_ih.t())            # one GEMM for all steps and directions
+        gx = _gemm(torch.addmm, x.reshape(T * B, I), w_ih.t(), b_ih)   # one GEMM for all steps and directions
         out = torch.empty((T, B, D * H), dtype=x.dtype, device=x.device)
         saved = torch.empty((T, B, D, 4 * H), dtype=x.dtype, device=x.device)
         with _Launch("gru_forward", x.device, tensors=(gx, out, saved)):
@@ -524,7 +548,7 @@ class _GruLayer(torch.autograd.Function):
             st = _lib.load().advstep_gru_backward_f32(dout.data_ptr(), w_hh.data_ptr(), saved.data_ptr(), out.data_ptr(),
                                                       dgx.data_ptr(), T, B, D, H, _stream(dout.device))
         _lib.check(st, "advstep_gru_backward_f32")
-        dx = torch.mm(dgx.view(T * B, D * 3 * H), w_ih).view(T, B, I)
+        dx = _gemm(torch.mm, dgx.view(T * B, D * 3 * H), w_ih).view(T, B, I)
         return dx, None, None, None, None
 
 

@@ -246,6 +246,14 @@ class BaseLCNN(nn.Module):
         layers = list(self.m_before_pooling)
         if len(layers) != 2 or not all(isinstance(m, BLSTMLayer) for m in layers) or not isinstance(self.m_output_act, nn.Linear):
             return None
+        if hidden4.shape[2] == 0:          # an input too short for the trunk: the plain path's behaviour, not EINVAL
+            return None
+        # the node bypasses these modules' forward(): anyone listening on them (feature extraction, debugging hooks) must
+        # keep being called, so the plain path runs instead
+        bypassed = [self.m_before_pooling, self.m_output_act] + layers + [m.l_blstm for m in layers]
+        if any(m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or getattr(m, "_backward_pre_hooks", None)
+               for m in bypassed):
+            return None
         params = [p for m in layers for p in m.parameters()] + list(self.m_output_act.parameters())
         if torch.is_grad_enabled() and any(p.requires_grad for p in params):
             return None

@@ -79,6 +79,7 @@ STEP_FAMILIES = (
     ("1x1 convolution + max-feature-map blocks", "hbm", ("conv1x1_mfm_forward", "conv1x1_mfm_backward")),
     ("frontend: STFT (in-LDS FFT) + filterbank + dB + DCT, both directions", "hbm",
      ("lfcc_forward", "lfcc_backward", "stft_frames", "stft_overlap_add", "stft_mel", "stft_mel_backward")),
+    ("library GEMMs: the recurrent layers' input projections (rocBLAS)", "mfma", ("rnn_projection_gemm",)),
     ("recurrent layers (one workgroup per utterance and direction) + tail", "hbm",
      ("lstm_forward", "lstm_backward", "gru_forward", "gru_backward", "lcnn_tail_pack", "lcnn_tail_forward",
       "lcnn_tail_unpack_add")),
@@ -497,19 +498,20 @@ def main():
                 peak = {"mfma": MFMA_F32_PEAK_TFLOPS, "valu": VALU_F32_PEAK_TFLOPS, "hbm": HBM_PEAK_GBS}[bound]
                 achieved = amount / (net * 1e-3) / (1e9 if bound == "hbm" else 1e12) if net > 0 else 0.0
                 rows.append({"family": family, "bound": bound, "ms_per_step": round(net, 3), "ms_per_step_bracketed": round(raw, 3),
-                             "share_of_step": round(net / step_ms_all, 4), "launches": n_launch, "achieved": round(achieved, 2),
+                             "share_of_step": round(net / line["ms_per_step"], 4), "launches": n_launch, "achieved": round(achieved, 2),
                              "peak": peak, "unit": "GB/s" if bound == "hbm" else "TFLOP/s", "frac": round(achieved / peak, 4)})
                 covered += net
             stray = {n: round(sum(v), 3) for n, v in ms_all.items() if n not in seen and v}
-            rows.append({"family": "not bracketed: ATen / rocBLAS / hipFFT launches, other hand-written launches, gaps between "
-                                   "launches", "bound": None, "ms_per_step": round(step_ms_all - covered, 3),
-                         "share_of_step": round(1.0 - covered / step_ms_all, 4), "other_hand_written_ms": stray})
+            rows.append({"family": "not bracketed: ATen / hipFFT launches, other hand-written launches, gaps between launches",
+                         "bound": None, "ms_per_step": round(line["ms_per_step"] - covered, 3),
+                         "share_of_step": round(1.0 - covered / line["ms_per_step"], 4), "other_hand_written_ms": stray})
             line["roofline_step"] = {
                 "step_ms_profiled": round(step_ms_all, 3), "launches_bracketed": sum(len(v) for v in ms_all.values()),
-                "share_priced": round(covered / step_ms_all, 4),
-                "clock": "HIP events on the launch stream around every hand-written launch of ONE step after the timed region "
-                         "(the brackets cost the step a few percent, so shares are of this step's own duration); a row's "
-                         "ms_per_step = sum over its launches of (bracket - empty_event_pair_ms)",
+                "share_priced": round(covered / line["ms_per_step"], 4),
+                "clock": "HIP events on the launch stream around every hand-written launch (and the recurrent layers' library "
+                         "GEMMs) of ONE step after the timed region; a row's ms_per_step = sum over its launches of (bracket - "
+                         "empty_event_pair_ms), i.e. kernel time; shares are of the timed region's ms_per_step (the bracketed "
+                         "step itself runs `step_ms_profiled`: ~1 200 event pairs cost it ~10 %)",
                 "conventions": "mfma: Winograd products through the matrix cores (direct count / 2.25); valu: 2 flop per "
                                "multiply-add of the direct convolution; hbm: bytes of the operands a launch reads or writes once",
                 "rows": rows}

@@ -30,7 +30,10 @@
 extern "C" {
 #endif
 
-#define ADVSTEP_ABI_VERSION 1
+/* 2 (round 4): advstep_conv3x3_mfm_pool2_backward_f32 takes a mode-2 prepared U (a mode-1 U — version 1's contract — gives wrong
+ * gradients without an error) and needs 128 KB of LDS per workgroup for K > 64; advstep_row_workspace_bytes grew in round 3.
+ * A binding built against another version must refuse the library (the Python binding does, for every build it is pointed at). */
+#define ADVSTEP_ABI_VERSION 2
 
 enum {
     ADVSTEP_OK = 0,

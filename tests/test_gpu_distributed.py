@@ -1,5 +1,5 @@
-"""BASELINE.json configs[4] rehearsed on ONE device: two ranks (one process each, gloo — RCCL refuses two ranks on the
-same GPU) run the shipped sharded loop, and `bench.py --gpus 2` launches its own ranks.  What runs here is everything
+"""BASELINE.json configs[4] rehearsed on ONE device: two and EIGHT ranks (one process each, gloo — RCCL refuses two ranks on the
+same GPU) run the shipped sharded loop, and `bench.py --gpus 2 / 8` launches its own ranks.  What runs here is everything
 of the 8-GPU path except the RCCL transport itself: rank discovery, contiguous shards of every global batch, per-rank
 models / streams / workspaces, the end-of-run all-reduce + all-gather, rank 0's report (SURVEY.md section 8-e;
 replaces nn.DataParallel, reference evaluate_models_on_adversarial_attacks.py:163,167)."""
@@ -17,7 +17,15 @@ import torch
 pytestmark = pytest.mark.gpu
 
 ROOT = Path(__file__).resolve().parent.parent
-GLOBAL_BATCH, N_ITEMS, SEED = 16, 40, 42            # 2 complete global batches; 8 utterances are dropped (drop_last)
+SEED = 42
+
+
+def _sizes(world):
+    """(global batch, items): 8 utterances per rank and batch, 2 complete global batches; 8 utterances are dropped (drop_last)."""
+    return 8 * world, 16 * world + 8
+
+
+GLOBAL_BATCH, N_ITEMS = _sizes(2)
 ATTACK = {"eps": 0.003, "steps": 3, "random_start": False}   # deterministic: the shard replay needs no RNG agreement
 
 
@@ -32,13 +40,13 @@ def _config():
     return yaml.safe_load((ROOT / "configs" / "aa_evaluation" / "lcnn.yaml").read_text())
 
 
-def _evaluate(dataset, batch_size, shuffle):
+def _evaluate(dataset, batch_size, shuffle, device="cuda:0"):
     from audio_deepfake_adversarial_attacks_amd import torchattacks
     from audio_deepfake_adversarial_attacks_amd.evaluation import generate_attacks
     from audio_deepfake_adversarial_attacks_amd.utils import set_seed
     cfg = _config()
     set_seed(SEED)                                     # equal replicas on every rank and in the replay
-    return generate_attacks([None, None, None], cfg, "cuda:0", attack_model_config=cfg, attack_method=torchattacks.PGD,
+    return generate_attacks([None, None, None], cfg, device, attack_model_config=cfg, attack_method=torchattacks.PGD,
                             attack_params=dict(ATTACK), batch_size=batch_size, dataset=dataset, share_weights=True,
                             shuffle=shuffle, num_workers=0, return_scores=True)
 
@@ -50,24 +58,24 @@ def _worker(rank, world, port, out_dir, backend="gloo"):
     sys.path.insert(0, str(ROOT))
     from audio_deepfake_adversarial_attacks_amd.datasets.synthetic import SyntheticDetectionDataset
     from audio_deepfake_adversarial_attacks_amd.evaluation import ShardedBatchSampler
+    # nccl: one rank per device (RCCL over xGMI) — the rank's device is addressed by its index (the visibility variables cannot
+    # be changed once the HIP runtime is up in this process); gloo: every rank shares cuda:0
+    device = f"cuda:{rank}" if backend == "nccl" else "cuda:0"
+    torch.cuda.set_device(torch.device(device))
+    n_batch, n_items = _sizes(world)
+    data = SyntheticDetectionDataset(n_items)
     if backend == "nccl":
-        # one rank per device (RCCL over xGMI); `_evaluate` addresses "cuda:0": make the rank's device the visible one
-        os.environ["HIP_VISIBLE_DEVICES"] = str(rank)
-        os.environ["CUDA_VISIBLE_DEVICES"] = str(rank)
-    torch.cuda.set_device(0)
-    data = SyntheticDetectionDataset(N_ITEMS)
-    if backend == "nccl":
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda:0"))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
     else:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        sharded = _evaluate(data, GLOBAL_BATCH, shuffle=True)
+        sharded = _evaluate(data, n_batch, shuffle=True, device=device)
     finally:
         dist.destroy_process_group()
     # the same rows through the single-process loop: this rank's contiguous slices, batch = the shard size, so the
     # LFCC batch-wide dB floor sees the same rows as in the sharded run
-    mine = sum(ShardedBatchSampler(N_ITEMS, GLOBAL_BATCH, rank, world, shuffle=True, seed=SEED), [])
-    alone = _evaluate(Subset(data, mine), GLOBAL_BATCH // world, shuffle=False)
+    mine = sum(ShardedBatchSampler(n_items, n_batch, rank, world, shuffle=True, seed=SEED), [])
+    alone = _evaluate(Subset(data, mine), n_batch // world, shuffle=False, device=device)
     np.savez(Path(out_dir) / f"rank{rank}.npz", mine=np.array(mine),
              sharded_pred=sharded["scores"]["y_pred"], sharded_label=sharded["scores"]["y_pred_label"],
              sharded_y=sharded["scores"]["y"], alone_pred=alone["scores"]["y_pred"],
@@ -75,24 +83,36 @@ def _worker(rank, world, port, out_dir, backend="gloo"):
              report=json.dumps({k: v for k, v in sharded.items() if k != "scores"}))
 
 
-@pytest.mark.timeout(900)
-@pytest.mark.parametrize("backend", ["gloo", "nccl"])
-def test_two_ranks_on_one_gpu_equal_single_process_shards(cuda, tmp_path, backend):
-    """backend = "gloo": two ranks sharing the one device of this pool's boxes.  backend = "nccl": the same comparison with one
-    rank per DEVICE over RCCL — what the 8-GPU job runs; skipped where fewer than two devices are visible (every box of this
-    pool), so it costs nothing here and runs as soon as the suite meets a multi-GPU node."""
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("backend,world", [("gloo", 2), ("nccl", 2), ("gloo", 8)])
+def test_ranks_on_one_gpu_equal_single_process_shards(cuda, tmp_path, backend, world):
+    """backend = "gloo": `world` ranks sharing the one device of this pool's boxes — 2, and 8 = BASELINE.json configs[4]'s rank
+    count: launcher-free rendezvous, `ShardedBatchSampler`'s eight contiguous shards and `aggregate_across_ranks` run at the real
+    world size before they ever meet an 8-GPU node.  backend = "nccl": the same comparison with one rank per DEVICE over RCCL
+    — what the 8-GPU job runs; skipped where fewer than two devices are visible (every box of this pool)."""
     import torch.multiprocessing as mp
     from audio_deepfake_adversarial_attacks_amd import metrics
-    world = 2
+    from audio_deepfake_adversarial_attacks_amd.evaluation import shard_bounds
     if backend == "nccl" and torch.cuda.device_count() < world:
         pytest.skip("needs two HIP devices (RCCL refuses two ranks on one device)")
+    n_batch, n_items = _sizes(world)
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), backend), nprocs=world, join=True)
     r = [np.load(tmp_path / f"rank{k}.npz") for k in range(world)]
-    per_rank = (N_ITEMS // GLOBAL_BATCH) * GLOBAL_BATCH // world
-    assert not set(r[0]["mine"]) & set(r[1]["mine"]) and len(r[0]["mine"]) == len(r[1]["mine"]) == per_rank
+    per_rank = (n_items // n_batch) * n_batch // world
+    seen = set()
+    for k in range(world):                                  # `world` disjoint shards of equal size ...
+        assert len(r[k]["mine"]) == per_rank and not seen & set(r[k]["mine"].tolist())
+        seen |= set(r[k]["mine"].tolist())
+    # ... each of them rank k's CONTIGUOUS slice of every global batch (DataParallel's scatter, reference :163)
+    order = torch.randperm(n_items, generator=torch.Generator().manual_seed(SEED)).tolist()
+    for k in range(world):
+        lo, hi = shard_bounds(n_batch, k, world)
+        want = sum((order[b * n_batch + lo:b * n_batch + hi] for b in range(n_items // n_batch)), [])
+        assert r[k]["mine"].tolist() == want, f"rank {k} shard"
     # every rank ends with the same complete table and the same report
     for key in ("sharded_pred", "sharded_label", "sharded_y", "report"):
-        assert np.array_equal(r[0][key], r[1][key]), key
+        for k in range(1, world):
+            assert np.array_equal(r[0][key], r[k][key]), (key, k)
     # rank k's rows of the gathered table == a single-process run over rank k's shard, bit for bit
     for k in range(world):
         rows = slice(k * per_rank, (k + 1) * per_rank)
@@ -114,21 +134,24 @@ def test_two_ranks_on_one_gpu_equal_single_process_shards(cuda, tmp_path, backen
     assert got["num_total"] == world * per_rank
 
 
-@pytest.mark.timeout(900)
-def test_bench_launches_its_own_ranks(cuda):
-    """`python bench.py --gpus 2` with no launcher in the environment must start two ranks itself and print ONE JSON
-    line (rehearsed on one device: --share-device --backend gloo; on a >= 2-GPU node the defaults use RCCL)."""
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_launches_its_own_ranks(cuda, world):
+    """`python bench.py --gpus N` with no launcher in the environment must start N ranks itself and print ONE JSON
+    line (rehearsed on one device: --share-device --backend gloo; on a >= N-GPU node the defaults use RCCL).  N = 8 is
+    BASELINE.json configs[4]'s rank count (B = 8 per rank here instead of 128)."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--batch", "8",
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", str(world), "--steps", "1", "--warmup", "1", "--batch", "8",
            "--share-device", "--backend", "gloo"]
-    proc = subprocess.run(cmd, cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=800)
+    proc = subprocess.run(cmd, cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=1400)
     assert proc.returncode == 0, proc.stderr[-2000:]
     lines = [l for l in proc.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, proc.stdout[-2000:]
     line = json.loads(lines[0])
-    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 16 and line["scaling"] == "weak"
-    assert line["value"] == pytest.approx(16 / (line["ms_per_step"] * 1e-3), rel=1e-6)
+    assert line["n_gpus"] == world and line["config"]["global_batch"] == 8 * world and line["scaling"] == "weak"
+    assert line["value"] == pytest.approx(8 * world / (line["ms_per_step"] * 1e-3), rel=1e-6)
     assert "cpu_baseline" not in line and line["roofline"]["launches_timed"] == 40
+    assert f"{world} independent contiguous shards" in line["config"]["sharding"]
 
 
 # ---- RCCL itself, on the one device this pool has (VERDICT r02 item 6) ---------------------------------------------------------

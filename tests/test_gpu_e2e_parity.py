@@ -160,3 +160,76 @@ def test_pgd40_at_full_batch_with_sampled_oracle_checks(cuda, hip, lcnn, parity_
     assert torch.isfinite(preds).all()
     parity_record["configs1_full_batch_sampled_checks"] = {"batch": 128, "steps": 40, "checked": dict(ops.checked),
                                                            "launches": dict(ops.calls)}
+
+
+def test_pgdl2_40_at_full_batch_on_specrnet_with_sampled_oracle_checks(cuda, hip, parity_record):
+    """configs[2] at full size: SpecRNet + mel-spec, PGDL2-40 (eps 0.1, alpha 0.2, Philox start), B = 128 — exactly the
+    single-pass L2 kernels' residency limit (B x C = 2 048 workgroups) — through attack_batch's order of operations, launch
+    0, 10, 20, 30 of every kernel re-computed by the C oracle, no row handed to the repair kernel, and the ball / box
+    invariants of the result (pgdl2.py:64-88)."""
+    from audio_deepfake_adversarial_attacks_amd import torchattacks
+    from audio_deepfake_adversarial_attacks_amd.datasets.synthetic import synthetic_waveforms
+    from audio_deepfake_adversarial_attacks_amd.evaluation import score_batch
+    from oracle.checked_ops import CheckedOps
+    model = _model("specrnet", {"frontend_algorithm": ["mel_spec"], "input_channels": 2}, cuda)
+    x, y = synthetic_waveforms(128, seed=4321)
+    x, y = x.to(cuda), y.to(cuda)
+    ops = CheckedOps(hip, every=10)
+    atk = E.armed(torchattacks.PGDL2(model, eps=0.1, alpha=0.2, steps=40), ops)
+    torch.manual_seed(43)
+    x01, mn, mx = ops.to_minmax(x)
+    adv01 = atk(x01, y)
+    repaired = hip.pgd_l2_repaired_rows(adv01)
+    adv = ops.revert_minmax(adv01, mn, mx)
+    preds, labels = score_batch(model.eval(), adv)
+    assert ops.calls["pgd_l2_step"] == 40 and ops.checked["pgd_l2_step"] == 4
+    assert ops.checked["ce2_loss_grad"] == 4 and ops.checked["pgd_l2_init"] == 1
+    assert repaired == 0                                  # every row's norm exchange completed inside the launch
+    norms = (adv01 - x01).norm(dim=1)
+    assert norms.max().item() <= 0.1 * (1 + 1e-5) and adv01.min() >= 0 and adv01.max() <= 1
+    assert norms.min().item() > 0.05                      # 40 steps of alpha = 2 eps: every utterance sits near the sphere
+    assert torch.isfinite(preds).all()
+    parity_record["configs2_full_batch_sampled_checks"] = {"batch": 128, "steps": 40, "checked": dict(ops.checked),
+                                                           "launches": dict(ops.calls), "pgd_l2_repaired_rows": repaired,
+                                                           "l2_norm_max": norms.max().item(), "l2_norm_min": norms.min().item()}
+
+
+def test_fgsm_and_cw_at_full_batch_rawnet3_to_lcnn_with_sampled_oracle_checks(cuda, hip, lcnn, parity_record):
+    """configs[3] at full size: attack model RawNet3, target LCNN + LFCC, B = 64; FGSM (AttackEnum.FGSM: eps 0.0005) and CW
+    (AttackEnum.CW: c 1, 100 steps, lr 0.01, early stop on) with every 10th launch of every kernel re-computed by the C
+    oracle, and the invariants of both results (fgsm.py:59-60, cw.py:70-110)."""
+    from audio_deepfake_adversarial_attacks_amd import torchattacks
+    from audio_deepfake_adversarial_attacks_amd.aa.aa_types import AttackEnum
+    from audio_deepfake_adversarial_attacks_amd.datasets.synthetic import synthetic_waveforms
+    from audio_deepfake_adversarial_attacks_amd.evaluation import score_batch
+    from oracle.checked_ops import CheckedOps
+    raw = _model("rawnet3", {}, cuda)
+    x, y = synthetic_waveforms(64, seed=31)
+    x, y = x.to(cuda), y.to(cuda)
+    record = {"batch": 64}
+    for member in ("FGSM", "CW"):
+        cls, params = AttackEnum[member].value
+        ops = CheckedOps(hip, every=10)
+        atk = E.armed(cls(raw, **params), ops)
+        x01, mn, mx = ops.to_minmax(x)
+        adv01 = atk(x01, y)
+        adv = ops.revert_minmax(adv01, mn, mx)
+        preds, labels = score_batch(lcnn.eval(), adv)
+        assert adv01.min() >= 0 and adv01.max() <= 1 and torch.isfinite(adv).all() and torch.isfinite(preds).all()
+        if member == "FGSM":
+            assert ops.calls["fgsm_step"] + 0 == 1 and ops.checked["fgsm_step"] == 1
+            assert (adv01 - x01).abs().max().item() <= params["eps"] + 1e-7
+            assert ((adv01 - x01).abs() > 0).float().mean().item() > 0.99
+        else:
+            iters = ops.calls["cw_adam_step"]
+            # cw.py:107-110: the cost is compared every steps // 10 iterations, so the attack stops at 10 k + 1 or runs all 100
+            assert iters == params["steps"] or (iters % (params["steps"] // 10) == 1 and iters >= 11), iters
+            assert ops.checked["cw_adam_step"] == (iters + 9) // 10 and ops.checked["cw_tanh_sqdist"] >= 1
+            assert ops.calls["cw_best_update"] == iters
+            changed = (adv01 - x01).abs().amax(dim=1) > 1e-6
+            # the best-so-far blend only takes an iterate that fools the attacked model: changed rows moved by < 11 lr
+            assert (adv01 - x01).abs().max().item() <= iters * params["lr"]
+            record["cw_iterations"] = iters
+            record["cw_rows_changed"] = int(changed.sum())
+        record[member] = {"checked": dict(ops.checked), "launches": dict(ops.calls)}
+    parity_record["configs3_full_batch_sampled_checks"] = record

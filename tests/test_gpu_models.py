@@ -94,3 +94,28 @@ def test_rawnet3_device_path_matches_reference_body(cuda, golden, parity_record)
     parity_record["rawnet3_body_device_vs_reference"] = fig
     assert fig["logit_max_abs"] <= 5e-6, fig
     assert fig["grad_rel_l2"] <= 3.5e-4 and fig["grad_max_abs_over_max"] <= 4e-4, fig
+
+
+def test_lcnn_fused_tail_steps_aside_for_hooks(cuda):
+    """the one-node tail (lcnn_ops.lcnn_tail) bypasses m_before_pooling / m_output_act's forward(); a hook on any
+    of them must keep firing, so the plain modules run then — with the same logits (reference lcnn.py:196-205)."""
+    from audio_deepfake_adversarial_attacks_amd.models.models import get_model
+    torch.manual_seed(3)
+    model = get_model("lcnn", {"frontend_algorithm": ["lfcc"], "input_channels": 1}, str(cuda)).to(cuda).eval()
+    for p in model.parameters():
+        p.requires_grad_(False)
+    x = torch.randn(4, 64_600, device=cuda) * 0.05
+    fused = model(x)
+    seen = []
+    handle = model.m_output_act.register_forward_hook(lambda m, i, o: seen.append(o.detach().clone()))
+    try:
+        hooked = model(x)
+    finally:
+        handle.remove()
+    assert len(seen) == 1 and torch.equal(seen[0], hooked)
+    assert (hooked - fused).abs().max().item() <= 2e-6          # separate ops vs one node: summation order only
+    seen.clear()
+    again = model(x)
+    assert not seen and torch.equal(again, fused)               # hook gone: the fused node is back, bit for bit
+    # the weight's w / T row is cached off the Parameter: nothing extra is pickled with the model
+    assert not hasattr(model.m_output_act.weight, "_advstep_over_t")

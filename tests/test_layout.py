@@ -39,7 +39,7 @@ def test_header_symbols_are_exported_and_bound(lib):
 
 
 def test_library_basics_without_gpu(lib):
-    assert lib.advstep_abi_version() == 1
+    assert lib.advstep_abi_version() == 2
     assert lib.advstep_device_count() >= 0
     assert lib.advstep_status_string(0) == b"ok" and b"workspace" in lib.advstep_status_string(2)
     # 4 planes of ceil(T / 4096) floats per row (two partial-sum planes, or two planes of 8-byte granules) + one 32-bit
