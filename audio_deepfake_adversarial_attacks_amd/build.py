@@ -13,7 +13,8 @@ SOURCES = [PKG / "csrc" / "advstep.hip", PKG / "csrc" / "lcnn_mfm.hip", PKG / "c
            PKG / "csrc" / "lfcc.hip", PKG / "csrc" / "lfcc_stft.hip", PKG / "csrc" / "fab.hip",
            PKG / "csrc" / "wave_prep.hip", PKG / "csrc" / "specrnet_gru.hip", PKG / "csrc" / "detector_elem.hip",
            PKG / "csrc" / "detector_conv.hip"]
-HEADERS = [ROOT / "include" / "advstep.h", ROOT / "include" / "advstep_lcnn.h", ROOT / "include" / "advstep_frontend.h",
+HEADERS = [PKG / "csrc" / "stft_tables.inc",       # generated twiddle constants (tools/gen_stft_tables.py), #included by lfcc_stft.hip
+           ROOT / "include" / "advstep.h", ROOT / "include" / "advstep_lcnn.h", ROOT / "include" / "advstep_frontend.h",
            ROOT / "include" / "advstep_fab.h", ROOT / "include" / "advstep_dataset.h", ROOT / "include" / "advstep_detector.h"]
 LIB = PKG / "libadvstep.so"
 STAMP = PKG / "libadvstep.so.buildkey"   # git-ignored like the library; travels with it to the GPU box

@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "advstep_frontend.h"
 
@@ -53,6 +54,122 @@ __device__ __forceinline__ float max_nan(float a, float b) {
     if (a != a) return a;
     if (b != b) return b;
     return a > b ? a : b;
+}
+
+// ---- round 4: the 256-point transform as 16 x 16 with the 16-point transforms in REGISTERS --------------------------------
+// The radix-4 Stockham form below (still used by the mel-spec kernels) puts one frame on a wave, 4 points on a lane, and
+// every one of its 4 stages through LDS; its kernels are VALU-issue-bound (profiles/r03_model_kernel_pmc.txt: 72 % of the
+// duration is vector-ALU issue; 406 / 928 wave-instructions per frame forward / backward), and a third of those
+// instructions is LDS addressing and swizzling.  Here a frame lives on 16 lanes (a wave carries 4 frames), a lane holds
+// 16 complex points, and with n = 16 n1 + n2, k = k1 + 16 k2
+//     X[k1 + 16 k2] = sum_n2 W16^(n2 k2) . W256^(n2 k1) . [ sum_n1 x[16 n1 + n2] W16^(n1 k1) ]
+// lane n2 transforms its 16 points over n1 in registers, multiplies by its 15 lane-constant twiddles, the 16 x 16 block is
+// transposed through LDS ONCE (16 ds_write_b64 + 16 ds_read_b64 per lane, pitch 17: conflict-free), and lane k1 transforms
+// over n2: the spectrum ends up "lane k1, register k2".  The inverse runs the same two passes on that layout (first over
+// k2, twiddle, transpose, then over k1) and ends with sample n = lane + 16 r in register r — the layout the frame was
+// loaded in, so the window constants are shared.  ~95 wave-instructions per frame and transform instead of ~260.
+#include "stft_tables.inc"
+
+__device__ __forceinline__ float2 cmulf(float2 a, float2 b) {        // fused: 2 mul + 2 fma
+    return make_float2(fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x));
+}
+__device__ __forceinline__ float2 cmulc(float2 a, float cr, float ci) { return cmulf(a, make_float2(cr, ci)); }
+
+// 4-point transform of (a, b, c, d): forward y1 = (a - c) - i (b - d), inverse y1 = (a - c) + i (b - d)
+template <bool INV>
+__device__ __forceinline__ void fft4(float2 &a, float2 &b, float2 &c, float2 &d) {
+    const float2 s02 = cadd(a, c), d02 = csub(a, c), s13 = cadd(b, d), d13 = csub(b, d);
+    const float2 r = INV ? make_float2(-d13.y, d13.x) : make_float2(d13.y, -d13.x);
+    a = cadd(s02, s13);
+    b = cadd(d02, r);
+    c = csub(s02, s13);
+    d = csub(d02, r);
+}
+
+// 16-point transform in place, natural order in and out: x[4 n1 + n2] -> 4-point over n1 -> W16^(n2 k1) -> 4-point over n2.
+template <bool INV>
+__device__ __forceinline__ void fft16(float2 (&x)[16]) {
+    constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, H = 0.70710678118654752f;
+#pragma unroll
+    for (int n2 = 0; n2 < 4; ++n2) fft4<INV>(x[n2], x[4 + n2], x[8 + n2], x[12 + n2]);      // x[4 k1 + n2] = b[n2][k1]
+    // W16^m = (cos, -sin)(2 pi m / 16); INV: conjugate
+    const float sg = INV ? 1.0f : -1.0f;
+    x[4 + 1] = cmulc(x[4 + 1], C1, sg * S1);       // n2 = 1, k1 = 1: W^1
+    x[8 + 1] = cmulc(x[8 + 1], H, sg * H);         // n2 = 1, k1 = 2: W^2
+    x[12 + 1] = cmulc(x[12 + 1], S1, sg * C1);     // n2 = 1, k1 = 3: W^3
+    x[4 + 2] = cmulc(x[4 + 2], H, sg * H);         // n2 = 2, k1 = 1: W^2
+    x[8 + 2] = INV ? make_float2(-x[8 + 2].y, x[8 + 2].x) : make_float2(x[8 + 2].y, -x[8 + 2].x);   // W^4 = -i (forward)
+    x[12 + 2] = cmulc(x[12 + 2], -H, sg * H);      // n2 = 2, k1 = 3: W^6
+    x[4 + 3] = cmulc(x[4 + 3], S1, sg * C1);       // n2 = 3, k1 = 1: W^3
+    x[8 + 3] = cmulc(x[8 + 3], -H, sg * H);        // n2 = 3, k1 = 2: W^6
+    x[12 + 3] = cmulc(x[12 + 3], -C1, -sg * S1);   // n2 = 3, k1 = 3: W^9
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1) fft4<INV>(x[4 * k1], x[4 * k1 + 1], x[4 * k1 + 2], x[4 * k1 + 3]);   // -> y[k1 + 4 k2] at x[4 k1 + k2]
+    // un-transpose the 4 x 4 block: y[k1 + 4 k2] sits at x[4 k1 + k2]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = i + 1; j < 4; ++j) {
+            const float2 t = x[4 * i + j];
+            x[4 * i + j] = x[4 * j + i];
+            x[4 * j + i] = t;
+        }
+}
+
+// An opaque copy of a lane index: loads from the constant tables indexed with it cannot be issued before this point (they are
+// invariant loads, which hipcc otherwise hoists to the top of the loop body and holds in registers across everything)
+__device__ __forceinline__ int here(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+// "These 16 values are complete HERE": an empty asm every one of them passes through, with a memory clobber.  The loads of the
+// next phase cannot be issued above it and the arithmetic producing the values cannot sink below it — without it hipcc overlaps
+// a phase's loads with the previous phase's arithmetic and the live set of the two (up to 180 registers) costs a wave of occupancy.
+__device__ __forceinline__ void phase_done(float2 (&x)[16]) {
+    asm volatile("" : "+v"(x[0].x), "+v"(x[0].y), "+v"(x[1].x), "+v"(x[1].y), "+v"(x[2].x), "+v"(x[2].y), "+v"(x[3].x), "+v"(x[3].y),
+                      "+v"(x[4].x), "+v"(x[4].y), "+v"(x[5].x), "+v"(x[5].y), "+v"(x[6].x), "+v"(x[6].y), "+v"(x[7].x), "+v"(x[7].y)
+                 :: "memory");
+    asm volatile("" : "+v"(x[8].x), "+v"(x[8].y), "+v"(x[9].x), "+v"(x[9].y), "+v"(x[10].x), "+v"(x[10].y), "+v"(x[11].x), "+v"(x[11].y),
+                      "+v"(x[12].x), "+v"(x[12].y), "+v"(x[13].x), "+v"(x[13].y), "+v"(x[14].x), "+v"(x[14].y), "+v"(x[15].x), "+v"(x[15].y)
+                 :: "memory");
+}
+
+template <int BASE>
+__device__ __forceinline__ void half_done(float2 (&x)[16]) {       // the same for x[BASE .. BASE + 7]
+    asm volatile("" : "+v"(x[BASE].x), "+v"(x[BASE].y), "+v"(x[BASE + 1].x), "+v"(x[BASE + 1].y), "+v"(x[BASE + 2].x), "+v"(x[BASE + 2].y),
+                      "+v"(x[BASE + 3].x), "+v"(x[BASE + 3].y), "+v"(x[BASE + 4].x), "+v"(x[BASE + 4].y), "+v"(x[BASE + 5].x),
+                      "+v"(x[BASE + 5].y), "+v"(x[BASE + 6].x), "+v"(x[BASE + 6].y), "+v"(x[BASE + 7].x), "+v"(x[BASE + 7].y)
+                 :: "memory");
+}
+
+constexpr int kPitch = 17;                       // float2 slots per row of a frame's 16 x 16 exchange block
+constexpr int kFrameSlots = 16 * kPitch;         // 272 float2 per frame (also holds a frame's 512 floats / 257 bins)
+constexpr int kGroup = 4;                        // frames per wave at a time (16 lanes each)
+
+// LDS-only ordering inside a wave (its LDS instructions execute in order; only the compiler and the counter must agree)
+__device__ __forceinline__ void lds_wave_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// 256-point transform of the wave's 4 frames.  Forward: in x[r] = z[16 r + l] (l = lane & 15), out x[r] = Z[l + 16 r].
+// Inverse: in x[r] = Z[l + 16 r], out x[r] = z[l + 16 r] (unnormalised).  `blk`: the frame's kFrameSlots float2 of LDS.
+template <bool INV>
+__device__ __forceinline__ void fft256_reg(float2 (&x)[16], const float2 *twl, float2 *blk, int l) {
+    fft16<INV>(x);
+    phase_done(x);
+    // W256^(l j), j = 1 .. 15: row l of the workgroup's 16 x 16 table in LDS (30 registers per lane if kept: they cost a wave
+    // of occupancy; the reads ride under the first 16-point transform)
+#pragma unroll
+    for (int j = 1; j < 16; ++j) {
+        const float2 t = twl[l * kPitch + j];
+        x[j] = cmulf(x[j], INV ? conjf2(t) : t);
+    }
+    lds_wave_fence();                            // whatever the caller last read from `blk` has been delivered
+#pragma unroll
+    for (int j = 0; j < 16; ++j) blk[j * kPitch + l] = x[j];
+    lds_wave_fence();
+#pragma unroll
+    for (int j = 0; j < 16; ++j) x[j] = blk[l * kPitch + j];
+    fft16<INV>(x);
 }
 
 // 256-point complex FFT of one wave's frame, radix 4, Stockham autosort: 4 stages ping-ponging between `a` and `b`
@@ -154,28 +271,18 @@ struct Lds {
     float red[kWavesPerBlock];
 };
 
-// twiddle tables (device global, written once per process by the first launch): [0, 252) the per-stage tables,
-// [256, 512) exp(-2 pi i k / 512)
-__device__ float2 g_twiddles[2 * kN];
-
-__global__ void stft_twiddle_kernel() {
-    const int m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= 2 * kN) return;
-    double ang = 0.0;
-    if (m >= kN) {
-        ang = -2.0 * M_PI * (m - kN) / 512.0;
-    } else if (m < kStageTw) {
-        const int stage = m < 12 ? 1 : (m < 60 ? 2 : 3), base = stage == 1 ? 0 : (stage == 2 ? 12 : 60), Ns = 1 << (2 * stage);
-        const int t = (m - base) / Ns + 1, k = (m - base) % Ns;
-        ang = -2.0 * M_PI * t * k / (4.0 * Ns);
-    }
-    g_twiddles[m] = make_float2((float)cos(ang), (float)sin(ang));
+// The radix-4 path's per-stage tables, from the compile-time constants (round 4: no device global, no first-launch fill):
+// stage s = 1, 2, 3 (Ns = 4^s): exp(-2 pi i t k / (4 Ns)) = W256^(t k 64 / Ns)
+__device__ __forceinline__ float2 stage_twiddle(int m) {
+    const int stage = m < 12 ? 1 : (m < 60 ? 2 : 3), base = stage == 1 ? 0 : (stage == 2 ? 12 : 60), Ns = 1 << (2 * stage);
+    const int t = (m - base) / Ns + 1, k = (m - base) % Ns;
+    return kTw256[(t * k * (64 / Ns)) & 255];
 }
 
 __device__ __forceinline__ void fill_twiddles(Lds &L) {
     for (int m = threadIdx.x; m < kN; m += kThreads) {
-        if (m < kStageTw) L.tw[m] = g_twiddles[m];
-        L.tw512[m] = g_twiddles[kN + m];
+        if (m < kStageTw) L.tw[m] = stage_twiddle(m);
+        L.tw512[m] = kTw512[m];
     }
 }
 
@@ -279,8 +386,13 @@ __device__ __forceinline__ void spectrum_grad_to_frame(Lds &L, int wave, int lan
 // Overlap-add of a workgroup's windowed frame gradients (dframe) into dx: every sample the frames touch is summed over
 // (positions that read it) x (frames) in a fixed order; positions are padded coordinates p = q + nfft/2.  Reflections
 // only exist next to the two ends of the signal.
-__device__ __forceinline__ void overlap_add_block(const float (*dframe)[kNfft], float *__restrict__ dxb, int f_base, int NF,
-                                                  int hop, int T) {
+template <int STRIDE>
+__device__ __attribute__((noinline)) void overlap_add_frames_cold(const float *dframe, float *__restrict__ dxb, int f_base, int NF, int hop,
+                                                                  int T, int tid, int nthreads);
+
+template <int STRIDE>
+__device__ __forceinline__ void overlap_add_frames(const float *dframe, float *__restrict__ dxb, int f_base, int NF, int hop, int T,
+                                                   int tid, int nthreads) {
     const int p_lo = f_base * hop;                                          // first padded position of the first frame
     const int frames_here = (NF - f_base) < kFramesPerBlockBwd ? (NF - f_base) : kFramesPerBlockBwd;
     const int p_hi = p_lo + (frames_here - 1) * hop + kNfft;                // one past the last
@@ -289,12 +401,12 @@ __device__ __forceinline__ void overlap_add_block(const float (*dframe)[kNfft], 
 #pragma unroll
         for (int fl = 0; fl < kFramesPerBlockBwd; ++fl) {
             const int n = p - p_lo - fl * hop;
-            if (fl < frames_here && n >= 0 && n < kNfft) acc += dframe[fl][n];
+            if (fl < frames_here && n >= 0 && n < kNfft) acc += dframe[fl * STRIDE + n];
         }
     };
     const bool near_left = p_lo < 2 * kN, near_right = p_hi > T;            // wave-uniform, almost always false
     const int t_first = p_lo - kN, span_all = p_hi - p_lo;
-    for (int i = threadIdx.x; i < span_all; i += kThreads) {
+    for (int i = tid; i < span_all; i += nthreads) {
         const int t = t_first + i;
         if (t < 0 || t >= T) continue;            // padded positions outside the signal are reached by reflection below
         float acc = 0.0f;
@@ -306,7 +418,7 @@ __device__ __forceinline__ void overlap_add_block(const float (*dframe)[kNfft], 
     if (!(near_left || near_right)) return;
     // samples reached ONLY through a reflection from this workgroup's range (their direct position belongs to another
     // workgroup's range or to none): left edge t = pad - p for p < pad, right edge t = 2 (T - 1) - (p - pad) for p - pad >= T
-    for (int i = threadIdx.x; i < span_all; i += kThreads) {
+    for (int i = tid; i < span_all; i += nthreads) {
         const int p = p_lo + i, q = p - kN;
         int t = -1;
         if (q < 0) t = -q;
@@ -318,6 +430,18 @@ __device__ __forceinline__ void overlap_add_block(const float (*dframe)[kNfft], 
         add_from(p, acc);
         if (acc != 0.0f) atomicAdd(dxb + t, acc);
     }
+}
+
+__device__ __forceinline__ void overlap_add_block(const float (*dframe)[kNfft], float *__restrict__ dxb, int f_base, int NF,
+                                                  int hop, int T) {
+    overlap_add_frames<kNfft>(&dframe[0][0], dxb, f_base, NF, hop, T, threadIdx.x, kThreads);
+}
+
+// the same as a real call: the first / last groups of an utterance only, kept out of the hot kernel's register allocation
+template <int STRIDE>
+__device__ __attribute__((noinline)) void overlap_add_frames_cold(const float *dframe, float *__restrict__ dxb, int f_base, int NF, int hop,
+                                                                  int T, int tid, int nthreads) {
+    overlap_add_frames<STRIDE>(dframe, dxb, f_base, NF, hop, T, tid, nthreads);
 }
 
 template <int SPAN_CAP>
@@ -348,7 +472,7 @@ __global__ __launch_bounds__(kThreads) void stft_bands_backward_kernel(const flo
         static_assert(kN == kThreads, "one twiddle pair per thread");
         constexpr int kWIt = (kBins * SPAN_CAP + kThreads - 1) / kThreads;
         const int m = threadIdx.x, nw = kBins * span_t;
-        const float2 t0 = g_twiddles[m < kStageTw ? m : 0], t1 = g_twiddles[kN + m];
+        const float2 t0 = stage_twiddle(m < kStageTw ? m : 0), t1 = kTw512[m];
         const int32_t s0 = fbt_start[m], s1 = fbt_start[kThreads + (m < kBins - kThreads ? m : 0)];
         float wq[kWIt];
 #pragma unroll
@@ -409,6 +533,367 @@ __global__ __launch_bounds__(kThreads) void stft_bands_backward_kernel(const flo
     }
     __syncthreads();   // all frames' windowed gradients are in LDS
     overlap_add_block(S.dframe, dx + b * T, f_base, NF, hop, T);
+}
+
+// ---- round 4: the LFCC pair on the register-resident transform -----------------------------------------------------------
+constexpr int kGroupsPerWave = 2;                                                   // 4-frame groups a wave works through
+constexpr int kBandsFramesPerBlock = kWavesPerBlock * kGroupsPerWave * kGroup;     // 32 consecutive frames per workgroup
+
+struct LdsReg {
+    float2 blk[kWavesPerBlock][kGroup][kFrameSlots];   // per wave and frame: exchange block / 256-vector / 512 floats
+    float2 twl[16 * kPitch];                           // [l][j] = W256^(l j), rows at pitch 17 (conflict-free)
+    float red[kWavesPerBlock];
+};
+// (the window and exp(-2 pi i k / 512) are read from global memory where they are used: both are 2 KB, L1-resident, and
+// keeping them out of LDS is what lets four workgroups share a CU)
+
+__device__ __forceinline__ void fill_reg_tables(LdsReg &S) {
+    for (int m = threadIdx.x; m < kN; m += kThreads) S.twl[(m >> 4) * kPitch + (m & 15)] = kTw256[((m >> 4) * (m & 15)) & 255];
+}
+
+// x[r] = (w[2n] x[q + 2n], w[2n + 1] x[q + 2n + 1]),  n = 16 r + l,  q = f hop - 256 (reflect padding at the ends)
+__device__ __forceinline__ void load_frame_reg(const float *__restrict__ xb, const float2 *__restrict__ win2, int T, int f, int hop,
+                                               float2 (&x)[16], int l) {
+    const int q_first = f * hop - kN;
+    if (q_first >= 0 && q_first + kNfft <= T && ((q_first & 1) == 0) && ((reinterpret_cast<uintptr_t>(xb) & 7u) == 0)) {
+        const float2 *x2 = reinterpret_cast<const float2 *>(xb + q_first);
+        float2 v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = x2[16 * r + l];          // 16 requests in flight
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float2 wv = win2[16 * r + l];
+            x[r] = make_float2(wv.x * v[r].x, wv.y * v[r].y);
+        }
+        return;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int n = 16 * r + l;
+        int q0 = q_first + 2 * n, q1 = q0 + 1;
+        q0 = q0 < 0 ? -q0 : q0;
+        q0 = q0 >= T ? 2 * (T - 1) - q0 : q0;
+        q1 = q1 < 0 ? -q1 : q1;
+        q1 = q1 >= T ? 2 * (T - 1) - q1 : q1;
+        const float2 wv = win2[n];
+        x[r] = make_float2(wv.x * xb[q0], wv.y * xb[q1]);
+    }
+}
+
+// A frame's 256-vector in its block: element k = l + 16 r (lane l, register r) at slot 17 r + l; the elements of lane 0 are
+// stored a second time in the spare 17th column of the row before (element 16 r at slot 17 (r - 1) + 16, element 0 at
+// 17 . 15 + 16), so that EVERY lane finds its mirror element (N - k) mod N at slot 17 (15 - r) + (16 - l): one lane-constant
+// base and compile-time offsets, no index arithmetic.
+__device__ __forceinline__ void park_vector(float2 *blk, const float2 (&x)[16], int l) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) blk[r * kPitch + l] = x[r];
+    if (l == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) blk[((r + 15) & 15) * kPitch + 16] = x[r];
+    }
+}
+__device__ __forceinline__ float2 mirror_of(const float2 *blk, int r, int l) { return blk[(15 - r) * kPitch + (16 - l)]; }
+
+// Z (the transform of the packed frame, lane l register r = Z[l + 16 r]) -> 2 X[l + 16 r] in place and 2 X[256] (real) in `nyq`
+// (meaningful on lane l == 0):  2 X[k] = (Z[k] + Z*[N - k]) + W512^k . (-i) (Z[k] - Z*[N - k]).  The factor 2 of the real-input
+// un-packing is left in: the forward folds 1/4 into its filterbank weights, the backward 1/2 into its bin coefficients.
+__device__ __forceinline__ void unpack_real_reg(float2 (&x)[16], float &nyq, float2 *blk, int l) {
+    lds_wave_fence();
+    park_vector(blk, x, l);
+    lds_wave_fence();
+    nyq = 2.0f * (x[0].x - x[0].y);
+    const int lt = here(l);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        if (r == 8) half_done<0>(x);               // two batches of 8 mirror + 8 table reads, not one of 16 + 16
+        const float2 zc = conjf2(mirror_of(blk, r, l));
+        const float2 e = cadd(x[r], zc), d = csub(x[r], zc);
+        x[r] = cadd(e, cmulf(kTw512[lt + 16 * r], make_float2(d.y, -d.x)));
+    }
+}
+
+constexpr int kRegSpan = 4;                    // taps per band the register-FFT forward kernel takes (the linear bank: 3)
+
+struct LdsRegFwd {
+    LdsReg c;
+    float fbw[kMaxBands * kRegSpan];           // [m][j], 0 beyond a band's run, beyond `span` and for m >= M
+    int32_t fbs[kMaxBands];
+};
+
+// grid (ceil(NF / 32), B); span <= kRegSpan, M <= kMaxBands
+__global__ __launch_bounds__(kThreads) void stft_bands_reg_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                                  const int32_t *__restrict__ fb_start,
+                                                                  const float *__restrict__ fb_w, int span,
+                                                                  float *__restrict__ band_db, float *__restrict__ bmax, int T,
+                                                                  int NF, int hop, int M) {
+    __shared__ LdsRegFwd SF;
+    LdsReg &S = SF.c;
+    fill_reg_tables(S);
+    for (int i = threadIdx.x; i < kMaxBands * kRegSpan; i += kThreads) {
+        const int m = i / kRegSpan, j = i % kRegSpan;
+        SF.fbw[i] = (m < M && j < span) ? 0.25f * fb_w[m * span + j] : 0.0f;      // |2 X|^2 / 4
+    }
+    for (int m = threadIdx.x; m < kMaxBands; m += kThreads) SF.fbs[m] = m < M ? fb_start[m] : 0;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, fs = lane >> 4, l = lane & 15;
+    __syncthreads();
+    const int64_t b = blockIdx.y;
+    float2 *blk = S.blk[wave][fs];
+    float vmax = -INFINITY;
+    for (int g = 0; g < kGroupsPerWave; ++g) {
+        const int f0 = blockIdx.x * kBandsFramesPerBlock + (wave * kGroupsPerWave + g) * kGroup;
+        if (f0 >= NF) break;                                   // wave-uniform
+        const int f = f0 + fs;
+        const bool live = f < NF;
+        // (the window and exp(-2 pi i k / 512) values a lane reads are the same for every group: they are indexed through
+        // here(), or hipcc hoists them out of this loop into ~64 registers per lane — a wave of occupancy)
+        float2 xr[16];
+        load_frame_reg(x + b * T, reinterpret_cast<const float2 *>(w), T, live ? f : NF - 1, hop, xr, here(l));
+        fft256_reg<false>(xr, S.twl, blk, l);
+        float nyq;
+        unpack_real_reg(xr, nyq, blk, l);
+        phase_done(xr);
+        // power spectrum -> the frame's 257 floats (every lane's reads of the 256-vector were issued before these writes);
+        // entries 257 .. 259 are zeroed: a band's padded taps may reach them (with weight 0)
+        float *pw = reinterpret_cast<float *>(blk);
+        lds_wave_fence();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pw[l + 16 * r] = fmaf(xr[r].x, xr[r].x, xr[r].y * xr[r].y);
+        if (l == 0) pw[kN] = nyq * nyq;
+        if (l >= 1 && l <= kRegSpan) pw[kN + l] = 0.0f;
+        lds_wave_fence();
+        // bands l, l + 16, ..., l + 112 of this lane's frame: starts, then weights and bins, each batch of reads in flight at once
+        float *row = band_db + (b * NF + (live ? f : NF - 1)) * M;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            int k0[4];
+            float wt[4][kRegSpan], pv[4][kRegSpan];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) k0[i] = SF.fbs[l + 16 * (4 * half + i)];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < kRegSpan; ++j) {
+                    wt[i][j] = SF.fbw[(l + 16 * (4 * half + i)) * kRegSpan + j];
+                    pv[i][j] = pw[k0[i] + j];
+                }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = l + 16 * (4 * half + i);
+                float band = 0.0f;
+#pragma unroll
+                for (int j = 0; j < kRegSpan; ++j) band = fmaf(wt[i][j], pv[i][j], band);
+                // 10 log10(v) = 3.0103 log2(v): the hardware log2 (1 ulp) keeps the dB value within 1e-6 relative
+                const float db = 3.010299956639812f * __log2f(band > kAmin ? band : (band != band ? band : kAmin));
+                if (live && m < M) {
+                    row[m] = db;
+                    vmax = max_nan(vmax, db);
+                }
+            }
+        }
+        lds_wave_fence();                                      // pw is rewritten by the next group's exchange
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) vmax = max_nan(vmax, __shfl_xor(vmax, off, 64));
+    if (lane == 0) S.red[wave] = vmax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float r = S.red[0];
+        for (int i = 1; i < kWavesPerBlock; ++i) r = max_nan(r, S.red[i]);
+        bmax[b * gridDim.x + blockIdx.x] = r;
+    }
+}
+
+// The overlap-add of a wave's 4 consecutive frames when no reflection is involved (all but the first and last groups of an
+// utterance): sample i of the 3 hop + 512 = 992 the frames cover is the sum of dframe[fl][i - fl hop] over the frames that reach
+// it, in frame order.  HOP = 160 is a compile-time constant so that, fully unrolled, most (64-sample slice, frame) pairs are
+// decided statically: all 64 lanes read, or none do; only the slices a frame's ends cut need a per-lane test.
+// Who else touches a sample: [0, 352) the group before, [640, 992) the group after (4 hops = 640 = ten slices), [352, 640)
+// nobody.  A wave works through consecutive groups, so the last 352 sums of a group stay in registers (`carry`, same lane, slice
+// j - 10) and are added to the next group's first 352, which are then complete: plain stores.  Only a wave's first and last
+// group meet other waves' sums, with one float atomic per sample onto the zeroed dx (two operands: commutative, bit-reproducible).
+// L2 float atomics were a quarter of this kernel (1 M lane-atomics per XCD and launch at one group per wave): 248 -> 44 per frame.
+template <int STRIDE>
+__device__ __forceinline__ void overlap_add_interior(const float *df, float *__restrict__ out, int lane, float (&carry)[6],
+                                                     bool carry_in, bool carry_out) {
+    constexpr int HOP = 160, kSpan = 3 * HOP + kNfft, kShared = kNfft - HOP;       // 992, 352
+    static_assert(4 * HOP == 640 && kSpan <= 16 * 64, "slices");
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        if (j % 4 == 0) lds_wave_fence();          // four slices' reads in flight at a time (16 would cost ~40 registers)
+        float acc = 0.0f;
+#pragma unroll
+        for (int fl = 0; fl < 4; ++fl) {
+            const int lo = HOP * fl - 64 * j, hi = lo + kNfft;         // lanes [lo, hi) of this slice lie inside frame fl
+            if (hi <= 0 || lo >= 64) continue;
+            if (lo <= 0 && hi >= 64) {
+                acc += df[fl * STRIDE + lane - lo];
+            } else {
+                const int n = lane - lo;
+                if ((unsigned)n < (unsigned)kNfft) acc += df[fl * STRIDE + n];
+            }
+        }
+        const int i = lane + 64 * j;
+        if (j < 6) {                               // slices 0 .. 5: [0, 352) shared with the group before, [352, 384) nobody's
+            const bool shared = i < kShared;
+            if (carry_in) {
+                out[i] = shared ? acc + carry[j] : acc;
+            } else if (j < 5) {
+                atomicAdd(out + i, acc);
+            } else {
+                if (shared) atomicAdd(out + i, acc);
+                else out[i] = acc;
+            }
+        } else if (j < 10) {                       // [384, 640): nobody else's
+            out[i] = acc;
+        } else {                                   // [640, 992): shared with the group after
+            if (carry_out) carry[j - 10] = acc;
+            else if (i < kSpan) atomicAdd(out + i, acc);
+        }
+    }
+}
+
+template <int SPAN_CAP>
+struct LdsRegBwd {
+    LdsReg c;
+    float fbt_w[(kBins + 1) * SPAN_CAP];       // [k][j], 0 beyond a bin's run and beyond span_t
+    int32_t fbt_start[kBins + 1];
+};   // 40 104 B with SPAN_CAP = 2: four workgroups per CU (a fifth array — the band gradients had one — makes it three)
+
+constexpr int kBwdGroupsPerWave = 4;                                                    // 16 consecutive frames per wave
+constexpr int kBwdFramesPerBlock = kWavesPerBlock * kBwdGroupsPerWave * kGroup;        // 64 per workgroup
+
+// grid (ceil(NF / 64), B).  A wave owns 4 CONSECUTIVE frames at a time and overlap-adds them itself: its 4 windowed frame
+// gradients meet in its own LDS block, every sample they touch is summed in frame order, and the <= 2 waves that share a sample
+// (4 hops = 640 samples of advance against 352 of overlap) combine with one float atomic each onto the zeroed dx — two
+// operands, commutative, so bit-reproducible; no workgroup barrier after the tables are staged.
+#ifndef STFT_BWD_WAVES
+#define STFT_BWD_WAVES 2
+#endif
+template <int SPAN_CAP>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(STFT_BWD_WAVES, STFT_BWD_WAVES)))
+void stft_bands_backward_reg_kernel(const float *__restrict__ x,
+                                                                           const float *__restrict__ w,
+                                                                           const float *__restrict__ dband,
+                                                                           const int32_t *__restrict__ fbt_start,
+                                                                           const float *__restrict__ fbt_w, int span_t,
+                                                                           float *__restrict__ dx, int T, int NF, int hop,
+                                                                           int M) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char raw[];
+    LdsRegBwd<SPAN_CAP> &S = *reinterpret_cast<LdsRegBwd<SPAN_CAP> *>(raw);
+    fill_reg_tables(S.c);
+    for (int i = threadIdx.x; i < kBins * SPAN_CAP; i += kThreads) {
+        const int k = i / SPAN_CAP, j = i % SPAN_CAP;
+        S.fbt_w[i] = j < span_t ? fbt_w[k * span_t + j] : 0.0f;
+    }
+    for (int i = threadIdx.x; i < kBins; i += kThreads) S.fbt_start[i] = fbt_start[i];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, fs = lane >> 4, l = lane & 15;
+    __syncthreads();
+    const int64_t b = blockIdx.y;
+    const float *xb = x + b * T;
+    float2 *blk = S.c.blk[wave][fs];
+    float carry[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    bool carried = false;                                      // the previous group left its last 352 sums in `carry`
+    // a group whose frames involve no reflection and all exist (wave-uniform)
+    auto interior = [&](int g0) {
+        return hop == 160 && g0 + kGroup <= NF && g0 * hop >= 2 * kN && g0 * hop + 3 * hop + kNfft <= T;
+    };
+    for (int g = 0; g < kBwdGroupsPerWave; ++g) {
+        const int f0 = blockIdx.x * kBwdFramesPerBlock + (wave * kBwdGroupsPerWave + g) * kGroup;
+        if (f0 >= NF) break;                                   // wave-uniform
+        const int f = f0 + fs;
+        const bool live = f < NF;
+        const int fc = live ? f : NF - 1;
+        // the frame's band gradients: requested now (8 registers: the latency hides behind the transform), parked after the
+        // un-packing in the frame's own block, which is free between the two exchanges; rows shorter than kMaxBands and the
+        // SPAN_CAP entries behind them read 0 (padded taps reach them with weight 0)
+        float dreg[kMaxBands / 16];
+        {
+            const float *src = dband + (b * NF + fc) * M;
+#pragma unroll
+            for (int i = 0; i < kMaxBands / 16; ++i) {
+                const int m = l + 16 * i;
+                dreg[i] = m < M ? src[m] : 0.0f;
+            }
+        }
+        float2 xr[16];
+        load_frame_reg(xb, reinterpret_cast<const float2 *>(w), T, fc, hop, xr, here(l));
+        phase_done(xr);
+        fft256_reg<false>(xr, S.c.twl, blk, l);
+        float nyq;
+        unpack_real_reg(xr, nyq, blk, l);
+        phase_done(xr);
+        float *drow = reinterpret_cast<float *>(blk);
+        lds_wave_fence();
+#pragma unroll
+        for (int i = 0; i < kMaxBands / 16; ++i) drow[l + 16 * i] = dreg[i];
+        if (l < SPAN_CAP) drow[kMaxBands + l] = 0.0f;
+        // G[k] = d L / d X[k] for the one-sided inverse: 2 X[k] dp[k], interior bins halved, DC / Nyquist real; xr holds 2 X.
+        // dp[k] = sum_j fbt_w[k][j] dband[fbt_start[k] + j]: four bins at a time, their starts first, then every weight and
+        // band gradient in flight at once
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            lds_wave_fence();          // one chunk's 20 reads in flight, not all four's: 66 registers fewer
+            int m0[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) m0[i] = S.fbt_start[l + 16 * (4 * q + i)];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 4 * q + i;
+                float dp = 0.0f;
+#pragma unroll
+                for (int j = 0; j < SPAN_CAP; ++j) dp = fmaf(S.fbt_w[(l + 16 * r) * SPAN_CAP + j], drow[m0[i] + j], dp);
+                const bool dc = r == 0 && l == 0;
+                const float c = dc ? dp : 0.5f * dp;
+                xr[r] = make_float2(c * xr[r].x, dc ? 0.0f : c * xr[r].y);
+            }
+            // this chunk's products are complete before the next chunk's reads are requested (see phase_done)
+            asm volatile("" : "+v"(xr[4 * q].x), "+v"(xr[4 * q].y), "+v"(xr[4 * q + 1].x), "+v"(xr[4 * q + 1].y), "+v"(xr[4 * q + 2].x),
+                              "+v"(xr[4 * q + 2].y), "+v"(xr[4 * q + 3].x), "+v"(xr[4 * q + 3].y) :: "memory");
+        }
+        float g_nyq = 0.0f;
+        if (l == 0) {
+            const int m0n = S.fbt_start[kN];
+            float dpn = 0.0f;
+#pragma unroll
+            for (int j = 0; j < SPAN_CAP; ++j) dpn = fmaf(S.fbt_w[kN * SPAN_CAP + j], drow[m0n + j], dpn);
+            g_nyq = dpn * nyq;
+        }
+        // pack for the inverse: Z'[k] = (G[k] + G*[N - k]) + i W512^-k (G[k] - G*[N - k]);  N - 0 is the Nyquist bin
+        phase_done(xr);
+        lds_wave_fence();
+        park_vector(blk, xr, l);
+        lds_wave_fence();
+        int lp = here(l);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (r == 8) half_done<0>(xr);
+            float2 gc = conjf2(mirror_of(blk, r, l));
+            if (r == 0 && l == 0) gc = make_float2(g_nyq, 0.0f);
+            const float2 e = cadd(xr[r], gc), d = csub(xr[r], gc);
+            const float2 wd = cmulf(conjf2(kTw512[lp + 16 * r]), d);
+            xr[r] = make_float2(e.x - wd.y, e.y + wd.x);
+        }
+        fft256_reg<true>(xr, S.c.twl, blk, l);
+        // z'[n] = dframe[2n] + i dframe[2n + 1], n = l + 16 r: window, park the frame's 512 floats in its block
+        lds_wave_fence();
+        lp = here(l);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float2 wv = reinterpret_cast<const float2 *>(w)[lp + 16 * r];
+            blk[l + 16 * r] = live ? make_float2(wv.x * xr[r].x, wv.y * xr[r].y) : make_float2(0.0f, 0.0f);
+        }
+        lds_wave_fence();
+        const float *df = reinterpret_cast<const float *>(S.c.blk[wave][0]);
+        if (interior(f0)) {
+            const bool carry_out = g + 1 < kBwdGroupsPerWave && f0 + kGroup < NF && interior(f0 + kGroup);
+            overlap_add_interior<2 * kFrameSlots>(df, dx + b * T + (f0 * hop - kN), lane, carry, carried, carry_out);
+            carried = carry_out;
+        } else {
+            overlap_add_frames_cold<2 * kFrameSlots>(df, dx + b * T, f0, NF, hop, T, lane, 64);
+            carried = false;
+        }
+        lds_wave_fence();
+    }
 }
 
 // ---- mel-spec frontend (src/frontends.py:53-79): STFT -> MelScale on the real and imaginary parts -> |.|, angle ----------
@@ -672,15 +1157,15 @@ __global__ __launch_bounds__(kThreads) void stft_mel_backward_out_kernel(const f
 
 constexpr int64_t kMaxGridY = 65535;
 
-// The table is a pure function of nothing: writing it again is harmless, so a racy "done" flag per device is enough.
-inline void ensure_twiddles(hipStream_t st) {
-    static bool done[64] = {};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev < 0 || dev >= 64 || !done[dev]) {
-        hipLaunchKernelGGL(stft_twiddle_kernel, dim3(2), dim3(256), 0, st);
-        if (dev >= 0 && dev < 64) done[dev] = true;
-    }
+__global__ void stft_fill_kernel(float *p, int64_t n, float v) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// ADVSTEP_STFT_REG=0 (read per call): the radix-4 in-LDS kernels of rounds 1 - 3 for the LFCC pair (A/B measurements)
+inline bool reg_fft_enabled() {
+    const char *e = getenv("ADVSTEP_STFT_REG");
+    return !(e && e[0] == '0');
 }
 
 }  // namespace
@@ -694,7 +1179,7 @@ extern "C" {
 
 size_t advstep_stft_bands_block_count(int64_t B, int64_t NF) {
     if (B <= 0 || NF <= 0) return 0;
-    return (size_t)(B * ceil_div(NF, kFramesPerBlockFwd));
+    return (size_t)(B * ceil_div(NF, kFramesPerBlockFwd));      // the larger of the two kernels' workgroup counts
 }
 
 int advstep_stft_bands_supported(int64_t nfft, int64_t hop, int64_t T) {
@@ -709,7 +1194,18 @@ int advstep_stft_bands_f32(const float *x, const float *window, const int32_t *f
     if (B == 0 || NF == 0 || M == 0) return ADVSTEP_OK;
     STFT_REQUIRE(x && window && fb_start && fb_w && band_db && block_max && B <= kMaxGridY);
     STFT_REQUIRE(advstep_stft_bands_supported(nfft, hop, T) && NF == 1 + T / hop);
-    ensure_twiddles(as_stream(stream));
+    if (reg_fft_enabled() && span <= kRegSpan && M <= kMaxBands) {
+        // the unused tail of block_max (sized for the radix-4 kernel's 16-frame workgroups) must not hold garbage: the
+        // reduction over it reads advstep_stft_bands_block_count entries
+        const int64_t blocks32 = ceil_div(NF, kBandsFramesPerBlock), blocks16 = ceil_div(NF, kFramesPerBlockFwd);
+        stft_fill_kernel<<<dim3((unsigned)ceil_div(B * blocks16, 256)), dim3(256), 0, as_stream(stream)>>>(block_max, B * blocks16,
+                                                                                                          -INFINITY);
+        (void)blocks32;
+        const dim3 grid((unsigned)ceil_div(NF, kBandsFramesPerBlock), (unsigned)B);
+        hipLaunchKernelGGL(stft_bands_reg_kernel, grid, dim3(kThreads), 0, as_stream(stream), x, window, fb_start, fb_w, (int)span,
+                           band_db, block_max, (int)T, (int)NF, (int)hop, (int)M);
+        return status_after_launch();
+    }
     const dim3 grid((unsigned)ceil_div(NF, kFramesPerBlockFwd), (unsigned)B);
     hipLaunchKernelGGL(stft_bands_kernel, grid, dim3(kThreads), 0, as_stream(stream), x, window, fb_start, fb_w, (int)span,
                        band_db, block_max, (int)T, (int)NF, (int)hop, (int)M);
@@ -727,16 +1223,21 @@ int advstep_stft_bands_backward_f32(const float *x, const float *window, const f
     // advance by at least the overlap between neighbouring workgroups' ranges
     STFT_REQUIRE(kFramesPerBlockBwd * hop >= kNfft - hop);
     hipStream_t st = as_stream(stream);
-    ensure_twiddles(st);
     if (hipMemsetAsync(dx, 0, (size_t)B * T * sizeof(float), st) != hipSuccess) return ADVSTEP_ELAUNCH;
-    const dim3 grid((unsigned)ceil_div(NF, kFramesPerBlockBwd), (unsigned)B);
+    const bool reg = reg_fft_enabled();
+    const dim3 grid((unsigned)ceil_div(NF, reg ? kBwdFramesPerBlock : kFramesPerBlockBwd), (unsigned)B);
     auto go = [&](auto kernel, size_t lds) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kernel, grid, dim3(kThreads), lds, st, x, window, dband, fbt_start, fbt_w, (int)span_t, dx, (int)T,
                            (int)NF, (int)hop, (int)M);
     };
-    if (span_t <= 2) go(stft_bands_backward_kernel<2>, sizeof(LdsBwd<2>));
-    else go(stft_bands_backward_kernel<kMaxSpanT>, sizeof(LdsBwd<kMaxSpanT>));
+    if (reg) {
+        if (span_t <= 2) go(stft_bands_backward_reg_kernel<2>, sizeof(LdsRegBwd<2>));
+        else go(stft_bands_backward_reg_kernel<kMaxSpanT>, sizeof(LdsRegBwd<kMaxSpanT>));
+    } else {
+        if (span_t <= 2) go(stft_bands_backward_kernel<2>, sizeof(LdsBwd<2>));
+        else go(stft_bands_backward_kernel<kMaxSpanT>, sizeof(LdsBwd<kMaxSpanT>));
+    }
     return status_after_launch();
 }
 
@@ -748,7 +1249,6 @@ int advstep_stft_mel_f32(const float *x, const float *window, const int32_t *fb_
     STFT_REQUIRE(x && window && fb_start && fb_w && out && B <= kMaxGridY && M <= kMelMax && span <= kMelMaxSpan);
     STFT_REQUIRE(advstep_stft_bands_supported(nfft, hop, T) && NF == 1 + T / hop);
     hipStream_t st = as_stream(stream);
-    ensure_twiddles(st);
     const size_t lds = sizeof(LdsMel);
     auto go = [&](auto kernel) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -771,7 +1271,6 @@ int advstep_stft_mel_backward_f32(const float *x, const float *window, const flo
     STFT_REQUIRE(advstep_stft_bands_supported(nfft, hop, T) && NF == 1 + T / hop);
     STFT_REQUIRE(kFramesPerBlockBwd * hop >= kNfft - hop);
     hipStream_t st = as_stream(stream);
-    ensure_twiddles(st);
     if (hipMemsetAsync(dx, 0, (size_t)B * T * sizeof(float), st) != hipSuccess) return ADVSTEP_ELAUNCH;
     const size_t lds = sizeof(LdsMelBwd);
     auto go = [&](auto kernel) {
@@ -795,7 +1294,6 @@ int advstep_stft_mel_backward_from_output_f32(const float *window, const float *
     STFT_REQUIRE(advstep_stft_bands_supported(nfft, hop, T) && NF == 1 + T / hop);
     STFT_REQUIRE(kFramesPerBlockBwd * hop >= kNfft - hop);
     hipStream_t st = as_stream(stream);
-    ensure_twiddles(st);
     if (hipMemsetAsync(dx, 0, (size_t)B * T * sizeof(float), st) != hipSuccess) return ADVSTEP_ELAUNCH;
     const size_t lds = sizeof(LdsMelBwdOut);
     auto go = [&](auto kernel) {
