@@ -216,8 +216,9 @@ def add_maxpool1d(a: torch.Tensor, b: Optional[torch.Tensor], k: int) -> torch.T
 
 def _afms_row(mode: int, a, b, alpha, r0, r1, out, rows: int, C: int, L: int) -> None:
     ptr = lambda t: None if t is None else t.data_ptr()
-    st = _lib.load().advstep_afms_row_f32(mode, a.data_ptr(), ptr(b), ptr(alpha), ptr(r0), ptr(r1), out.data_ptr(), rows, C, L,
-                                          _stream(a.device))
+    with _Launch("afms_row", a.device, tensors=(a, b, out) if out.numel() >= a.numel() else (a, b)):
+        st = _lib.load().advstep_afms_row_f32(mode, a.data_ptr(), ptr(b), ptr(alpha), ptr(r0), ptr(r1), out.data_ptr(), rows, C, L,
+                                              _stream(a.device))
     _lib.check(st, "advstep_afms_row_f32")
 
 
@@ -425,8 +426,9 @@ class _AttendPool(torch.autograd.Function):
         lib = _lib.load()
         if C <= 256 and tuple(weight.shape) == (C, C) and weight.is_contiguous():
             gate = torch.empty((N, C), dtype=x.dtype, device=x.device)
-            st = lib.advstep_gate_fc_forward_f32(mean.data_ptr(), weight.data_ptr(), bias.data_ptr() if bias is not None else None,
-                                                 gate.data_ptr(), N, C, _stream(x.device))
+            with _Launch("attend_gate_fc", x.device, tensors=(mean, weight, gate)):
+                st = lib.advstep_gate_fc_forward_f32(mean.data_ptr(), weight.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                                     gate.data_ptr(), N, C, _stream(x.device))
             _lib.check(st, "advstep_gate_fc_forward_f32")
         else:
             gate = torch.sigmoid(torch.addmm(bias, mean, weight.t()) if bias is not None else mean @ weight.t()).contiguous()
@@ -436,8 +438,9 @@ class _AttendPool(torch.autograd.Function):
         # is not kept for backward (ADVSTEP_ATTEND_XW=0: gather them out of x in backward, A/B)
         compact = _attend_xw_enabled()
         xw = torch.empty_like(y) if compact else None
-        st = _lib.load().advstep_gate_maxpool2_forward_xw_f32(x.data_ptr(), gate.data_ptr(), y.data_ptr(), sel.data_ptr(),
-                                                              None if xw is None else xw.data_ptr(), N, C, H, W, _stream(x.device))
+        with _Launch("attend_pool_forward", x.device, tensors=(x, y, sel, xw)):
+            st = _lib.load().advstep_gate_maxpool2_forward_xw_f32(x.data_ptr(), gate.data_ptr(), y.data_ptr(), sel.data_ptr(),
+                                                                  None if xw is None else xw.data_ptr(), N, C, H, W, _stream(x.device))
         _lib.check(st, "advstep_gate_maxpool2_forward_xw_f32")
         ctx.compact, ctx.shape = compact, (N, C, H, W)
         ctx.save_for_backward(xw if compact else x, sel, gate, weight)
@@ -452,8 +455,9 @@ class _AttendPool(torch.autograd.Function):
         if ctx.compact:
             blocks = 1
             partial = torch.empty((N * C, 1), dtype=gy.dtype, device=dev)
-            st = lib.advstep_gate_maxpool2_backward_gate_pooled_f32(gy.data_ptr(), kept.data_ptr(), partial.data_ptr(), N, C, H, W,
-                                                                    _stream(dev))
+            with _Launch("attend_pool_backward", dev, tensors=(gy, kept)):
+                st = lib.advstep_gate_maxpool2_backward_gate_pooled_f32(gy.data_ptr(), kept.data_ptr(), partial.data_ptr(), N, C, H, W,
+                                                                        _stream(dev))
             _lib.check(st, "advstep_gate_maxpool2_backward_gate_pooled_f32")
         else:
             blocks = max(lib.advstep_gate_maxpool2_blocks(H, W), 1)
@@ -463,15 +467,17 @@ class _AttendPool(torch.autograd.Function):
             _lib.check(st, "advstep_gate_maxpool2_backward_gate_f32")
         if C <= 256 and tuple(weight.shape) == (C, C) and weight.is_contiguous():
             g_mean = torch.empty((N, C), dtype=gy.dtype, device=dev)
-            st = lib.advstep_gate_fc_backward_f32(partial.data_ptr(), blocks, gate.data_ptr(), weight.data_ptr(), 1.0 / float(H * W),
-                                                  g_mean.data_ptr(), N, C, _stream(dev))
+            with _Launch("attend_gate_fc", dev, tensors=(partial, gate, weight, g_mean)):
+                st = lib.advstep_gate_fc_backward_f32(partial.data_ptr(), blocks, gate.data_ptr(), weight.data_ptr(), 1.0 / float(H * W),
+                                                      g_mean.data_ptr(), N, C, _stream(dev))
             _lib.check(st, "advstep_gate_fc_backward_f32")
         else:
             ggate = partial.sum(dim=1).view(N, C)
             g_mean = (((ggate * gate * (1.0 - gate)) @ weight) / float(H * W)).contiguous()
         gx = torch.empty((N, C, H, W), dtype=gy.dtype, device=dev)
-        st = lib.advstep_gate_maxpool2_backward_input_f32(gy.data_ptr(), sel.data_ptr(), gate.data_ptr(), g_mean.data_ptr(),
-                                                          gx.data_ptr(), N, C, H, W, _stream(dev))
+        with _Launch("attend_pool_backward", dev, tensors=(gy, sel, gx)):
+            st = lib.advstep_gate_maxpool2_backward_input_f32(gy.data_ptr(), sel.data_ptr(), gate.data_ptr(), g_mean.data_ptr(),
+                                                              gx.data_ptr(), N, C, H, W, _stream(dev))
         _lib.check(st, "advstep_gate_maxpool2_backward_input_f32")
         return gx, None, None
 

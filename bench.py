@@ -87,7 +87,8 @@ STEP_FAMILIES = (
      ("mfm_forward", "mfm_backward", "mfm_pool2_forward", "mfm_pool2_backward", "conv3x3_mfm_backward", "affine_act_forward",
       "affine_act_backward", "add_maxpool2_forward", "maxpool2_backward", "add_maxpool1d_forward", "maxpool1d_backward",
       "gate_maxpool2_forward", "gate_maxpool2_backward", "weighted_stats_forward", "weighted_stats_backward",
-      "log_meannorm_forward", "log_meannorm_backward", "tail_pool1d_forward", "tail_pool1d_backward")),
+      "log_meannorm_forward", "log_meannorm_backward", "tail_pool1d_forward", "tail_pool1d_backward", "attend_pool_forward",
+      "attend_pool_backward", "attend_gate_fc", "afms_row", "res2net_link_forward", "res2net_link_backward")),
     ("attack step, random start, min-max, loss gradient", "hbm",
      ("pgd_linf_step", "pgd_linf_init", "pgd_l2_step", "pgd_l2_init", "fgsm_step", "cw_adam_step", "cw_tanh_sqdist",
       "cw_best_update", "cw_init_w", "minmax_normalize", "minmax_revert", "ce2_loss_grad")),
