@@ -697,6 +697,30 @@ __global__ __launch_bounds__(kBlock, 8) void pgd_l2_fused_kernel(const float *__
     }
 }
 
+// Round 4: the single-pass calls are ONE node shorter.  Until round 3 a memset node zeroed the granules and flags before every
+// launch (stale granules of the previous call carry the same phase tags).  Now the repair kernel — queued behind every single-pass
+// launch anyway — leaves the row's state clean for the NEXT call: granules zeroed, the flag moved to `last` (diagnostics) and
+// lowered.  Contract (include/advstep.h): the caller zero-fills a workspace once, before its first use; every call leaves it
+// valid for the next.  A workspace that is NOT clean cannot produce a wrong row: a tag that is neither this phase nor poison makes
+// its readers wait, and a wait that does not end hands the row to the repair pass (slow, never wrong); only a stale granule with
+// a matching tag could be consumed, and those no longer outlive their call.
+// Returns the row's flag (workgroup-uniform).
+__device__ __forceinline__ unsigned take_flag_and_clean(unsigned long long *g0, unsigned long long *g1, int C, unsigned *fail,
+                                                        unsigned *last, int64_t b) {
+    __shared__ unsigned flag_s;
+    if (threadIdx.x == 0) {
+        flag_s = fail[b];
+        last[b] = flag_s;
+        fail[b] = 0u;
+    }
+    if ((int)threadIdx.x < C) {
+        g0[b * C + threadIdx.x] = 0ull;
+        if (g1) g1[b * C + threadIdx.x] = 0ull;
+    }
+    __syncthreads();
+    return flag_s;
+}
+
 // Repair pass of the single-pass step: one workgroup per row, returns at once unless the row's flag is up.  The row's tiles
 // are visited in sequence with the three-kernel path's own expressions and reductions (sumsq_partial / pgd_l2_delta /
 // pgd_l2_project), so a repaired row carries the same bits as any other.  adv / orig / grad are re-read from global memory:
@@ -705,10 +729,11 @@ template <bool VEC>
 __global__ __launch_bounds__(kBlock) void pgd_l2_repair_kernel(const float *__restrict__ adv, const float *__restrict__ grad,
                                                                const float *__restrict__ orig, float *out, int64_t T, int C,
                                                                float alpha, float eps, float eps_div, float lo, float hi,
-                                                               const unsigned *__restrict__ fail, float *__restrict__ gnorm,
+                                                               unsigned long long *gran_g, unsigned long long *gran_d,
+                                                               unsigned *fail, unsigned *last, float *__restrict__ gnorm,
                                                                float *__restrict__ dnorm) {
     const int64_t b = blockIdx.x;
-    if (!fail[b]) return;
+    if (!take_flag_and_clean(gran_g, gran_d, C, fail, last, b)) return;
     __shared__ float gpart[64], dpart[64], lds[12];
     float4 a[kVecs], g[kVecs], x[kVecs];
     for (int tile = 0; tile < C; ++tile) {
@@ -909,9 +934,10 @@ __global__ __launch_bounds__(kBlock, 8) void pgd_l2_init_philox_fused_kernel(con
 template <bool VEC>
 __global__ __launch_bounds__(kBlock) void pgd_l2_init_philox_repair_kernel(const float *__restrict__ x, float *out, int64_t T, int C,
                                                                            float eps, float lo, float hi, uint64_t seed,
-                                                                           uint64_t offset, const unsigned *__restrict__ fail) {
+                                                                           uint64_t offset, unsigned long long *gran, unsigned *fail,
+                                                                           unsigned *last) {
     const int64_t b = blockIdx.x;
-    if (!fail[b]) return;
+    if (!take_flag_and_clean(gran, nullptr, C, fail, last, b)) return;
     __shared__ float npart[64], lds[8];
     float4 nz[kVecs], xv[kVecs];
     for (int tile = 0; tile < C; ++tile) {
@@ -1050,9 +1076,10 @@ inline size_t row_ws_plane(int64_t B, int64_t T) {
     const size_t one = (size_t)B * (size_t)tiles_per_row(T) * sizeof(float);
     return (one + 15) & ~(size_t)15;
 }
-// ... followed by one 32-bit "row needs repair" flag per row (single-pass PGD-L2 paths)
+// ... followed by two 32-bit words per row (single-pass PGD-L2 paths): the live "row needs repair" flags, and the flags of the
+// LAST single-pass call as its repair pass left them (advstep_pgd_l2_repaired_rows reads those)
 inline size_t row_ws_flags(int64_t B) { return ((size_t)B * sizeof(unsigned) + 15) & ~(size_t)15; }
-inline size_t row_ws_bytes(int64_t B, int64_t T) { return 4 * row_ws_plane(B, T) + row_ws_flags(B); }
+inline size_t row_ws_bytes(int64_t B, int64_t T) { return 4 * row_ws_plane(B, T) + 2 * row_ws_flags(B); }
 inline bool carve_ws(void *ws, size_t ws_bytes, int64_t B, int64_t T, RowWs *out) {
     if (!ws || !aligned16(ws) || ws_bytes < row_ws_bytes(B, T)) return false;
     out->p0 = static_cast<float *>(ws);
@@ -1320,21 +1347,21 @@ int advstep_pgd_l2_init_philox_f32(const float *x, float *out, int64_t B, int64_
     const void *fused = vec ? (const void *)pgd_l2_init_philox_fused_kernel<true> : (const void *)pgd_l2_init_philox_fused_kernel<false>;
     if (l2_single_pass() && C <= 64 && !overlaps(x, out, (size_t)B * T * sizeof(float)) &&
         B * C <= l2_resident_capacity(vec ? kCapInitVec : kCapInitScalar, fused)) {
-        // granules + row flags zeroed by one memset node; the repair kernel behind the launch serves flagged rows
-        if (hipMemsetAsync(ws, 0, row_ws_bytes(B, T), st) != hipSuccess) return ADVSTEP_ELAUNCH;
+        // the repair kernel behind the launch serves flagged rows and leaves granules + flags clean for the next call
         unsigned long long *gran = static_cast<unsigned long long *>(ws);
         unsigned *fail = reinterpret_cast<unsigned *>(static_cast<char *>(ws) + 4 * row_ws_plane(B, T));
+        unsigned *last = reinterpret_cast<unsigned *>(static_cast<char *>(ws) + 4 * row_ws_plane(B, T) + row_ws_flags(B));
         const unsigned spins = l2_spin_limit();
         if (vec) {
             hipLaunchKernelGGL(pgd_l2_init_philox_fused_kernel<true>, dim3(C, (unsigned)B), dim3(kBlock), 0, st, x, out, T, eps, lo,
                                hi, seed, offset, gran, fail, spins);
             hipLaunchKernelGGL(pgd_l2_init_philox_repair_kernel<true>, dim3((unsigned)B), dim3(kBlock), 0, st, x, out, T, C, eps,
-                               lo, hi, seed, offset, fail);
+                               lo, hi, seed, offset, gran, fail, last);
         } else {
             hipLaunchKernelGGL(pgd_l2_init_philox_fused_kernel<false>, dim3(C, (unsigned)B), dim3(kBlock), 0, st, x, out, T, eps, lo,
                                hi, seed, offset, gran, fail, spins);
             hipLaunchKernelGGL(pgd_l2_init_philox_repair_kernel<false>, dim3((unsigned)B), dim3(kBlock), 0, st, x, out, T, C, eps,
-                               lo, hi, seed, offset, fail);
+                               lo, hi, seed, offset, gran, fail, last);
         }
         return status_after_launch();
     }
@@ -1358,24 +1385,24 @@ int advstep_pgd_l2_step_f32(const float *adv, const float *grad, const float *or
     const size_t row_bytes = (size_t)B * T * sizeof(float);
     if (l2_single_pass() && C <= 64 && !overlaps(adv, out, row_bytes) && !overlaps(grad, out, row_bytes) &&
         !overlaps(orig, out, row_bytes) && B * C <= l2_resident_capacity(vec ? kCapStepVec : kCapStepScalar, fused)) {
-        // the launch fits the device's resident capacity for this kernel: one launch, 16 B per sample; granules + row flags
-        // zeroed by one memset node, the repair kernel behind the launch serves rows whose exchange was abandoned
+        // the launch fits the device's resident capacity for this kernel: one launch, 16 B per sample; the repair kernel behind
+        // it serves rows whose exchange was abandoned and leaves granules + flags clean for the next call (no memset node)
         const size_t plane = 2 * row_ws_plane(B, T);
-        if (hipMemsetAsync(ws, 0, row_ws_bytes(B, T), st) != hipSuccess) return ADVSTEP_ELAUNCH;
         unsigned long long *gg = static_cast<unsigned long long *>(ws);
         unsigned long long *gd = reinterpret_cast<unsigned long long *>(static_cast<char *>(ws) + plane);
         unsigned *fail = reinterpret_cast<unsigned *>(static_cast<char *>(ws) + 2 * plane);
+        unsigned *last = reinterpret_cast<unsigned *>(static_cast<char *>(ws) + 2 * plane + row_ws_flags(B));
         const unsigned spins = l2_spin_limit();
         if (vec) {
             hipLaunchKernelGGL(pgd_l2_fused_kernel<true>, dim3(C, (unsigned)B), dim3(kBlock), 0, st, adv, grad, orig, out, T, alpha,
                                eps, eps_div, lo, hi, gg, gd, fail, spins, gnorm, dnorm);
             hipLaunchKernelGGL(pgd_l2_repair_kernel<true>, dim3((unsigned)B), dim3(kBlock), 0, st, adv, grad, orig, out, T, C, alpha,
-                               eps, eps_div, lo, hi, fail, gnorm, dnorm);
+                               eps, eps_div, lo, hi, gg, gd, fail, last, gnorm, dnorm);
         } else {
             hipLaunchKernelGGL(pgd_l2_fused_kernel<false>, dim3(C, (unsigned)B), dim3(kBlock), 0, st, adv, grad, orig, out, T, alpha,
                                eps, eps_div, lo, hi, gg, gd, fail, spins, gnorm, dnorm);
             hipLaunchKernelGGL(pgd_l2_repair_kernel<false>, dim3((unsigned)B), dim3(kBlock), 0, st, adv, grad, orig, out, T, C, alpha,
-                               eps, eps_div, lo, hi, fail, gnorm, dnorm);
+                               eps, eps_div, lo, hi, gg, gd, fail, last, gnorm, dnorm);
         }
         return status_after_launch();
     }
@@ -1392,8 +1419,8 @@ int advstep_pgd_l2_repaired_rows(const void *ws, size_t ws_bytes, int64_t B, int
     ADV_REQUIRE(B >= 0 && T >= 0 && count);
     if (B == 0 || T == 0) return hipMemsetAsync(count, 0, sizeof(int), as_stream(stream)) == hipSuccess ? ADVSTEP_OK : ADVSTEP_ELAUNCH;
     if (!ws || !aligned16(ws) || ws_bytes < row_ws_bytes(B, T)) return ADVSTEP_EWORKSPACE;
-    const unsigned *fail = reinterpret_cast<const unsigned *>(static_cast<const char *>(ws) + 4 * row_ws_plane(B, T));
-    hipLaunchKernelGGL(count_flags_kernel, dim3(1), dim3(64), 0, as_stream(stream), fail, B, count);
+    const unsigned *last = reinterpret_cast<const unsigned *>(static_cast<const char *>(ws) + 4 * row_ws_plane(B, T) + row_ws_flags(B));
+    hipLaunchKernelGGL(count_flags_kernel, dim3(1), dim3(64), 0, as_stream(stream), last, B, count);
     return status_after_launch();
 }
 

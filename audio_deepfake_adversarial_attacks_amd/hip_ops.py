@@ -73,7 +73,8 @@ def _workspace(device: torch.device, B: int, T: int) -> Tuple[int, int]:
     key = (device.index if device.index is not None else torch.cuda.current_device(), _stream(device))
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < need:
-        ws = torch.empty(max(need, 1 << 16), dtype=torch.uint8, device=device)
+        # zero-filled ONCE: the single-pass PGD-L2 calls keep their exchange state clean from call to call (include/advstep.h)
+        ws = torch.zeros(max(need, 1 << 16), dtype=torch.uint8, device=device)
         _workspaces[key] = ws
     return ws.data_ptr(), ws.numel()
 
