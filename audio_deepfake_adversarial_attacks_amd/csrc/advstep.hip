@@ -108,11 +108,16 @@ __device__ __forceinline__ float4 philox_uniform4(uint64_t q, uint64_t seed, uin
 __device__ __forceinline__ float4 philox_normal4(uint32_t q, uint32_t b, uint64_t seed, uint64_t offset) {
     const Quad r = philox4x32_10(q, b, (uint32_t)offset, (uint32_t)(offset >> 32), (uint32_t)seed,
                                  (uint32_t)(seed >> 32));
-    const float r0 = sqrtf(-2.0f * logf(u01_open0(r.v[0])));
-    const float r1 = sqrtf(-2.0f * logf(u01_open0(r.v[2])));
+    // Round 4: the hardware transcendentals (v_log_f32, v_sin_f32 / v_cos_f32: ~1 ulp / ~1e-6 absolute) instead of OCML's
+    // correctly-rounded-ish logf / sinf / cosf, which were what this start kernel spent its time in (24 us for 8 B / sample = 0.34
+    // of the HBM roofline).  The random start has no reference bit pattern to match (pgdl2.py:55-62 draws from torch's own
+    // generator); the oracle twin (oracle/kernels.py, libm) agrees to ~1e-9 after the eps / ||n|| scaling, inside the 1e-7 bound
+    // oracle/checked_ops.py applies, and every path of the library (single-pass, repair, two-kernel) calls THIS function.
+    const float r0 = sqrtf(-2.0f * __logf(u01_open0(r.v[0])));
+    const float r1 = sqrtf(-2.0f * __logf(u01_open0(r.v[2])));
     const float t0 = 6.283185307179586f * u01(r.v[1]);
     const float t1 = 6.283185307179586f * u01(r.v[3]);
-    return make_float4(r0 * cosf(t0), r0 * sinf(t0), r1 * cosf(t1), r1 * sinf(t1));
+    return make_float4(r0 * __cosf(t0), r0 * __sinf(t0), r1 * __cosf(t1), r1 * __sinf(t1));
 }
 
 __device__ __forceinline__ float f4_get(const float4 &v, int k) {
