@@ -1155,6 +1155,253 @@ __global__ __launch_bounds__(kThreads) void stft_mel_backward_out_kernel(const f
     overlap_add_block(S.dframe, dx + b * T, f_base, NF, hop, T);
 }
 
+// ---- round 4: the mel-spec pair on the register-resident transform -----------------------------------------------------------
+constexpr int kMelRegSpan = 16;                 // taps per band the register-FFT forward kernel takes (80 HTK bands over 257 bins: 16)
+constexpr int kMelBandsPerLane = (kMelMax + 15) / 16;      // a lane owns bands l, l + 16, ..., of its frame
+
+struct LdsMelReg {
+    LdsReg c;
+    float fbw[kMelMax * kMelRegSpan];           // [m][j], 0 beyond a band's run, beyond `span` and for m >= M
+    int32_t fbs[kMelMax];
+};
+static_assert(2 * kMelMax * (kBandsFramesPerBlock + 1) * sizeof(float) <= sizeof(LdsReg::blk), "the output tile aliases the exchange blocks");
+
+// grid (ceil(NF / 32), B); span <= kMelRegSpan, M <= kMelMax.  A wave works through two groups of 4 frames; a lane keeps the
+// magnitude / phase of its 5 bands of both groups in registers until every wave of the workgroup is done with its exchange
+// blocks, which then hold the workgroup's (plane, band) x 32-frame output tile: rows of 128 bytes go out.
+__global__ __launch_bounds__(kThreads) void stft_mel_reg_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                                const int32_t *__restrict__ fb_start,
+                                                                const float *__restrict__ fb_w, int span,
+                                                                float *__restrict__ out, int T, int NF, int hop, int M) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char raw[];
+    LdsMelReg &SF = *reinterpret_cast<LdsMelReg *>(raw);
+    LdsReg &S = SF.c;
+    fill_reg_tables(S);
+    for (int i = threadIdx.x; i < kMelMax * kMelRegSpan; i += kThreads) {
+        const int m = i / kMelRegSpan, j = i % kMelRegSpan;
+        SF.fbw[i] = (m < M && j < span) ? 0.5f * fb_w[m * span + j] : 0.0f;       // the transform below delivers 2 X
+    }
+    for (int m = threadIdx.x; m < kMelMax; m += kThreads) {
+        const int k0 = m < M ? fb_start[m] : 0;
+        SF.fbs[m] = k0 + kMelRegSpan <= kBins + 15 ? k0 : kBins + 15 - kMelRegSpan;      // padded taps stay inside the frame's block
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, fs = lane >> 4, l = lane & 15;
+    __syncthreads();
+    const int64_t b = blockIdx.y;
+    const int f_base = blockIdx.x * kBandsFramesPerBlock;
+    float2 *blk = S.blk[wave][fs];
+    float mag[kGroupsPerWave][kMelBandsPerLane], ph[kGroupsPerWave][kMelBandsPerLane];
+#pragma unroll
+    for (int g = 0; g < kGroupsPerWave; ++g) {
+        const int f0 = f_base + (wave * kGroupsPerWave + g) * kGroup;
+#pragma unroll
+        for (int i = 0; i < kMelBandsPerLane; ++i) mag[g][i] = ph[g][i] = 0.0f;
+        if (f0 >= NF) continue;                                 // wave-uniform
+        const int f = f0 + fs;
+        const bool live = f < NF;
+        float2 xr[16];
+        load_frame_reg(x + b * T, reinterpret_cast<const float2 *>(w), T, live ? f : NF - 1, hop, xr, here(l));
+        phase_done(xr);
+        fft256_reg<false>(xr, S.twl, blk, l);
+        float nyq;
+        unpack_real_reg(xr, nyq, blk, l);
+        phase_done(xr);
+        // 2 X[0 .. 256] as a plain 257-vector in the frame's block (the mirror reads above were issued before these writes);
+        // slots 257 .. 271 read 0: padded taps reach them with weight 0
+        lds_wave_fence();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) blk[l + 16 * r] = xr[r];
+        if (l == 0) blk[kN] = make_float2(nyq, 0.0f);
+        if (l >= 1) blk[kN + l] = make_float2(0.0f, 0.0f);
+        lds_wave_fence();
+        // Y[m] = sum_j fb[m][j] X[k0(m) + j] for the lane's bands, one band's 16 weights + 16 bins in flight at a time
+#pragma unroll
+        for (int i = 0; i < kMelBandsPerLane; ++i) {
+            const int m = l + 16 * i;
+            if (m < kMelMax) {
+                const int k0 = SF.fbs[m];
+                float re = 0.0f, im = 0.0f;
+#pragma unroll
+                for (int j = 0; j < kMelRegSpan; ++j) {
+                    const float wt = SF.fbw[m * kMelRegSpan + j];
+                    const float2 z = blk[k0 + j];
+                    re = fmaf(wt, z.x, re);
+                    im = fmaf(wt, z.y, im);
+                }
+                mag[g][i] = sqrtf(re * re + im * im);
+                ph[g][i] = atan2f(im, re);
+                asm volatile("" : "+v"(mag[g][i]), "+v"(ph[g][i]) :: "memory");       // this band is complete before the next one's reads
+            }
+        }
+        lds_wave_fence();
+    }
+    __syncthreads();                                            // every wave is done with its exchange blocks
+    float *tile = reinterpret_cast<float *>(&S.blk[0][0][0]);   // [plane][band][33]
+#pragma unroll
+    for (int g = 0; g < kGroupsPerWave; ++g) {
+        const int fl = (wave * kGroupsPerWave + g) * kGroup + fs;
+#pragma unroll
+        for (int i = 0; i < kMelBandsPerLane; ++i) {
+            const int m = l + 16 * i;
+            if (m < M) {
+                tile[(0 * kMelMax + m) * (kBandsFramesPerBlock + 1) + fl] = mag[g][i];
+                tile[(1 * kMelMax + m) * (kBandsFramesPerBlock + 1) + fl] = ph[g][i];
+            }
+        }
+    }
+    __syncthreads();
+    const int frames_here = (NF - f_base) < kBandsFramesPerBlock ? (NF - f_base) : kBandsFramesPerBlock;
+    for (int i = threadIdx.x; i < 2 * M * kBandsFramesPerBlock; i += kThreads) {
+        const int fl = i % kBandsFramesPerBlock, row = i / kBandsFramesPerBlock, plane = row / M, m = row - plane * M;
+        if (fl < frames_here)
+            out[((b * 2 + plane) * M + m) * NF + f_base + fl] = tile[(plane * kMelMax + m) * (kBandsFramesPerBlock + 1) + fl];
+    }
+}
+
+template <int SPAN_CAP>
+struct LdsMelRegBwd {
+    LdsReg c;
+    float fbt_w[(kBins + 1) * SPAN_CAP];
+    int32_t fbt_start[kBins + 1];
+};
+
+// grid (ceil(NF / 64), B): d x from d out and out alone (see stft_mel_backward_out_kernel), a wave owning 16 consecutive frames
+// in 4 groups, its overlap-add carried in registers from group to group (see stft_bands_backward_reg_kernel).  Per group the
+// frame's (d magnitude, d phase, magnitude, phase) rows are staged in the frame's own exchange block (4 x 80 floats), turned
+// into d Y (80 complex, behind them), projected back onto the bins, packed and inverse-transformed.
+template <int SPAN_CAP>
+__global__ __launch_bounds__(kThreads) void stft_mel_backward_out_reg_kernel(const float *__restrict__ w, const float *__restrict__ dout,
+                                                                             const float *__restrict__ out,
+                                                                             const int32_t *__restrict__ fbt_start,
+                                                                             const float *__restrict__ fbt_w, int span_t,
+                                                                             float *__restrict__ dx, int T, int NF, int hop, int M) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char raw[];
+    LdsMelRegBwd<SPAN_CAP> &S = *reinterpret_cast<LdsMelRegBwd<SPAN_CAP> *>(raw);
+    fill_reg_tables(S.c);
+    for (int i = threadIdx.x; i < kBins * SPAN_CAP; i += kThreads) {
+        const int k = i / SPAN_CAP, j = i % SPAN_CAP;
+        S.fbt_w[i] = j < span_t ? fbt_w[k * span_t + j] : 0.0f;
+    }
+    for (int i = threadIdx.x; i < kBins; i += kThreads) S.fbt_start[i] = fbt_start[i];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, fs = lane >> 4, l = lane & 15;
+    __syncthreads();
+    const int64_t b = blockIdx.y;
+    float2 *blk = S.c.blk[wave][fs];
+    float carry[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    bool carried = false;
+    auto interior = [&](int g0) {
+        return hop == 160 && g0 + kGroup <= NF && g0 * hop >= 2 * kN && g0 * hop + 3 * hop + kNfft <= T;
+    };
+    constexpr int kRows = 4 * kMelMax;                          // staged floats per frame; d Y follows at float offset kRows
+    static_assert((kRows + 2 * (kMelMax + 8)) * sizeof(float) <= kFrameSlots * sizeof(float2), "stage + d Y fit a frame's block");
+    for (int g = 0; g < kBwdGroupsPerWave; ++g) {
+        const int f0 = blockIdx.x * kBwdFramesPerBlock + (wave * kBwdGroupsPerWave + g) * kGroup;
+        if (f0 >= NF) break;                                    // wave-uniform
+        const int f = f0 + fs;
+        const bool live = f < NF;
+        // (plane, band, frame) -> the frame's block: plane 0, 1 = d out, planes 2, 3 = out; a wave-instruction reads 16 rows x 4
+        // consecutive frames (16-byte runs: the tensor is frame-minor)
+        float *stage = reinterpret_cast<float *>(blk);
+        {
+            float *wave_blocks = reinterpret_cast<float *>(S.c.blk[wave][0]);
+            for (int i = lane; i < 4 * M * kGroup; i += 64) {
+                const int fl = i & 3, row = i >> 2, plane = row / M, m = row - plane * M;
+                const float *src = plane < 2 ? dout : out;
+                const float v = f0 + fl < NF ? src[((b * 2 + (plane & 1)) * M + m) * NF + f0 + fl] : 0.0f;
+                wave_blocks[fl * 2 * kFrameSlots + plane * kMelMax + m] = v;
+            }
+        }
+        lds_wave_fence();
+        // d (|Y|, angle Y) -> d Y from the forward OUTPUT: g_mag (cos, sin) + (g_phase / |Y|) (-sin, cos), 0 at |Y| = 0
+        float2 *dy = reinterpret_cast<float2 *>(stage + kRows);
+#pragma unroll
+        for (int i = 0; i < kMelBandsPerLane; ++i) {
+            const int m = l + 16 * i;
+            if (m < kMelMax) {
+                float2 gy = make_float2(0.0f, 0.0f);
+                if (m < M) {
+                    const float gm = stage[m], gp = stage[kMelMax + m], mg = stage[2 * kMelMax + m], phv = stage[3 * kMelMax + m];
+                    if (mg > 0.0f) {
+                        float sn, cs;
+                        sincosf(phv, &sn, &cs);
+                        const float q = gp / mg;
+                        gy.x = gm * cs - q * sn;
+                        gy.y = gm * sn + q * cs;
+                    }
+                }
+                dy[m] = gy;
+            }
+        }
+        if (l < 8) dy[kMelMax + l] = make_float2(0.0f, 0.0f);   // padded taps read these with weight 0
+        lds_wave_fence();
+        // d X[k] = sum_j fbt_w[k][j] d Y[fbt_start[k] + j], four bins at a time (see stft_bands_backward_reg_kernel)
+        float2 xr[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            lds_wave_fence();
+            int m0[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) m0[i] = S.fbt_start[l + 16 * (4 * q + i)];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 4 * q + i;
+                float re = 0.0f, im = 0.0f;
+#pragma unroll
+                for (int j = 0; j < SPAN_CAP; ++j) {
+                    const float wt = S.fbt_w[(l + 16 * r) * SPAN_CAP + j];
+                    const float2 gy = dy[m0[i] + j];
+                    re = fmaf(wt, gy.x, re);
+                    im = fmaf(wt, gy.y, im);
+                }
+                // one-sided inverse: interior bins halved, the imaginary part of DC dropped
+                const bool dc = r == 0 && l == 0;
+                xr[r] = dc ? make_float2(re, 0.0f) : make_float2(0.5f * re, 0.5f * im);
+            }
+            asm volatile("" : "+v"(xr[4 * q].x), "+v"(xr[4 * q].y), "+v"(xr[4 * q + 1].x), "+v"(xr[4 * q + 1].y), "+v"(xr[4 * q + 2].x),
+                              "+v"(xr[4 * q + 2].y), "+v"(xr[4 * q + 3].x), "+v"(xr[4 * q + 3].y) :: "memory");
+        }
+        float g_nyq = 0.0f;
+        if (l == 0) {
+            const int m0n = S.fbt_start[kN];
+#pragma unroll
+            for (int j = 0; j < SPAN_CAP; ++j) g_nyq = fmaf(S.fbt_w[kN * SPAN_CAP + j], dy[m0n + j].x, g_nyq);
+        }
+        phase_done(xr);
+        lds_wave_fence();
+        park_vector(blk, xr, l);
+        lds_wave_fence();
+        int lp = here(l);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (r == 8) half_done<0>(xr);
+            float2 gc = conjf2(mirror_of(blk, r, l));
+            if (r == 0 && l == 0) gc = make_float2(g_nyq, 0.0f);
+            const float2 e = cadd(xr[r], gc), d = csub(xr[r], gc);
+            const float2 wd = cmulf(conjf2(kTw512[lp + 16 * r]), d);
+            xr[r] = make_float2(e.x - wd.y, e.y + wd.x);
+        }
+        fft256_reg<true>(xr, S.c.twl, blk, l);
+        lds_wave_fence();
+        lp = here(l);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float2 wv = reinterpret_cast<const float2 *>(w)[lp + 16 * r];
+            blk[l + 16 * r] = live ? make_float2(wv.x * xr[r].x, wv.y * xr[r].y) : make_float2(0.0f, 0.0f);
+        }
+        lds_wave_fence();
+        const float *df = reinterpret_cast<const float *>(S.c.blk[wave][0]);
+        if (interior(f0)) {
+            const bool carry_out = g + 1 < kBwdGroupsPerWave && f0 + kGroup < NF && interior(f0 + kGroup);
+            overlap_add_interior<2 * kFrameSlots>(df, dx + b * T + (f0 * hop - kN), lane, carry, carried, carry_out);
+            carried = carry_out;
+        } else {
+            overlap_add_frames_cold<2 * kFrameSlots>(df, dx + b * T, f0, NF, hop, T, lane, 64);
+            carried = false;
+        }
+        lds_wave_fence();
+    }
+}
+
 constexpr int64_t kMaxGridY = 65535;
 
 __global__ void stft_fill_kernel(float *p, int64_t n, float v) {
@@ -1249,6 +1496,14 @@ int advstep_stft_mel_f32(const float *x, const float *window, const int32_t *fb_
     STFT_REQUIRE(x && window && fb_start && fb_w && out && B <= kMaxGridY && M <= kMelMax && span <= kMelMaxSpan);
     STFT_REQUIRE(advstep_stft_bands_supported(nfft, hop, T) && NF == 1 + T / hop);
     hipStream_t st = as_stream(stream);
+    if (reg_fft_enabled() && span <= kMelRegSpan) {
+        const size_t lds_reg = sizeof(LdsMelReg);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(stft_mel_reg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds_reg);
+        hipLaunchKernelGGL(stft_mel_reg_kernel, dim3((unsigned)ceil_div(NF, kBandsFramesPerBlock), (unsigned)B), dim3(kThreads),
+                           lds_reg, st, x, window, fb_start, fb_w, (int)span, out, (int)T, (int)NF, (int)hop, (int)M);
+        return status_after_launch();
+    }
     const size_t lds = sizeof(LdsMel);
     auto go = [&](auto kernel) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1295,6 +1550,16 @@ int advstep_stft_mel_backward_from_output_f32(const float *window, const float *
     STFT_REQUIRE(kFramesPerBlockBwd * hop >= kNfft - hop);
     hipStream_t st = as_stream(stream);
     if (hipMemsetAsync(dx, 0, (size_t)B * T * sizeof(float), st) != hipSuccess) return ADVSTEP_ELAUNCH;
+    if (reg_fft_enabled()) {
+        auto go_reg = [&](auto kernel, size_t lds_reg) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_reg);
+            hipLaunchKernelGGL(kernel, dim3((unsigned)ceil_div(NF, kBwdFramesPerBlock), (unsigned)B), dim3(kThreads), lds_reg, st, window,
+                               dout, out, fbt_start, fbt_w, (int)span_t, dx, (int)T, (int)NF, (int)hop, (int)M);
+        };
+        if (span_t <= 2) go_reg(stft_mel_backward_out_reg_kernel<2>, sizeof(LdsMelRegBwd<2>));
+        else go_reg(stft_mel_backward_out_reg_kernel<kMaxSpanT>, sizeof(LdsMelRegBwd<kMaxSpanT>));
+        return status_after_launch();
+    }
     const size_t lds = sizeof(LdsMelBwdOut);
     auto go = [&](auto kernel) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

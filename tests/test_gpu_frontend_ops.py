@@ -116,8 +116,11 @@ def test_fused_mel_spec_matches_torch_chain(cuda, monkeypatch, B, T):
 
 def test_mel_backward_from_output_equals_backward_from_waveform(cuda, monkeypatch):
     """The shipped mel-spec gradient reconstructs d Y from the forward OUTPUT (|Y|, phase) and skips the spectrum; the first
-    version recomputed framing + FFT + band projection from the waveform.  Same gradient to 1e-5 relative (the output's
-    rounding enters through cos / sin of the stored phase); exact zeros where |Y| = 0 (silent utterance)."""
+    version recomputed framing + FFT + band projection from the waveform.  With the radix-4 kernels on both sides (the
+    recomputation runs the forward's own transform, bit for bit) the two agree to 1e-5 relative.  The shipped pair (round 4:
+    register-resident transform) is held against a float64 evaluation of the torch chain instead: its error is the same
+    4e-5 the radix-4 pair has — the float32 phase written by the forward enters through g_phase / |Y| either way — and exact
+    zeros come out where |Y| = 0 (silent utterance)."""
     from audio_deepfake_adversarial_attacks_amd.frontends import MelSpecFrontend
     fe = MelSpecFrontend().to(cuda)
     gen = torch.Generator().manual_seed(21)
@@ -125,16 +128,23 @@ def test_mel_backward_from_output_equals_backward_from_waveform(cuda, monkeypatc
     x[2] = 0.0
     gy = torch.randn(3, 2, 80, 404, generator=gen).to(cuda)
 
-    def run(from_output):
+    def run(from_output, reg):
         monkeypatch.setenv("ADVSTEP_MEL_BWD_FROM_OUTPUT", "1" if from_output else "0")
+        monkeypatch.setenv("ADVSTEP_STFT_REG", reg)
         a = x.clone().requires_grad_(True)
         (g,) = torch.autograd.grad(fe(a), a, gy)
         return g
 
-    g0, g1 = run(False), run(True)
+    g0, g1 = run(False, "0"), run(True, "0")
     assert (g0[:2] - g1[:2]).norm().item() <= 1e-5 * g0[:2].norm().item()
     assert not g0[2].any() and not g1[2].any()
-    assert torch.equal(run(True), g1)
+    shipped = run(True, "1")
+    assert not shipped[2].any() and torch.equal(run(True, "1"), shipped)
+    monkeypatch.setenv("ADVSTEP_FUSED_MEL", "0")
+    a = x.double().clone().requires_grad_(True)
+    (g64,) = torch.autograd.grad(MelSpecFrontend().to(cuda).double()(a), a, gy.double())
+    err = lambda g: ((g.double() - g64)[:2].norm() / g64[:2].norm()).item()
+    assert err(shipped) <= 1.5e-4 and err(shipped) <= 1.25 * err(g1), (err(shipped), err(g1))
 
 
 def test_fused_mel_spec_with_wide_bands(cuda, monkeypatch):
