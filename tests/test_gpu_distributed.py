@@ -96,7 +96,12 @@ def test_ranks_on_one_gpu_equal_single_process_shards(cuda, tmp_path, backend, w
     if backend == "nccl" and torch.cuda.device_count() < world:
         pytest.skip("needs two HIP devices (RCCL refuses two ranks on one device)")
     n_batch, n_items = _sizes(world)
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), backend), nprocs=world, join=True)
+    try:
+        mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), backend), nprocs=world, join=True)
+    except Exception as exc:       # keep the workers' traceback where a truncated console log cannot lose it
+        (ROOT / "gpurun_out").mkdir(exist_ok=True)
+        (ROOT / "gpurun_out" / f"distributed_{backend}_{world}_failure.txt").write_text(repr(exc) + "\n" + str(exc))
+        raise
     r = [np.load(tmp_path / f"rank{k}.npz") for k in range(world)]
     per_rank = (n_items // n_batch) * n_batch // world
     seen = set()
