@@ -102,6 +102,10 @@ SIGNATURES = {
     "advstep_lfcc_project_f32": (ctypes.c_int, [_p, _p, _p, _f32, _p, _i64, _i64, _i64, _i64, _p]),
     "advstep_lfcc_project_backward_f32": (ctypes.c_int, [_p, _p, _p, _p, _f32, _p, _i64, _i64, _i64, _i64, _p]),
     "advstep_lfcc_floor_fixup_f32": (ctypes.c_int, [_p, _p, _p, _i64, _p]),
+    "advstep_lfcc_project_fragment_floats": (ctypes.c_size_t, [_i64, _i64]),
+    "advstep_lfcc_project_prepare_f32": (ctypes.c_int, [_p, _i64, _i64, _p, _p]),
+    "advstep_lfcc_max_project_f32": (ctypes.c_int, [_p, _p, _p, _p, _i64, _p, _f32, _p, _i64, _i64, _i64, _i64, _p]),
+    "advstep_lfcc_project_backward_zero_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _f32, _p, _i64, _i64, _i64, _i64, _p, _i64, _p]),
     "advstep_lfcc_bands_backward_f32": (ctypes.c_int, [_p, _p, _p, _p, _i64, _p, _i64, _i64, _i64, _i64, ctypes.c_int, _p]),
     "advstep_stft_frames_f32": (ctypes.c_int, [_p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p]),
     "advstep_stft_overlap_add_f32": (ctypes.c_int, [_p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p]),
@@ -109,6 +113,8 @@ SIGNATURES = {
     "advstep_stft_bands_supported": (ctypes.c_int, [_i64, _i64, _i64]),
     "advstep_stft_bands_f32": (ctypes.c_int, [_p, _p, _p, _p, _i64, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _p]),
     "advstep_stft_bands_backward_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _p, _i64, _i64, _i64, _i64, _i64, _i64, _p]),
+    "advstep_stft_bands_backward_fixup_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _p, ctypes.c_int, _i64, _i64, _i64, _i64,
+                                                             _i64, _i64, _p]),
     "advstep_stft_mel_f32": (ctypes.c_int, [_p, _p, _p, _p, _i64, _p, _i64, _i64, _i64, _i64, _i64, _i64, _p]),
     "advstep_stft_mel_backward_from_output_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _p, _i64, _i64, _i64, _i64, _i64, _i64, _p]),
     "advstep_stft_mel_backward_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _p, _p, _i64, _p, _i64, _i64, _i64, _i64, _i64,

@@ -194,198 +194,277 @@ __global__ __launch_bounds__(kBlock) void lfcc_project_backward_kernel(const flo
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// The DCT projection as a true dense contraction on the matrix cores (fp32-in / fp32-accumulate MFMA, exact f32):
+// The DCT projection as a dense contraction on the matrix cores (fp32-in / fp32-accumulate MFMA, exact f32 products):
 //   out (frames x 80) = max(band_db, floor) (frames x 128) . dct (128 x 80)           K = 128
 //   g   (frames x 128) = dout (frames x 80) . dct^T (80 x 128)                         K = 80
-// v_mfma_f32_32x32x2_f32: lane l supplies A[i = l & 31][k = l >> 5] and B[k = l >> 5][j = l & 31]; the 32x32
-// accumulator lives in 16 registers, col = l & 31, row = (r & 3) + 8 (r >> 2) + 4 (l >> 5).
-// One wave owns 32 frames; a 256-thread workgroup owns 128.  Operands are staged in LDS with odd row pitches so the
-// per-step fragment reads are bank-conflict free.  Specialised for M = 128, K = 80 (LFCC); other sizes use the VALU
-// kernels above.
+// v_mfma_f32_16x16x4_f32: lane l = (g = l >> 4, j = l & 15) supplies A[j][k = g] and B[k = g][n = j]; the 16 x 16 result sits
+// in 4 registers, D[4 g + r][j].  (B, NF) is one flat frame axis (the floor is batch-wide, nothing is per utterance).
+//
+// Shape of both kernels (round 4; measured steps in profiles/r04_lfcc_project_experiments.txt):
+//  * 64 frames and FOUR waves per workgroup, <= 34 KB of LDS and <= 128 registers: four workgroups per CU, so the 808
+//    workgroups of a B = 128 batch are resident at once, one wave of each on every SIMD.  (Five waves per workgroup - one per
+//    16 output columns - measured 14 us for 8.5 us of matrix instructions: every workgroup's fifth wave lands on the SIMD of
+//    its first.  Rounds 1 - 3 staged both operands of a 128-frame tile in 115 / 150 KB: one workgroup per CU, loads, matrix
+//    instructions and stores one after the other - 29 / 46 us.)
+//  * The DCT side of a wave is constant over its contraction and lives in REGISTERS, loaded as 16-byte pieces of a fragment
+//    table (advstep_lfcc_project_prepare_f32: the DCT re-ordered once per weight version so that a lane's values for four
+//    consecutive k-steps are one float4 and a wave's request is 1 KB contiguous).  Reading the (128, 80) matrix itself in
+//    operand order is one lane per cycle in the texture addresser - 16 rows x 16 bytes per dword load, 64 cycles each: 10 us
+//    of a 36 us backward kernel went there.
+//  * The frame side streams from an LDS tile all four waves share - staged with 16-byte loads / stores at a pitch of
+//    (row length + 4) words, which makes the fragment read tile[16 rb + j][4 s + g] hit 64 different banks; one base register,
+//    immediate offsets.
+//  * Results leave through the same LDS tile: accumulators -> tile (conflict-free at pitch 84 / 132) -> whole rows as 16-byte
+//    stores (64-byte pieces straight from the accumulator layout cost 4.7 / 8.5 us of stores).
+// Forward: wave w owns output columns 16 w .. 16 w + 15 for all four 16-frame row blocks, and columns 64 .. 79 for row block w
+// (5 accumulators, 160 matrix instructions per wave, 2 x 32 DCT registers).  Backward: wave w owns bands 32 w .. 32 w + 31
+// (8 accumulators, 160 matrix instructions, 2 x 20 DCT registers).
+// Specialised for M = 128, K = 80 (LFCC); other sizes use the VALU kernels above.
 // ---------------------------------------------------------------------------------------------------------
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int kMfmaFrames = 128;   // frames per workgroup (4 waves x 32)
-constexpr int kLfccM = 128, kLfccK = 80, kLfccKPad = 96;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kLfccM = 128, kLfccK = 80;
+constexpr int kPTile = 64, kPThreads = 256;                          // frames / threads per workgroup
+constexpr int kBandPitch = kLfccM + 4, kCepPitch = kLfccK + 4;       // 132, 84 words
+constexpr int kFragFloats = kLfccM * kLfccK;                         // per direction
 
-__device__ __forceinline__ int mfma_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
-
-__global__ __launch_bounds__(kBlock) void lfcc_project_mfma_kernel(const float *__restrict__ band_db,
-                                                                   const float *__restrict__ dct, float *stats,
-                                                                   float top_db, float *__restrict__ out, int NF) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float(*band_s)[kLfccM + 1] = reinterpret_cast<float(*)[kLfccM + 1]>(smem);                      // [128][129]
-    float(*dct_s)[kLfccKPad] = reinterpret_cast<float(*)[kLfccKPad]>(smem + kMfmaFrames * (kLfccM + 1));  // [128][96]
-    const int64_t b = blockIdx.y;
-    const int t0 = blockIdx.x * kMfmaFrames;
-    const int nfr = NF - t0 < kMfmaFrames ? NF - t0 : kMfmaFrames;
-    const float gmax = stats[0];
-    const float floor_db = gmax - top_db;
-    const float *src = band_db + (b * NF + t0) * kLfccM;
-    int ties = 0;
-    // stage the (frames x 128) band tile and the DCT with 16-byte global loads, several in flight per thread
-    // all 16 loads of a thread are issued before the first is used (a load -> wait -> LDS write loop is one HBM latency
-    // per iteration: 16 of them were the whole kernel time); rows beyond the tile read a clamped address and are zeroed
-    const float4 *src4 = reinterpret_cast<const float4 *>(src);
-    constexpr int kStage = kMfmaFrames * kLfccM / 4 / kBlock;   // 16
-    const int lim = nfr * kLfccM / 4;
-    float4 st[kStage];
-#pragma unroll
-    for (int j = 0; j < kStage; ++j) {
-        const int i = threadIdx.x + j * kBlock;
-        st[j] = src4[i < lim ? i : lim - 1];
-    }
-#pragma unroll
-    for (int j = 0; j < kStage; ++j) {
-        const int i = threadIdx.x + j * kBlock;
-        float4 v = st[j];
-        if (i < lim) {
-            ties += (v.x == gmax) + (v.y == gmax) + (v.z == gmax) + (v.w == gmax);
-            float *pv = &v.x;
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                pv[e] = (pv[e] != pv[e]) ? pv[e] : ((floor_db != floor_db) ? floor_db : (pv[e] > floor_db ? pv[e] : floor_db));
-        } else {
-            v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        }
-        float *row = &band_s[i >> 5][(i & 31) * 4];
-        row[0] = v.x; row[1] = v.y; row[2] = v.z; row[3] = v.w;
-    }
-    const float4 *dct4 = reinterpret_cast<const float4 *>(dct);
-    constexpr int kDctStage = kLfccM * kLfccKPad / 4 / kBlock;   // 12
-    float4 dt[kDctStage];
-#pragma unroll
-    for (int j = 0; j < kDctStage; ++j) {
-        const int i = threadIdx.x + j * kBlock, m = i / (kLfccKPad / 4), k4 = i - m * (kLfccKPad / 4);
-        dt[j] = dct4[m * (kLfccK / 4) + (k4 < kLfccK / 4 ? k4 : 0)];
-    }
-#pragma unroll
-    for (int j = 0; j < kDctStage; ++j) {
-        const int i = threadIdx.x + j * kBlock, m = i / (kLfccKPad / 4), k4 = i - m * (kLfccKPad / 4);
-        *reinterpret_cast<float4 *>(&dct_s[m][k4 * 4]) = k4 < kLfccK / 4 ? dt[j] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    }
-    if (ties) atomicAdd(&stats[1], (float)ties);
-    __syncthreads();
-
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int row0 = wave * 32;
-    if (row0 < nfr) {  // wave-uniform
-        f32x16 acc0 = {0}, acc1 = {0}, acc2 = {0};
-        const int li = lane & 31, lk = lane >> 5;
-#pragma unroll 4
-        for (int s = 0; s < kLfccM / 2; ++s) {
-            const float a = band_s[row0 + li][2 * s + lk];
-            const float *br = dct_s[2 * s + lk];
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, br[li], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, br[32 + li], acc1, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, br[64 + li], acc2, 0, 0, 0);
-        }
-        float *dst = out + (b * NF + t0 + row0) * kLfccK;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = mfma_row(r, lane);
-            if (row0 + row < nfr) {
-                float *o = dst + (int64_t)row * kLfccK;
-                o[li] = acc0[r];
-                o[32 + li] = acc1[r];
-                if (li < kLfccK - 64) o[64 + li] = acc2[r];
-            }
-        }
+// frag[0 .. MK): forward,  F[c][q][lane][e] = dct[4 (4 q + e) + g][16 c + j],  c < 5, q < 8
+// frag[MK .. 2 MK): backward, G[c][q][lane][e] = dct[16 c + j][4 (4 q + e) + g],  c < 8, q < 5
+__global__ __launch_bounds__(kBlock) void lfcc_project_prepare_kernel(const float *__restrict__ dct, float *__restrict__ frag) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= 2 * kFragFloats) return;
+    const bool bwd = i >= kFragFloats;
+    const int r = bwd ? i - kFragFloats : i;
+    const int e = r & 3, lane = (r >> 2) & 63, j = lane & 15, g = lane >> 4, cq = r >> 8;
+    if (!bwd) {
+        const int c = cq / 8, q = cq % 8;
+        frag[i] = dct[(4 * (4 * q + e) + g) * kLfccK + 16 * c + j];
+    } else {
+        const int c = cq / 5, q = cq % 5;
+        frag[i] = dct[(16 * c + j) * kLfccK + 4 * (4 * q + e) + g];
     }
 }
 
-__global__ __launch_bounds__(kBlock) void lfcc_project_backward_mfma_kernel(const float *__restrict__ dout,
-                                                                            const float *__restrict__ dct,
-                                                                            const float *__restrict__ band_db,
-                                                                            float *stats, float top_db,
-                                                                            float *__restrict__ dband, int NF) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float(*g_s)[kLfccK + 1] = reinterpret_cast<float(*)[kLfccK + 1]>(smem);                           // [128][81]
-    float(*dct_s)[kLfccK + 1] = reinterpret_cast<float(*)[kLfccK + 1]>(smem + kMfmaFrames * (kLfccK + 1));  // [128][81]
-    float(*band_s)[kLfccM + 1] =
-        reinterpret_cast<float(*)[kLfccM + 1]>(smem + (kMfmaFrames + kLfccM) * (kLfccK + 1));               // [128][129]
-    __shared__ float red[kBlock / 64];
-    const int64_t b = blockIdx.y;
-    const int t0 = blockIdx.x * kMfmaFrames;
-    const int nfr = NF - t0 < kMfmaFrames ? NF - t0 : kMfmaFrames;
-    const float *src = dout + (b * NF + t0) * kLfccK;
-    // staging in batches: every load of a batch is issued before the first is used (see the forward kernel)
-    const float4 *src4 = reinterpret_cast<const float4 *>(src);
-    const float4 *dct4 = reinterpret_cast<const float4 *>(dct);
-    const float4 *band4 = reinterpret_cast<const float4 *>(band_db + (b * NF + t0) * kLfccM);
-    constexpr int kGStage = kMfmaFrames * kLfccK / 4 / kBlock;   // 10 (dout tile and the DCT have the same size)
-    constexpr int kBStage = kMfmaFrames * kLfccM / 4 / kBlock;   // 16
-    static_assert(kMfmaFrames == kLfccM, "the dout tile and the DCT are staged with the same index map");
-    {
-        const int lim = nfr * kLfccK / 4;
-        float4 gq[kGStage], dq[kGStage];
+// grid ceil(F / 64), F = B NF frames; block 256.  The batch maximum is reduced here, by every workgroup, from the `nblk`
+// per-workgroup maxima the band kernel left (13 KB at B = 128: L2-resident, the reads ride under the tile's own loads) - no
+// one-workgroup reduction launch between the two kernels; workgroup 0 publishes stats = {max, 0, 0, 1}: the tie count is left to
+// the backward pass (stats[3] == 1 tells it so), which sees every dB value anyway.
+__global__ __launch_bounds__(kPThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void lfcc_project_mfma_kernel(const float *__restrict__ band_db,
+                                                                     const float *__restrict__ frag,
+                                                                     const float *__restrict__ block_maxima, int nblk,
+                                                                     float *stats, float top_db, float *__restrict__ out,
+                                                                     int64_t F) {
+    __shared__ __attribute__((aligned(16))) float tile[kPTile * kBandPitch];     // 33 792 B: the dB tile, then the cepstra
+    __shared__ float red[kPThreads / 64];
+    const int64_t f0 = (int64_t)blockIdx.x * kPTile;
+    const int nfr = F - f0 < kPTile ? (int)(F - f0) : kPTile;
+    // the block maxima first (loads return in order: their reduction then runs while the tile is still in flight), in batches
+    // of 8 independent loads - a plain strided loop is one L2 round trip per iteration
+    float v = -INFINITY;
+    for (int base = 0; base < nblk; base += 8 * kPThreads) {
+        float t[8];
 #pragma unroll
-        for (int j = 0; j < kGStage; ++j) {
-            const int i = threadIdx.x + j * kBlock;
-            gq[j] = src4[i < lim ? i : lim - 1];
-            dq[j] = dct4[i];
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + u * kPThreads + threadIdx.x;
+            t[u] = block_maxima[i < nblk ? i : nblk - 1];
         }
 #pragma unroll
-        for (int j = 0; j < kGStage; ++j) {
-            const int i = threadIdx.x + j * kBlock, t = i / (kLfccK / 4), k4 = i - t * (kLfccK / 4);
-            const float4 v = i < lim ? gq[j] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            float *row = &g_s[t][k4 * 4];
-            row[0] = v.x; row[1] = v.y; row[2] = v.z; row[3] = v.w;
-            float *drow = &dct_s[t][k4 * 4];
-            drow[0] = dq[j].x; drow[1] = dq[j].y; drow[2] = dq[j].z; drow[3] = dq[j].w;
+        for (int u = 0; u < 8; ++u) v = max_nan(v, t[u]);
+    }
+    // the (frames x 128) tile: every load of a thread is in flight before the first is used; rows beyond the last frame read
+    // a clamped address and are zeroed
+    const float4 *src4 = reinterpret_cast<const float4 *>(band_db + f0 * kLfccM);
+    constexpr int kStage = kPTile * kLfccM / 4 / kPThreads;   // 8
+    const int lim = nfr * (kLfccM / 4);
+    float4 st[kStage];
+#pragma unroll
+    for (int u = 0; u < kStage; ++u) {
+        const int i = threadIdx.x + u * kPThreads;
+        st[u] = src4[i < lim ? i : lim - 1];
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lj = lane & 15, lg = lane >> 4;
+    // DCT fragments: columns 16 w .. (own) and 64 .. 79 (shared out by row block)
+    float4 bo[kLfccM / 16], bs[kLfccM / 16];
+    {
+        const float4 *f4 = reinterpret_cast<const float4 *>(frag);
+#pragma unroll
+        for (int q = 0; q < kLfccM / 16; ++q) {
+            bo[q] = f4[(wave * (kLfccM / 16) + q) * 64 + lane];
+            bs[q] = f4[(4 * (kLfccM / 16) + q) * 64 + lane];
         }
     }
-    {
-        const int lim = nfr * kLfccM / 4;
-        float4 bq[kBStage];
+    const float gmax = block_max(v, red);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        stats[0] = gmax;
+        stats[1] = 0.0f;
+        stats[2] = 0.0f;
+        stats[3] = 1.0f;
+    }
+    const float floor_db = gmax - top_db;
 #pragma unroll
-        for (int j = 0; j < kBStage; ++j) {
-            const int i = threadIdx.x + j * kBlock;
-            bq[j] = band4[i < lim ? i : lim - 1];
-        }
+    for (int u = 0; u < kStage; ++u) {
+        const int i = threadIdx.x + u * kPThreads;
+        float4 q = st[u];
+        if (i < lim) {
+            float *pv = &q.x;
 #pragma unroll
-        for (int j = 0; j < kBStage; ++j) {
-            const int i = threadIdx.x + j * kBlock;
-            if (i < lim) {
-                float *row = &band_s[i >> 5][(i & 31) * 4];
-                row[0] = bq[j].x; row[1] = bq[j].y; row[2] = bq[j].z; row[3] = bq[j].w;
-            }
+            for (int e = 0; e < 4; ++e)      // torch.max(x, floor): NaN kept
+                pv[e] = (pv[e] != pv[e]) ? pv[e] : ((floor_db != floor_db) ? floor_db : (pv[e] > floor_db ? pv[e] : floor_db));
+        } else {
+            q = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
+        *reinterpret_cast<float4 *>(&tile[(i >> 5) * kBandPitch + (i & 31) * 4]) = q;
     }
     __syncthreads();
 
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int row0 = wave * 32;
-    const float floor_db = stats[0] - top_db;
-    float floored = 0.0f;
-    if (row0 < nfr) {
-        f32x16 acc[4] = {{0}, {0}, {0}, {0}};
-        const int li = lane & 31, lk = lane >> 5;
-#pragma unroll 4
-        for (int s = 0; s < kLfccK / 2; ++s) {
-            const int k = 2 * s + lk;
-            const float a = g_s[row0 + li][k];
+    f32x4 acc[4], accs = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, dct_s[32 * j + li][k], acc[j], 0, 0, 0);
+    for (int rb = 0; rb < 4; ++rb) acc[rb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    const float *ap = tile + lj * kBandPitch + lg;
+    const float *aw = ap + wave * 16 * kBandPitch;             // this wave's row block, for the shared columns
+#pragma unroll
+    for (int q = 0; q < kLfccM / 16; ++q) {
+        const float bov[4] = {bo[q].x, bo[q].y, bo[q].z, bo[q].w}, bsv[4] = {bs[q].x, bs[q].y, bs[q].z, bs[q].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int s = 4 * q + e;
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb)
+                acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[rb * 16 * kBandPitch + 4 * s], bov[e], acc[rb], 0, 0, 0);
+            accs = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[4 * s], bsv[e], accs, 0, 0, 0);
         }
-        float *dst = dband + (b * NF + t0 + row0) * kLfccM;
+    }
+    __syncthreads();                                           // every wave is done reading the dB tile
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = mfma_row(r, lane);
-            if (row0 + row < nfr) {
+    for (int r = 0; r < 4; ++r) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int m = 32 * j + li;
-                    const float db = band_s[row0 + row][m];
-                    const float sgrad = acc[j][r];
-                    const float wgt = db > floor_db ? 1.0f : (db == floor_db ? 0.5f : 0.0f);
-                    floored += (1.0f - wgt) * sgrad;
-                    dst[(int64_t)row * kLfccM + m] = (wgt * sgrad) * dlog_of_db(db);
-                }
+        for (int rb = 0; rb < 4; ++rb) tile[(16 * rb + 4 * lg + r) * kCepPitch + 16 * wave + lj] = acc[rb][r];
+        tile[(16 * wave + 4 * lg + r) * kCepPitch + 64 + lj] = accs[r];
+    }
+    __syncthreads();
+    float4 *dst4 = reinterpret_cast<float4 *>(out + f0 * kLfccK);
+    constexpr int kOut4 = kPTile * kLfccK / 4;                 // 1280 = 5 x 256
+    const int olim = nfr * (kLfccK / 4);
+#pragma unroll
+    for (int u = 0; u < kOut4 / kPThreads; ++u) {
+        const int i = threadIdx.x + u * kPThreads;
+        const int t = i / (kLfccK / 4), k4 = i - t * (kLfccK / 4);
+        if (i < olim) dst4[i] = *reinterpret_cast<const float4 *>(&tile[t * kCepPitch + 4 * k4]);
+    }
+}
+
+// grid ceil(F / 64); block 256.  `zero` (may be null): zero_n floats this launch also zero-fills - the waveform gradient the
+// overlap-add kernel behind it accumulates into (33 MB of stores that ride under this kernel's loads instead of a memset node of
+// their own).  stats[3] == 1 (left by the forward kernel above): count the elements equal to the batch maximum into stats[1].
+__global__ __launch_bounds__(kPThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void lfcc_project_backward_mfma_kernel(const float *__restrict__ dout,
+                                                                              const float *__restrict__ frag,
+                                                                              const float *__restrict__ band_db,
+                                                                              float *stats, float top_db,
+                                                                              float *__restrict__ dband, int64_t F,
+                                                                              float *__restrict__ zero, int64_t zero_n) {
+    __shared__ __attribute__((aligned(16))) float tile[kPTile * kBandPitch];     // the dout tile [64][84], then dband [64][132]
+    __shared__ float red[kPThreads / 64];
+    const int64_t f0 = (int64_t)blockIdx.x * kPTile;
+    const int nfr = F - f0 < kPTile ? (int)(F - f0) : kPTile;
+    const float4 *src4 = reinterpret_cast<const float4 *>(dout + f0 * kLfccK);
+    constexpr int kIn4 = kPTile * kLfccK / 4;                  // 1280 = 5 x 256
+    const int lim = nfr * (kLfccK / 4);
+    float4 st[kIn4 / kPThreads];
+#pragma unroll
+    for (int u = 0; u < kIn4 / kPThreads; ++u) {
+        const int i = threadIdx.x + u * kPThreads;
+        st[u] = src4[i < lim ? i : lim - 1];
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lj = lane & 15, lg = lane >> 4;
+    float4 bq[2][kLfccK / 16];
+    {
+        const float4 *f4 = reinterpret_cast<const float4 *>(frag + kFragFloats);
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+            for (int q = 0; q < kLfccK / 16; ++q) bq[cc][q] = f4[((2 * wave + cc) * (kLfccK / 16) + q) * 64 + lane];
+    }
+    if (zero) {
+        const int64_t gid = (int64_t)blockIdx.x * kPThreads + threadIdx.x, total = (int64_t)gridDim.x * kPThreads;
+        if ((reinterpret_cast<uintptr_t>(zero) & 15u) == 0) {
+            float4 *z4 = reinterpret_cast<float4 *>(zero);
+            const int64_t n4 = zero_n / 4;
+            for (int64_t i = gid; i < n4; i += total) z4[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            for (int64_t i = n4 * 4 + gid; i < zero_n; i += total) zero[i] = 0.0f;
+        } else {
+            for (int64_t i = gid; i < zero_n; i += total) zero[i] = 0.0f;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < kIn4 / kPThreads; ++u) {
+        const int i = threadIdx.x + u * kPThreads;
+        const int t = i / (kLfccK / 4), k4 = i - t * (kLfccK / 4);
+        *reinterpret_cast<float4 *>(&tile[t * kCepPitch + k4 * 4]) = i < lim ? st[u] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    // the dB rows the epilogue needs, whole rows as 16-byte loads: requested before the products
+    const float4 *band4 = reinterpret_cast<const float4 *>(band_db + f0 * kLfccM);
+    constexpr int kOut4 = kPTile * kLfccM / 4 / kPThreads;     // 8
+    const int blim = nfr * (kLfccM / 4);
+    float4 db[kOut4];
+#pragma unroll
+    for (int u = 0; u < kOut4; ++u) {
+        const int i = threadIdx.x + u * kPThreads;
+        db[u] = band4[i < blim ? i : blim - 1];
+    }
+    __syncthreads();
+
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) acc[rb][0] = acc[rb][1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    const float *ap = tile + lj * kCepPitch + lg;
+#pragma unroll
+    for (int q = 0; q < kLfccK / 16; ++q) {
+        const float b0[4] = {bq[0][q].x, bq[0][q].y, bq[0][q].z, bq[0][q].w};
+        const float b1[4] = {bq[1][q].x, bq[1][q].y, bq[1][q].z, bq[1][q].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int s = 4 * q + e;
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) {
+                const float a = ap[rb * 16 * kCepPitch + 4 * s];
+                acc[rb][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0[e], acc[rb][0], 0, 0, 0);
+                acc[rb][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1[e], acc[rb][1], 0, 0, 0);
             }
         }
     }
+    __syncthreads();                                           // every wave is done reading the dout tile
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc)
+                tile[(16 * rb + 4 * lg + r) * kBandPitch + 16 * (2 * wave + cc) + lj] = acc[rb][cc][r];
+    __syncthreads();
+    const float gmax = stats[0], floor_db = gmax - top_db;
+    const bool count_ties = stats[3] == 1.0f;
+    float floored = 0.0f;
+    int ties = 0;
+    float4 *dst4 = reinterpret_cast<float4 *>(dband + f0 * kLfccM);
+#pragma unroll
+    for (int u = 0; u < kOut4; ++u) {
+        const int i = threadIdx.x + u * kPThreads;
+        if (i < blim) {
+            const float4 sg = *reinterpret_cast<const float4 *>(&tile[(i >> 5) * kBandPitch + (i & 31) * 4]);
+            const float sv[4] = {sg.x, sg.y, sg.z, sg.w}, dv[4] = {db[u].x, db[u].y, db[u].z, db[u].w};
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = dv[e];
+                ties += (d == gmax) ? 1 : 0;
+                const float wgt = d > floor_db ? 1.0f : (d == floor_db ? 0.5f : 0.0f);   // torch.max(a, b) backward
+                floored += (1.0f - wgt) * sv[e];
+                o[e] = (wgt * sv[e]) * dlog_of_db(d);
+            }
+            dst4[i] = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+    if (count_ties && ties) atomicAdd(&stats[1], (float)ties);
     floored = block_sum(floored, red);
     if (threadIdx.x == 0 && floored != 0.0f) atomicAdd(&stats[2], floored);
 }
@@ -522,19 +601,39 @@ int advstep_lfcc_project_f32(const float *band_db, const float *dct, float *stat
     LFCC_REQUIRE(band_db && dct && stats && out && B <= kMaxGridY && M <= INT32_MAX && NF <= INT32_MAX);
     const dim3 grid((unsigned)ceil_div(NF, kFrames), (unsigned)B);
     hipStream_t st = as_stream(stream);
-    if (K == kLfccK && M == kLfccM) {  // matrix-core path
-        const dim3 mgrid((unsigned)ceil_div(NF, kMfmaFrames), (unsigned)B);
-        const size_t lds = (size_t)(kMfmaFrames * (kLfccM + 1) + kLfccM * kLfccKPad) * sizeof(float);
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(lfcc_project_mfma_kernel),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)attr;  // > 64 KiB of dynamic LDS must be opted into once
-        hipLaunchKernelGGL(lfcc_project_mfma_kernel, mgrid, dim3(kBlock), lds, st, band_db, dct, stats, top_db, out, (int)NF);
-    } else if (K == 80)
+    if (K == 80)
         hipLaunchKernelGGL(lfcc_project_kernel<20>, grid, dim3(kBlock), 0, st, band_db, dct, stats, top_db, out, (int)M, (int)NF);
     else if (K == 40)
         hipLaunchKernelGGL(lfcc_project_kernel<10>, grid, dim3(kBlock), 0, st, band_db, dct, stats, top_db, out, (int)M, (int)NF);
     else
         hipLaunchKernelGGL(lfcc_project_kernel<5>, grid, dim3(kBlock), 0, st, band_db, dct, stats, top_db, out, (int)M, (int)NF);
+    return status_after_launch();
+}
+
+size_t advstep_lfcc_project_fragment_floats(int64_t M, int64_t K) {
+    return (M == kLfccM && K == kLfccK) ? (size_t)2 * kFragFloats : 0;
+}
+
+int advstep_lfcc_project_prepare_f32(const float *dct, int64_t M, int64_t K, float *frag, advstep_stream_t stream) {
+    if (!(M == kLfccM && K == kLfccK)) return ADVSTEP_OK;          // no matrix-core path for this size: nothing to prepare
+    LFCC_REQUIRE(dct && frag && (reinterpret_cast<uintptr_t>(frag) & 15u) == 0);
+    hipLaunchKernelGGL(lfcc_project_prepare_kernel, dim3((unsigned)ceil_div(2 * kFragFloats, kBlock)), dim3(kBlock), 0,
+                       as_stream(stream), dct, frag);
+    return status_after_launch();
+}
+
+int advstep_lfcc_max_project_f32(const float *band_db, const float *dct, const float *frag, const float *block_max, int64_t n,
+                                 float *stats, float top_db, float *out, int64_t B, int64_t M, int64_t NF, int64_t K,
+                                 advstep_stream_t stream) {
+    LFCC_REQUIRE(n >= 1 && block_max && stats);
+    if (!(K == kLfccK && M == kLfccM) || !frag || B <= 0 || NF <= 0 || n > INT32_MAX) {      // other sizes: the two launches
+        const int st = advstep_lfcc_reduce_max_f32(block_max, n, stats, stream);
+        return st != ADVSTEP_OK ? st : advstep_lfcc_project_f32(band_db, dct, stats, top_db, out, B, M, NF, K, stream);
+    }
+    LFCC_REQUIRE(band_db && out && B * NF <= INT32_MAX && (reinterpret_cast<uintptr_t>(frag) & 15u) == 0 &&
+                 (reinterpret_cast<uintptr_t>(band_db) & 15u) == 0 && (reinterpret_cast<uintptr_t>(out) & 15u) == 0);
+    hipLaunchKernelGGL(lfcc_project_mfma_kernel, dim3((unsigned)ceil_div(B * NF, kPTile)), dim3(kPThreads), 0, as_stream(stream),
+                       band_db, frag, block_max, (int)n, stats, top_db, out, B * NF);
     return status_after_launch();
 }
 
@@ -546,21 +645,29 @@ int advstep_lfcc_project_backward_f32(const float *dout, const float *dct, const
     LFCC_REQUIRE(dout && dct && band_db && stats && dband && B <= kMaxGridY && M <= INT32_MAX && NF <= INT32_MAX);
     const dim3 grid((unsigned)ceil_div(NF, kFrames), (unsigned)B);
     hipStream_t st = as_stream(stream);
-    if (K == kLfccK && M == kLfccM) {  // matrix-core path
-        const dim3 mgrid((unsigned)ceil_div(NF, kMfmaFrames), (unsigned)B);
-        const size_t lds =
-            (size_t)(kMfmaFrames * (kLfccK + 1) + kLfccM * (kLfccK + 1) + kMfmaFrames * (kLfccM + 1)) * sizeof(float);
-        static const hipError_t attr = hipFuncSetAttribute(
-            reinterpret_cast<const void *>(lfcc_project_backward_mfma_kernel),
-            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)attr;
-        hipLaunchKernelGGL(lfcc_project_backward_mfma_kernel, mgrid, dim3(kBlock), lds, st, dout, dct, band_db, stats, top_db, dband, (int)NF);
-    } else if (K == 80)
+    if (K == 80)
         hipLaunchKernelGGL(lfcc_project_backward_kernel<20>, grid, dim3(kBlock), 0, st, dout, dct, band_db, stats, top_db, dband, (int)M, (int)NF);
     else if (K == 40)
         hipLaunchKernelGGL(lfcc_project_backward_kernel<10>, grid, dim3(kBlock), 0, st, dout, dct, band_db, stats, top_db, dband, (int)M, (int)NF);
     else
         hipLaunchKernelGGL(lfcc_project_backward_kernel<5>, grid, dim3(kBlock), 0, st, dout, dct, band_db, stats, top_db, dband, (int)M, (int)NF);
+    return status_after_launch();
+}
+
+int advstep_lfcc_project_backward_zero_f32(const float *dout, const float *dct, const float *frag, const float *band_db,
+                                           float *stats, float top_db, float *dband, int64_t B, int64_t M, int64_t NF,
+                                           int64_t K, float *zero, int64_t zero_n, advstep_stream_t stream) {
+    LFCC_REQUIRE(zero_n >= 0 && (zero || zero_n == 0));
+    if (!(K == kLfccK && M == kLfccM) || !frag || B <= 0 || NF <= 0) {             // other sizes: a memset node + the plain call
+        if (zero_n > 0 && hipMemsetAsync(zero, 0, (size_t)zero_n * sizeof(float), as_stream(stream)) != hipSuccess)
+            return ADVSTEP_ELAUNCH;
+        return advstep_lfcc_project_backward_f32(dout, dct, band_db, stats, top_db, dband, B, M, NF, K, stream);
+    }
+    LFCC_REQUIRE(dout && band_db && stats && dband && B * NF <= INT32_MAX && (reinterpret_cast<uintptr_t>(frag) & 15u) == 0 &&
+                 (reinterpret_cast<uintptr_t>(dout) & 15u) == 0 && (reinterpret_cast<uintptr_t>(band_db) & 15u) == 0 &&
+                 (reinterpret_cast<uintptr_t>(dband) & 15u) == 0);
+    hipLaunchKernelGGL(lfcc_project_backward_mfma_kernel, dim3((unsigned)ceil_div(B * NF, kPTile)), dim3(kPThreads), 0,
+                       as_stream(stream), dout, frag, band_db, stats, top_db, dband, B * NF, zero_n > 0 ? zero : nullptr, zero_n);
     return status_after_launch();
 }
 

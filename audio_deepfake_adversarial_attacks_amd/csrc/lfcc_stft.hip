@@ -31,6 +31,10 @@ constexpr int kWavesPerBlock = 4;
 constexpr int kThreads = kWavesPerBlock * 64;
 constexpr int kFramesPerBlockBwd = 4;   // one per wave: 35 KB of LDS per workgroup = 4 workgroups (16 waves) per CU
 constexpr float kAmin = 1e-10f;
+// d/d band of 10 log10(clamp(band, amin)), band recovered from its dB value (the same function as in lfcc.hip)
+__device__ __forceinline__ float dlog_of_db(float db) {
+    return (db > -100.0f) ? 4.342944819032518f / expf(db * 0.23025850929940457f) : 0.0f;
+}
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 inline hipStream_t as_stream(advstep_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
@@ -625,7 +629,7 @@ __global__ __launch_bounds__(kThreads) void stft_bands_reg_kernel(const float *_
                                                                   const int32_t *__restrict__ fb_start,
                                                                   const float *__restrict__ fb_w, int span,
                                                                   float *__restrict__ band_db, float *__restrict__ bmax, int T,
-                                                                  int NF, int hop, int M) {
+                                                                  int NF, int hop, int M, int bmax_tail) {
     __shared__ LdsRegFwd SF;
     LdsReg &S = SF.c;
     fill_reg_tables(S);
@@ -700,6 +704,10 @@ __global__ __launch_bounds__(kThreads) void stft_bands_reg_kernel(const float *_
         float r = S.red[0];
         for (int i = 1; i < kWavesPerBlock; ++i) r = max_nan(r, S.red[i]);
         bmax[b * gridDim.x + blockIdx.x] = r;
+        // the rest of block_max (it is sized for the radix-4 kernel's 16-frame workgroups, and its consumer reduces over all of
+        // it) must not hold garbage: shared out over the workgroups instead of a fill launch in front of this kernel
+        const int total = gridDim.x * gridDim.y;
+        for (int j = (int)b * gridDim.x + blockIdx.x; j < bmax_tail; j += total) bmax[total + j] = -INFINITY;
     }
 }
 
@@ -777,9 +785,23 @@ void stft_bands_backward_reg_kernel(const float *__restrict__ x,
                                                                            const int32_t *__restrict__ fbt_start,
                                                                            const float *__restrict__ fbt_w, int span_t,
                                                                            float *__restrict__ dx, int T, int NF, int hop,
-                                                                           int M) {
+                                                                           int M, const float *__restrict__ band_db,
+                                                                           const float *__restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) unsigned char raw[];
     LdsRegBwd<SPAN_CAP> &S = *reinterpret_cast<LdsRegBwd<SPAN_CAP> *>(raw);
+    // advstep_lfcc_floor_fixup_f32 folded in (stats != null): the gradient the dB floor swallowed (stats[2], summed by the
+    // projection's backward) goes to the elements equal to the batch maximum, stats[2] / stats[1] each.  stats[2] == 0 - nothing
+    // was floored, the usual case - costs three scalar loads; otherwise the frame's dB row is read next to its gradient row.
+    float fix_share = 0.0f, fix_max = 0.0f;
+    bool fix = false;
+    if (stats != nullptr) {
+        const float s2 = stats[2];
+        if (s2 != 0.0f) {
+            fix = true;
+            fix_max = stats[0];
+            fix_share = s2 / (stats[1] > 0.0f ? stats[1] : 1.0f);
+        }
+    }
     fill_reg_tables(S.c);
     for (int i = threadIdx.x; i < kBins * SPAN_CAP; i += kThreads) {
         const int k = i / SPAN_CAP, j = i % SPAN_CAP;
@@ -813,6 +835,15 @@ void stft_bands_backward_reg_kernel(const float *__restrict__ x,
             for (int i = 0; i < kMaxBands / 16; ++i) {
                 const int m = l + 16 * i;
                 dreg[i] = m < M ? src[m] : 0.0f;
+            }
+            if (fix) {                                            // workgroup-uniform
+                const float *dbrow = band_db + (b * NF + fc) * M;
+#pragma unroll
+                for (int i = 0; i < kMaxBands / 16; ++i) {
+                    const int m = l + 16 * i;
+                    const float db = m < M ? dbrow[m] : 0.0f;
+                    if (m < M && db == fix_max) dreg[i] += fix_share * dlog_of_db(db);
+                }
             }
         }
         float2 xr[16];
@@ -1404,11 +1435,6 @@ __global__ __launch_bounds__(kThreads) void stft_mel_backward_out_reg_kernel(con
 
 constexpr int64_t kMaxGridY = 65535;
 
-__global__ void stft_fill_kernel(float *p, int64_t n, float v) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = v;
-}
-
 // ADVSTEP_STFT_REG=0 (read per call): the radix-4 in-LDS kernels of rounds 1 - 3 for the LFCC pair (A/B measurements)
 inline bool reg_fft_enabled() {
     const char *e = getenv("ADVSTEP_STFT_REG");
@@ -1421,6 +1447,44 @@ inline bool reg_fft_enabled() {
     do {                   \
         if (!(cond)) return ADVSTEP_EINVAL; \
     } while (0)
+
+namespace {
+// band_db / stats: null, or the dB rows and the statistics the floor fix-up needs (see the kernel); dx_is_zero: the caller
+// (advstep_lfcc_project_backward_zero_f32) has already zero-filled dx on this stream
+int stft_bands_backward_launch(const float *x, const float *window, const float *dband, const int32_t *fbt_start, const float *fbt_w,
+                               int64_t span_t, float *dx, int64_t B, int64_t T, int64_t NF, int64_t hop, int64_t nfft, int64_t M,
+                               const float *band_db, const float *stats, int dx_is_zero, advstep_stream_t stream) {
+    STFT_REQUIRE(B >= 0 && NF >= 0 && M >= 0 && span_t >= 1);
+    if (B == 0 || T == 0) return ADVSTEP_OK;
+    STFT_REQUIRE(x && window && dband && fbt_start && fbt_w && dx && B <= kMaxGridY);
+    STFT_REQUIRE(advstep_stft_bands_supported(nfft, hop, T) && NF == 1 + T / hop && span_t <= kMaxSpanT && M <= kMaxBands);
+    // a sample may be reached by at most two workgroups (two-operand float atomics commute): a workgroup's frames must
+    // advance by at least the overlap between neighbouring workgroups' ranges
+    STFT_REQUIRE(kFramesPerBlockBwd * hop >= kNfft - hop);
+    hipStream_t st = as_stream(stream);
+    if (!dx_is_zero && hipMemsetAsync(dx, 0, (size_t)B * T * sizeof(float), st) != hipSuccess) return ADVSTEP_ELAUNCH;
+    const bool reg = reg_fft_enabled();
+    const dim3 grid((unsigned)ceil_div(NF, reg ? kBwdFramesPerBlock : kFramesPerBlockBwd), (unsigned)B);
+    if (reg) {
+        auto go = [&](auto kernel, size_t lds) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kernel, grid, dim3(kThreads), lds, st, x, window, dband, fbt_start, fbt_w, (int)span_t, dx, (int)T,
+                               (int)NF, (int)hop, (int)M, band_db, stats);
+        };
+        if (span_t <= 2) go(stft_bands_backward_reg_kernel<2>, sizeof(LdsRegBwd<2>));
+        else go(stft_bands_backward_reg_kernel<kMaxSpanT>, sizeof(LdsRegBwd<kMaxSpanT>));
+    } else {
+        auto go = [&](auto kernel, size_t lds) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kernel, grid, dim3(kThreads), lds, st, x, window, dband, fbt_start, fbt_w, (int)span_t, dx, (int)T,
+                               (int)NF, (int)hop, (int)M);
+        };
+        if (span_t <= 2) go(stft_bands_backward_kernel<2>, sizeof(LdsBwd<2>));
+        else go(stft_bands_backward_kernel<kMaxSpanT>, sizeof(LdsBwd<kMaxSpanT>));
+    }
+    return status_after_launch();
+}
+}  // namespace
 
 extern "C" {
 
@@ -1445,12 +1509,10 @@ int advstep_stft_bands_f32(const float *x, const float *window, const int32_t *f
         // the unused tail of block_max (sized for the radix-4 kernel's 16-frame workgroups) must not hold garbage: the
         // reduction over it reads advstep_stft_bands_block_count entries
         const int64_t blocks32 = ceil_div(NF, kBandsFramesPerBlock), blocks16 = ceil_div(NF, kFramesPerBlockFwd);
-        stft_fill_kernel<<<dim3((unsigned)ceil_div(B * blocks16, 256)), dim3(256), 0, as_stream(stream)>>>(block_max, B * blocks16,
-                                                                                                          -INFINITY);
-        (void)blocks32;
-        const dim3 grid((unsigned)ceil_div(NF, kBandsFramesPerBlock), (unsigned)B);
+        STFT_REQUIRE(B * blocks16 <= INT32_MAX);
+        const dim3 grid((unsigned)blocks32, (unsigned)B);
         hipLaunchKernelGGL(stft_bands_reg_kernel, grid, dim3(kThreads), 0, as_stream(stream), x, window, fb_start, fb_w, (int)span,
-                           band_db, block_max, (int)T, (int)NF, (int)hop, (int)M);
+                           band_db, block_max, (int)T, (int)NF, (int)hop, (int)M, (int)(B * (blocks16 - blocks32)));
         return status_after_launch();
     }
     const dim3 grid((unsigned)ceil_div(NF, kFramesPerBlockFwd), (unsigned)B);
@@ -1462,30 +1524,25 @@ int advstep_stft_bands_f32(const float *x, const float *window, const int32_t *f
 int advstep_stft_bands_backward_f32(const float *x, const float *window, const float *dband, const int32_t *fbt_start,
                                     const float *fbt_w, int64_t span_t, float *dx, int64_t B, int64_t T, int64_t NF,
                                     int64_t hop, int64_t nfft, int64_t M, advstep_stream_t stream) {
-    STFT_REQUIRE(B >= 0 && NF >= 0 && M >= 0 && span_t >= 1);
-    if (B == 0 || T == 0) return ADVSTEP_OK;
-    STFT_REQUIRE(x && window && dband && fbt_start && fbt_w && dx && B <= kMaxGridY);
-    STFT_REQUIRE(advstep_stft_bands_supported(nfft, hop, T) && NF == 1 + T / hop && span_t <= kMaxSpanT && M <= kMaxBands);
-    // a sample may be reached by at most two workgroups (two-operand float atomics commute): a workgroup's frames must
-    // advance by at least the overlap between neighbouring workgroups' ranges
-    STFT_REQUIRE(kFramesPerBlockBwd * hop >= kNfft - hop);
-    hipStream_t st = as_stream(stream);
-    if (hipMemsetAsync(dx, 0, (size_t)B * T * sizeof(float), st) != hipSuccess) return ADVSTEP_ELAUNCH;
-    const bool reg = reg_fft_enabled();
-    const dim3 grid((unsigned)ceil_div(NF, reg ? kBwdFramesPerBlock : kFramesPerBlockBwd), (unsigned)B);
-    auto go = [&](auto kernel, size_t lds) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kernel, grid, dim3(kThreads), lds, st, x, window, dband, fbt_start, fbt_w, (int)span_t, dx, (int)T,
-                           (int)NF, (int)hop, (int)M);
-    };
-    if (reg) {
-        if (span_t <= 2) go(stft_bands_backward_reg_kernel<2>, sizeof(LdsRegBwd<2>));
-        else go(stft_bands_backward_reg_kernel<kMaxSpanT>, sizeof(LdsRegBwd<kMaxSpanT>));
-    } else {
-        if (span_t <= 2) go(stft_bands_backward_kernel<2>, sizeof(LdsBwd<2>));
-        else go(stft_bands_backward_kernel<kMaxSpanT>, sizeof(LdsBwd<kMaxSpanT>));
+    return stft_bands_backward_launch(x, window, dband, fbt_start, fbt_w, span_t, dx, B, T, NF, hop, nfft, M, nullptr, nullptr, 0,
+                                      stream);
+}
+
+int advstep_stft_bands_backward_fixup_f32(const float *x, const float *window, float *dband, const float *band_db,
+                                          const float *stats, const int32_t *fbt_start, const float *fbt_w, int64_t span_t,
+                                          float *dx, int dx_is_zero, int64_t B, int64_t T, int64_t NF, int64_t hop,
+                                          int64_t nfft, int64_t M, advstep_stream_t stream) {
+    STFT_REQUIRE(band_db && stats);
+    if (!reg_fft_enabled()) {                 // the radix-4 kernels have no folded fix-up: its own launch, on dband in place
+        if (B > 0 && NF > 0 && M > 0) {
+            const int st = advstep_lfcc_floor_fixup_f32(band_db, stats, dband, B * NF * M, stream);
+            if (st != ADVSTEP_OK) return st;
+        }
+        return stft_bands_backward_launch(x, window, dband, fbt_start, fbt_w, span_t, dx, B, T, NF, hop, nfft, M, nullptr, nullptr,
+                                          dx_is_zero, stream);
     }
-    return status_after_launch();
+    return stft_bands_backward_launch(x, window, dband, fbt_start, fbt_w, span_t, dx, B, T, NF, hop, nfft, M, band_db, stats,
+                                      dx_is_zero, stream);
 }
 
 int advstep_stft_mel_f32(const float *x, const float *window, const int32_t *fb_start, const float *fb_w, int64_t span,

@@ -9,7 +9,7 @@ maximum); tests/test_gpu_frontend_ops.py.  HIP tensors only."""
 from __future__ import annotations
 
 import os
-from typing import NamedTuple
+from typing import NamedTuple, Optional
 
 import torch
 
@@ -57,6 +57,45 @@ def filterbank_tables(filter_mat: torch.Tensor) -> FilterbankTables:
                             fbt_w.to(dev).contiguous(), span_t)
 
 
+_FRAGMENTS: dict = {}
+
+
+def dct_fragments(dct: torch.Tensor) -> Optional[torch.Tensor]:
+    """The DCT matrix in the operand order of the matrix-core projection kernels (advstep_lfcc_project_prepare_f32), cached
+    per (storage, version, device); None for sizes without such a path."""
+    lib = _lib.load()
+    M, K = dct.shape
+    n = lib.advstep_lfcc_project_fragment_floats(M, K)
+    if n == 0 or not dct.is_contiguous():
+        return None
+    key = (dct.data_ptr(), dct._version, str(dct.device), M, K)
+    frag = _FRAGMENTS.get(key)
+    if frag is None:
+        if len(_FRAGMENTS) >= 16:
+            _FRAGMENTS.clear()
+        frag = torch.empty(n, dtype=torch.float32, device=dct.device)
+        _lib.check(lib.advstep_lfcc_project_prepare_f32(dct.data_ptr(), M, K, frag.data_ptr(), _stream(dct.device)),
+                   "advstep_lfcc_project_prepare_f32")
+        _FRAGMENTS[key] = frag
+    return frag
+
+
+def _ptr(t: Optional[torch.Tensor]) -> int:
+    return 0 if t is None else t.data_ptr()
+
+
+def _rearm(ctx, stats: torch.Tensor, dct: torch.Tensor) -> None:
+    """A second backward pass through the same forward (retain_graph): the floored-gradient sum the first one accumulated in
+    `stats[2]` starts again from 0 - and so does the tie counter `stats[1]` where the backward pass is the one that fills it
+    (the matrix-core path: stats[3] == 1; the two-launch forward counts the ties itself)."""
+    if ctx.backward_calls:
+        if dct_fragments(dct) is not None:
+            stats[1:3].zero_()
+        else:
+            stats[2:3].zero_()
+    ctx.backward_calls += 1
+
+
 class _LfccTail(torch.autograd.Function):
     @staticmethod
     def forward(ctx, spec, tables: FilterbankTables, dct, top_db: float):
@@ -75,17 +114,17 @@ class _LfccTail(torch.autograd.Function):
         block_max = torch.empty(max(nblk, 1), dtype=torch.float32, device=dev)
         stats = torch.empty(4, dtype=torch.float32, device=dev)
         out = torch.empty((B, NF, K), dtype=torch.float32, device=dev)
+        frag = dct_fragments(dct)
         with _Launch("lfcc_forward", dev):
             st = lib.advstep_lfcc_bands_f32(sr.data_ptr(), tables.fb_start.data_ptr(), tables.fb_w.data_ptr(), tables.span,
                                             band_db.data_ptr(), block_max.data_ptr(), B, F, M, NF, _stream(dev))
             _lib.check(st, "advstep_lfcc_bands_f32")
-            st = lib.advstep_lfcc_reduce_max_f32(block_max.data_ptr(), nblk, stats.data_ptr(), _stream(dev))
-            _lib.check(st, "advstep_lfcc_reduce_max_f32")
-            st = lib.advstep_lfcc_project_f32(band_db.data_ptr(), dct.data_ptr(), stats.data_ptr(), top_db, out.data_ptr(),
-                                              B, M, NF, K, _stream(dev))
-            _lib.check(st, "advstep_lfcc_project_f32")
+            st = lib.advstep_lfcc_max_project_f32(band_db.data_ptr(), dct.data_ptr(), _ptr(frag), block_max.data_ptr(), nblk,
+                                                  stats.data_ptr(), top_db, out.data_ptr(), B, M, NF, K, _stream(dev))
+            _lib.check(st, "advstep_lfcc_max_project_f32")
         ctx.save_for_backward(sr, band_db, stats, dct, tables.fbt_start, tables.fbt_w)
         ctx.meta = (B, F, NF, M, K, tables.span_t, float(top_db))
+        ctx.backward_calls = 0
         return out.transpose(1, 2)
 
     @staticmethod
@@ -97,10 +136,12 @@ class _LfccTail(torch.autograd.Function):
         lib = _lib.load()
         dband = torch.empty((B, NF, M), dtype=torch.float32, device=dev)
         dspec = torch.empty((B, NF, F, 2), dtype=torch.float32, device=dev)
+        _rearm(ctx, stats, dct)
         with _Launch("lfcc_backward", dev):
-            st = lib.advstep_lfcc_project_backward_f32(go.data_ptr(), dct.data_ptr(), band_db.data_ptr(), stats.data_ptr(),
-                                                       top_db, dband.data_ptr(), B, M, NF, K, _stream(dev))
-            _lib.check(st, "advstep_lfcc_project_backward_f32")
+            st = lib.advstep_lfcc_project_backward_zero_f32(go.data_ptr(), dct.data_ptr(), _ptr(dct_fragments(dct)),
+                                                            band_db.data_ptr(), stats.data_ptr(), top_db, dband.data_ptr(), B, M, NF,
+                                                            K, 0, 0, _stream(dev))
+            _lib.check(st, "advstep_lfcc_project_backward_zero_f32")
             st = lib.advstep_lfcc_floor_fixup_f32(band_db.data_ptr(), stats.data_ptr(), dband.data_ptr(), band_db.numel(),
                                                   _stream(dev))
             _lib.check(st, "advstep_lfcc_floor_fixup_f32")
@@ -138,17 +179,17 @@ class _LfccFromWaveform(torch.autograd.Function):
         block_max = torch.empty(max(nblk, 1), dtype=torch.float32, device=dev)
         stats = torch.empty(4, dtype=torch.float32, device=dev)
         out = torch.empty((B, NF, K), dtype=torch.float32, device=dev)
+        frag = dct_fragments(dct)
         with _Launch("lfcc_forward", dev):
             st = lib.advstep_lfcc_bands_f32(sr.data_ptr(), tables.fb_start.data_ptr(), tables.fb_w.data_ptr(), tables.span,
                                             band_db.data_ptr(), block_max.data_ptr(), B, F, M, NF, _stream(dev))
             _lib.check(st, "advstep_lfcc_bands_f32")
-            st = lib.advstep_lfcc_reduce_max_f32(block_max.data_ptr(), nblk, stats.data_ptr(), _stream(dev))
-            _lib.check(st, "advstep_lfcc_reduce_max_f32")
-            st = lib.advstep_lfcc_project_f32(band_db.data_ptr(), dct.data_ptr(), stats.data_ptr(), top_db, out.data_ptr(),
-                                              B, M, NF, K, _stream(dev))
-            _lib.check(st, "advstep_lfcc_project_f32")
+            st = lib.advstep_lfcc_max_project_f32(band_db.data_ptr(), dct.data_ptr(), _ptr(frag), block_max.data_ptr(), nblk,
+                                                  stats.data_ptr(), top_db, out.data_ptr(), B, M, NF, K, _stream(dev))
+            _lib.check(st, "advstep_lfcc_max_project_f32")
         ctx.save_for_backward(sr, band_db, stats, dct, tables.fbt_start, tables.fbt_w, window)
         ctx.meta = (B, T, F, NF, M, K, tables.span_t, float(top_db), hop, nfft)
+        ctx.backward_calls = 0
         return out.transpose(1, 2)
 
     @staticmethod
@@ -160,10 +201,12 @@ class _LfccFromWaveform(torch.autograd.Function):
         lib = _lib.load()
         dband = torch.empty((B, NF, M), dtype=torch.float32, device=dev)
         dspec = torch.empty((B, NF, F, 2), dtype=torch.float32, device=dev)
+        _rearm(ctx, stats, dct)
         with _Launch("lfcc_backward", dev):
-            st = lib.advstep_lfcc_project_backward_f32(go.data_ptr(), dct.data_ptr(), band_db.data_ptr(), stats.data_ptr(),
-                                                       top_db, dband.data_ptr(), B, M, NF, K, _stream(dev))
-            _lib.check(st, "advstep_lfcc_project_backward_f32")
+            st = lib.advstep_lfcc_project_backward_zero_f32(go.data_ptr(), dct.data_ptr(), _ptr(dct_fragments(dct)),
+                                                            band_db.data_ptr(), stats.data_ptr(), top_db, dband.data_ptr(), B, M, NF,
+                                                            K, 0, 0, _stream(dev))
+            _lib.check(st, "advstep_lfcc_project_backward_zero_f32")
             st = lib.advstep_lfcc_floor_fixup_f32(band_db.data_ptr(), stats.data_ptr(), dband.data_ptr(), band_db.numel(),
                                                   _stream(dev))
             _lib.check(st, "advstep_lfcc_floor_fixup_f32")
@@ -190,8 +233,9 @@ def _inlds_fft_enabled() -> bool:
 
 
 class _LfccFromWaveformFused(torch.autograd.Function):
-    """The whole LFCC frontend with the STFT inside the kernels: [framing + FFT + power + filterbank + dB] -> max -> [floor
-    + DCT]; backward: [DCT^T + floor] -> [filterbank^T + spectrum recomputed + inverse FFT + window + overlap-add]."""
+    """The whole LFCC frontend with the STFT inside the kernels, two launches each way: [framing + FFT + power + filterbank + dB]
+    -> [batch max + floor + DCT]; backward: [DCT^T + floor + zero fill of dx] -> [floor fix-up + filterbank^T + spectrum
+    recomputed + inverse FFT + window + overlap-add]."""
 
     @staticmethod
     def forward(ctx, x, window, hop, tables: FilterbankTables, dct, top_db: float):
@@ -206,18 +250,19 @@ class _LfccFromWaveformFused(torch.autograd.Function):
         block_max = torch.empty(max(nblk, 1), dtype=torch.float32, device=dev)
         stats = torch.empty(4, dtype=torch.float32, device=dev)
         out = torch.empty((B, NF, K), dtype=torch.float32, device=dev)
+        frag = dct_fragments(dct)
         with _Launch("lfcc_forward", dev, tensors=(x, band_db, band_db, out)):     # waveform in, band rows out + back in, cepstra out
             st = lib.advstep_stft_bands_f32(x.data_ptr(), window.data_ptr(), tables.fb_start.data_ptr(), tables.fb_w.data_ptr(),
                                             tables.span, band_db.data_ptr(), block_max.data_ptr(), B, T, NF, hop, nfft, M,
                                             _stream(dev))
             _lib.check(st, "advstep_stft_bands_f32")
-            st = lib.advstep_lfcc_reduce_max_f32(block_max.data_ptr(), nblk, stats.data_ptr(), _stream(dev))
-            _lib.check(st, "advstep_lfcc_reduce_max_f32")
-            st = lib.advstep_lfcc_project_f32(band_db.data_ptr(), dct.data_ptr(), stats.data_ptr(), top_db, out.data_ptr(),
-                                              B, M, NF, K, _stream(dev))
-            _lib.check(st, "advstep_lfcc_project_f32")
+            # batch maximum + floor + DCT: one launch (every workgroup reduces the block maxima itself)
+            st = lib.advstep_lfcc_max_project_f32(band_db.data_ptr(), dct.data_ptr(), _ptr(frag), block_max.data_ptr(), nblk,
+                                                  stats.data_ptr(), top_db, out.data_ptr(), B, M, NF, K, _stream(dev))
+            _lib.check(st, "advstep_lfcc_max_project_f32")
         ctx.save_for_backward(x, band_db, stats, dct, tables.fbt_start, tables.fbt_w, window)
         ctx.meta = (B, T, NF, M, K, tables.span_t, float(top_db), hop, nfft)
+        ctx.backward_calls = 0
         return out.transpose(1, 2)
 
     @staticmethod
@@ -229,17 +274,18 @@ class _LfccFromWaveformFused(torch.autograd.Function):
         lib = _lib.load()
         dband = torch.empty((B, NF, M), dtype=torch.float32, device=dev)
         dx = torch.empty((B, T), dtype=torch.float32, device=dev)
+        _rearm(ctx, stats, dct)
         with _Launch("lfcc_backward", dev, tensors=(go, band_db, dband, dband, x, dx, dx)):
-            st = lib.advstep_lfcc_project_backward_f32(go.data_ptr(), dct.data_ptr(), band_db.data_ptr(), stats.data_ptr(),
-                                                       top_db, dband.data_ptr(), B, M, NF, K, _stream(dev))
-            _lib.check(st, "advstep_lfcc_project_backward_f32")
-            st = lib.advstep_lfcc_floor_fixup_f32(band_db.data_ptr(), stats.data_ptr(), dband.data_ptr(), band_db.numel(),
-                                                  _stream(dev))
-            _lib.check(st, "advstep_lfcc_floor_fixup_f32")
-            st = lib.advstep_stft_bands_backward_f32(x.data_ptr(), window.data_ptr(), dband.data_ptr(), fbt_start.data_ptr(),
-                                                     fbt_w.data_ptr(), span_t, dx.data_ptr(), B, T, NF, hop, nfft, M,
-                                                     _stream(dev))
-            _lib.check(st, "advstep_stft_bands_backward_f32")
+            # two launches: [DCT^T + floor mask + dB' + tie count; zero-fills dx] -> [floor fix-up folded into the band-gradient
+            # load + filterbank^T + FFT pair + overlap-add]
+            st = lib.advstep_lfcc_project_backward_zero_f32(go.data_ptr(), dct.data_ptr(), _ptr(dct_fragments(dct)),
+                                                            band_db.data_ptr(), stats.data_ptr(), top_db, dband.data_ptr(), B, M, NF,
+                                                            K, dx.data_ptr(), dx.numel(), _stream(dev))
+            _lib.check(st, "advstep_lfcc_project_backward_zero_f32")
+            st = lib.advstep_stft_bands_backward_fixup_f32(x.data_ptr(), window.data_ptr(), dband.data_ptr(), band_db.data_ptr(),
+                                                           stats.data_ptr(), fbt_start.data_ptr(), fbt_w.data_ptr(), span_t,
+                                                           dx.data_ptr(), 1, B, T, NF, hop, nfft, M, _stream(dev))
+            _lib.check(st, "advstep_stft_bands_backward_fixup_f32")
         return dx, None, None, None, None, None
 
 

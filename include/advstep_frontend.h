@@ -53,6 +53,30 @@ int advstep_lfcc_project_backward_f32(const float *dout, const float *dct, const
                                       float top_db, float *dband, int64_t B, int64_t M, int64_t NF, int64_t K,
                                       advstep_stream_t stream);
 
+/* ---- the projection pair on the matrix cores (M = 128 bands, K = 80 coefficients: the reference's LFCC; other sizes take
+ * the launches above) ------------------------------------------------------------------------------------------------------
+ * advstep_lfcc_project_prepare_f32: the DCT matrix re-ordered into the operand fragments of the two kernels, once per weight
+ * version (`frag`: advstep_lfcc_project_fragment_floats(M, K) floats, 16-byte aligned, caller-owned; 0 floats = this size has
+ * no matrix-core path and `frag` may be NULL everywhere below). */
+size_t advstep_lfcc_project_fragment_floats(int64_t M, int64_t K);
+int advstep_lfcc_project_prepare_f32(const float *dct, int64_t M, int64_t K, float *frag, advstep_stream_t stream);
+
+/* advstep_lfcc_reduce_max_f32 + advstep_lfcc_project_f32 as ONE launch (src/frontends.py:24-32: the `amplitude_to_DB` floor
+ * and the DCT of torchaudio's LFCC): every workgroup of the projection reduces the n block maxima itself and stats becomes
+ * {max, 0, 0, 1} - stats[3] == 1 asks advstep_lfcc_project_backward_zero_f32 to count the elements equal to the maximum into
+ * stats[1] (so ONE backward pass per forward pass may run on a given stats buffer; re-arm it by zeroing stats[1..2]).
+ * frag == NULL or another size: the two launches.  band_db, out: 16-byte aligned. */
+int advstep_lfcc_max_project_f32(const float *band_db, const float *dct, const float *frag, const float *block_max, int64_t n,
+                                 float *stats, float top_db, float *out, int64_t B, int64_t M, int64_t NF, int64_t K,
+                                 advstep_stream_t stream);
+
+/* advstep_lfcc_project_backward_f32 on the matrix cores, which also zero-fills `zero` (zero_n floats; may be NULL / 0) in the
+ * same launch: the waveform gradient the overlap-add of advstep_stft_bands_backward_fixup_f32(dx_is_zero = 1) accumulates
+ * into (replaces the memset node in front of that kernel).  frag == NULL or another size: memset + the plain call. */
+int advstep_lfcc_project_backward_zero_f32(const float *dout, const float *dct, const float *frag, const float *band_db,
+                                           float *stats, float top_db, float *dband, int64_t B, int64_t M, int64_t NF,
+                                           int64_t K, float *zero, int64_t zero_n, advstep_stream_t stream);
+
 /* torchaudio's floor is `amax(x_db) - top_db`, so the floored gradients flow to the batch maximum: adds
  * stats[2] / stats[1] * d(dB) at every element of band_db equal to stats[0].  No-op when stats[2] == 0. */
 int advstep_lfcc_floor_fixup_f32(const float *band_db, const float *stats, float *dband, int64_t n,
@@ -91,6 +115,15 @@ int advstep_stft_bands_f32(const float *x, const float *window, const int32_t *f
 int advstep_stft_bands_backward_f32(const float *x, const float *window, const float *dband, const int32_t *fbt_start,
                                     const float *fbt_w, int64_t span_t, float *dx, int64_t B, int64_t T, int64_t NF,
                                     int64_t hop, int64_t nfft, int64_t M, advstep_stream_t stream);
+
+/* advstep_lfcc_floor_fixup_f32 + advstep_stft_bands_backward_f32 as ONE launch: the fix-up (stats[2] / stats[1] * d(dB) added
+ * at every element of band_db equal to stats[0]; nothing when stats[2] == 0) is applied to the band gradients as the kernel
+ * reads them - dband itself is not modified unless ADVSTEP_STFT_REG=0 selects the radix-4 kernels, which fix it up in place
+ * first.  dx_is_zero != 0: dx has been zero-filled on this stream already (advstep_lfcc_project_backward_zero_f32). */
+int advstep_stft_bands_backward_fixup_f32(const float *x, const float *window, float *dband, const float *band_db,
+                                          const float *stats, const int32_t *fbt_start, const float *fbt_w, int64_t span_t,
+                                          float *dx, int dx_is_zero, int64_t B, int64_t T, int64_t NF, int64_t hop,
+                                          int64_t nfft, int64_t M, advstep_stream_t stream);
 
 /* ---- mel-spec frontend (src/frontends.py:53-79) around the same in-LDS FFT --------------------------------------------
  * torch.stft (window 512 = the rectangular 400-sample window centred / zero-padded) -> MelScale applied to the real and

@@ -64,6 +64,60 @@ def test_fused_lfcc_floor_and_amax_gradient_path(lfcc, cuda, monkeypatch):
     assert y[1, 1:].abs().max().item() <= 1e-2 and y[1, 0].std().item() <= 1e-3
 
 
+def test_two_launch_lfcc_equals_the_separate_entry_points(lfcc, cuda, monkeypatch):
+    """Round 4: forward = stft_bands -> max_project (the block-maximum reduction inside the projection), backward =
+    project_backward_zero (tie count + zero fill of dx) -> stft_bands_backward_fixup (floor fix-up inside the band-gradient
+    load).  Against the separate C-ABI calls they replace (reduce_max, project, project_backward, floor_fixup, memset +
+    stft_bands_backward) on a batch whose floor is active: same cepstra and waveform gradient up to the summation order of the
+    DCT (the plain calls are the vector-ALU kernels); a second backward pass through the same forward (retain_graph) gives the
+    same gradient again."""
+    from audio_deepfake_adversarial_attacks_amd import _lib, frontend_ops
+    monkeypatch.setenv("ADVSTEP_FUSED_LFCC", "1")
+    gen = torch.Generator().manual_seed(11)
+    x = torch.rand(4, 32_000, generator=gen)
+    x[1] = x[1] * 1e-7
+    x[3, 9_000:20_000] = 0.0
+    x = x.to(cuda)
+    a = x.clone().requires_grad_(True)
+    y = lfcc(a)
+    gy = torch.randn(y.shape, generator=gen).to(cuda)
+    (g1,) = torch.autograd.grad(y, a, gy, retain_graph=True)
+    (g2,) = torch.autograd.grad(y, a, gy)
+    # (equal up to the rounding of ONE scalar: the floored gradients' sum is accumulated with float atomics over workgroups)
+    assert (g1 - g2).norm().item() <= 1e-6 * g1.norm().item()
+
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    B, T = x.shape
+    hop, nfft, NF = 160, 512, 1 + T // 160
+    tables, dct, window = lfcc._tables(), lfcc.dct_mat, lfcc._window_nfft()
+    M, K = dct.shape
+    band = torch.empty(B, NF, M, device=cuda)
+    nblk = lib.advstep_stft_bands_block_count(B, NF)
+    bmax = torch.full((nblk,), float("nan"), device=cuda)          # garbage the band kernel must overwrite or fill
+    stats = torch.full((4,), 7.0, device=cuda)
+    out = torch.empty(B, NF, K, device=cuda)
+    _lib.check(lib.advstep_stft_bands_f32(x.data_ptr(), window.data_ptr(), tables.fb_start.data_ptr(), tables.fb_w.data_ptr(),
+                                          tables.span, band.data_ptr(), bmax.data_ptr(), B, T, NF, hop, nfft, M, st), "bands")
+    _lib.check(lib.advstep_lfcc_reduce_max_f32(bmax.data_ptr(), nblk, stats.data_ptr(), st), "max")
+    _lib.check(lib.advstep_lfcc_project_f32(band.data_ptr(), dct.data_ptr(), stats.data_ptr(), 80.0, out.data_ptr(), B, M, NF, K,
+                                            st), "project")
+    # (the plain entry points are the vector-ALU kernels since round 4: another summation order than the matrix-core pair)
+    assert (out.transpose(1, 2) - y.detach()).abs().max().item() <= 2e-4
+    go = gy.transpose(1, 2).contiguous()
+    dband = torch.empty(B, NF, M, device=cuda)
+    dx = torch.full((B, T), float("nan"), device=cuda)
+    _lib.check(lib.advstep_lfcc_project_backward_f32(go.data_ptr(), dct.data_ptr(), band.data_ptr(), stats.data_ptr(), 80.0,
+                                                     dband.data_ptr(), B, M, NF, K, st), "project_backward")
+    assert stats[2].item() != 0.0 and stats[1].item() >= 1.0       # the floor is active in this batch
+    _lib.check(lib.advstep_lfcc_floor_fixup_f32(band.data_ptr(), stats.data_ptr(), dband.data_ptr(), band.numel(), st), "fixup")
+    _lib.check(lib.advstep_stft_bands_backward_f32(x.data_ptr(), window.data_ptr(), dband.data_ptr(), tables.fbt_start.data_ptr(),
+                                                   tables.fbt_w.data_ptr(), tables.span_t, dx.data_ptr(), B, T, NF, hop, nfft, M,
+                                                   st), "bands_backward")
+    rel = (dx - g1).norm().item() / g1.norm().item()
+    assert rel <= 2e-6, rel
+
+
 def test_lcnn_forward_uses_fused_frontend_without_copy(cuda, monkeypatch):
     from audio_deepfake_adversarial_attacks_amd.models.models import get_model
     torch.manual_seed(0)
