@@ -55,9 +55,11 @@ SIGNATURES = {
     "advstep_lstm_forward_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p]),
     "advstep_lstm_backward_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p]),
     "advstep_lstm_backward_bcast_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p]),
+    "advstep_lstm_backward_outer_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p]),
     "advstep_lcnn_tail_pack_f32": (ctypes.c_int, [_p, _p, _i64, _i64, _i64, _i64, _p]),
     "advstep_lcnn_tail_forward_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _p]),
     "advstep_lcnn_tail_unpack_add_f32": (ctypes.c_int, [_p, _p, _p, _i64, _i64, _i64, _i64, _p]),
+    "advstep_lcnn_tail_unpack_add_outer_f32": (ctypes.c_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _p]),
     "advstep_gru_supported": (ctypes.c_int, [_i64]),
     "advstep_gru_forward_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p]),
     "advstep_gru_backward_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p]),

@@ -100,7 +100,8 @@ __global__ __launch_bounds__(4 * H) void lstm_backward_kernel(const float *__res
                                                               const float *__restrict__ w_hh,
                                                               const float *__restrict__ gates,
                                                               const float *__restrict__ cell, float *__restrict__ dgx,
-                                                              int T, int B, int D, int64_t dout_t_stride) {
+                                                              int T, int B, int D, int64_t dout_t_stride, int64_t dout_b_stride,
+                                                              const float *__restrict__ dout_scale) {
     __shared__ __attribute__((aligned(16))) float dg_s[4 * H];
     __shared__ float part[4 * H];
     const int b = blockIdx.x, d = blockIdx.y, tid = threadIdx.x;
@@ -135,7 +136,10 @@ __global__ __launch_bounds__(4 * H) void lstm_backward_kernel(const float *__res
                 const int tp = d == 0 ? step - 1 : T - step;
                 v.c_prev = cell[(((int64_t)tp * B + b) * D + d) * H + j];
             }
-            v.dout = dout[(int64_t)t * dout_t_stride + (int64_t)b * D * H + d * H + j];   // stride 0: the same (B, D H) for every t
+            // strides 0: the same row for every frame / utterance; dout_scale: one factor per utterance (the outer product
+            // dz[b] * row[f] of the mean's gradient, formed here instead of by an elementwise launch in front of this kernel)
+            v.dout = dout[(int64_t)t * dout_t_stride + (int64_t)b * dout_b_stride + d * H + j];
+            if (dout_scale) v.dout = dout_scale[b] * v.dout;
         }
         return v;
     };
@@ -227,10 +231,21 @@ __global__ __launch_bounds__(256) void lcnn_tail_forward_kernel(const float *__r
     const int b = blockIdx.x, k = threadIdx.x;
     float acc = 0.0f;
     if (k < F) {
+        // the same sum in the same order, the loads of 8 frames in flight at a time (a plain loop is one L2 round trip per frame:
+        // 25 in a row were most of this kernel's 9 us)
         float s = 0.0f;
-        for (int t = 0; t < T; ++t) {
-            const int64_t i = ((int64_t)t * B + b) * F + k;
-            s += a[i] + xt[i];
+        for (int t0 = 0; t0 < T; t0 += 8) {
+            float av[8], xv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int t = t0 + u < T ? t0 + u : T - 1;
+                const int64_t i = ((int64_t)t * B + b) * F + k;
+                av[u] = a[i];
+                xv[u] = xt[i];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (t0 + u < T) s += av[u] + xv[u];
         }
         acc = (s / (float)T) * w[k];
     }
@@ -241,14 +256,16 @@ __global__ __launch_bounds__(256) void lcnn_tail_forward_kernel(const float *__r
     if (threadIdx.x == 0) z[b] = ((red[0] + red[1]) + (red[2] + red[3])) + (bias ? bias[0] : 0.0f);
 }
 
-// dx4 (B, C, T, W) = dxt (T, B, C W) + g0 (B, C W)
+// dx4 (B, C, T, W) = dxt (T, B, C W) + g0 (B, C W);  dz != null: g0[b][k] = dz[b] * g0[k] (g0 is then ONE row)
 __global__ __launch_bounds__(256) void lcnn_tail_unpack_add_kernel(const float *__restrict__ dxt, const float *__restrict__ g0,
-                                                                   float *__restrict__ dx4, int B, int C, int T, int W) {
+                                                                   const float *__restrict__ dz, float *__restrict__ dx4, int B,
+                                                                   int C, int T, int W) {
     const int64_t total = (int64_t)B * C * T * W;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int w = (int)(i % W), t = (int)((i / W) % T), c = (int)((i / ((int64_t)W * T)) % C), b = (int)(i / ((int64_t)W * T * C));
         const int k = c * W + w;
-        dx4[i] = dxt[((int64_t)t * B + b) * C * W + k] + g0[(int64_t)b * C * W + k];
+        const float g = dz ? dz[b] * g0[k] : g0[(int64_t)b * C * W + k];
+        dx4[i] = dxt[((int64_t)t * B + b) * C * W + k] + g;
     }
 }
 
@@ -279,7 +296,8 @@ int advstep_lstm_backward_f32(const float *dout, const float *w_hh, const float 
     if (T == 0 || B == 0) return ADVSTEP_OK;
     LSTM_REQUIRE(dout && w_hh && gates && cell && dgx && T <= INT32_MAX && B <= INT32_MAX);
     hipLaunchKernelGGL(lstm_backward_kernel<80>, dim3((unsigned)B, (unsigned)D), dim3(320), 0, as_stream(stream), dout,
-                       w_hh, gates, cell, dgx, (int)T, (int)B, (int)D, (int64_t)B * D * H);
+                       w_hh, gates, cell, dgx, (int)T, (int)B, (int)D, (int64_t)B * D * H, (int64_t)D * H,
+                       static_cast<const float *>(nullptr));
     return status_after_launch();
 }
 
@@ -289,7 +307,17 @@ int advstep_lstm_backward_bcast_f32(const float *dout_row, const float *w_hh, co
     if (T == 0 || B == 0) return ADVSTEP_OK;
     LSTM_REQUIRE(dout_row && w_hh && gates && cell && dgx && T <= INT32_MAX && B <= INT32_MAX);
     hipLaunchKernelGGL(lstm_backward_kernel<80>, dim3((unsigned)B, (unsigned)D), dim3(320), 0, as_stream(stream), dout_row,
-                       w_hh, gates, cell, dgx, (int)T, (int)B, (int)D, (int64_t)0);
+                       w_hh, gates, cell, dgx, (int)T, (int)B, (int)D, (int64_t)0, (int64_t)D * H, static_cast<const float *>(nullptr));
+    return status_after_launch();
+}
+
+int advstep_lstm_backward_outer_f32(const float *dz, const float *row, const float *w_hh, const float *gates, const float *cell,
+                                    float *dgx, int64_t T, int64_t B, int64_t D, int64_t H, advstep_stream_t stream) {
+    LSTM_REQUIRE(T >= 0 && B >= 0 && (D == 1 || D == 2) && advstep_lstm_supported(H));
+    if (T == 0 || B == 0) return ADVSTEP_OK;
+    LSTM_REQUIRE(dz && row && w_hh && gates && cell && dgx && T <= INT32_MAX && B <= INT32_MAX);
+    hipLaunchKernelGGL(lstm_backward_kernel<80>, dim3((unsigned)B, (unsigned)D), dim3(320), 0, as_stream(stream), row, w_hh, gates,
+                       cell, dgx, (int)T, (int)B, (int)D, (int64_t)0, (int64_t)0, dz);
     return status_after_launch();
 }
 
@@ -322,7 +350,19 @@ int advstep_lcnn_tail_unpack_add_f32(const float *dxt, const float *g0, float *d
     LSTM_REQUIRE(dxt && g0 && dx4 && B <= INT32_MAX && C <= INT32_MAX && T <= INT32_MAX && W <= INT32_MAX);
     const int64_t blocks = (total + 255) / 256;
     hipLaunchKernelGGL(lcnn_tail_unpack_add_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0,
-                       as_stream(stream), dxt, g0, dx4, (int)B, (int)C, (int)T, (int)W);
+                       as_stream(stream), dxt, g0, static_cast<const float *>(nullptr), dx4, (int)B, (int)C, (int)T, (int)W);
+    return status_after_launch();
+}
+
+int advstep_lcnn_tail_unpack_add_outer_f32(const float *dxt, const float *dz, const float *row, float *dx4, int64_t B, int64_t C,
+                                           int64_t T, int64_t W, advstep_stream_t stream) {
+    LSTM_REQUIRE(B >= 0 && C >= 0 && T >= 0 && W >= 0);
+    const int64_t total = B * C * T * W;
+    if (total == 0) return ADVSTEP_OK;
+    LSTM_REQUIRE(dxt && dz && row && dx4 && B <= INT32_MAX && C <= INT32_MAX && T <= INT32_MAX && W <= INT32_MAX);
+    const int64_t blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(lcnn_tail_unpack_add_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0,
+                       as_stream(stream), dxt, row, dz, dx4, (int)B, (int)C, (int)T, (int)W);
     return status_after_launch();
 }
 

@@ -480,13 +480,14 @@ class _LcnnTail(torch.autograd.Function):
         F = C * W
         lib, dev = _lib.load(), dz.device
         st = _stream(dev)
-        # the mean's gradient: the same row for every frame — of the second layer's output and of the skip connection
-        g0 = dz.reshape(B, 1) * w_over_t
+        # the mean's gradient dz[b] * (w / T)[f]: the same row for every frame — of the second layer's output and of the skip
+        # connection — formed inside the two kernels that read it (one elementwise launch less)
+        dzc = dz.reshape(B).contiguous()
         dgx2 = torch.empty((T, B, D, 4 * H), dtype=dz.dtype, device=dev)
         with _Launch("lstm_backward", dev, tensors=(gates2, cell2, dgx2)):
-            s_ = lib.advstep_lstm_backward_bcast_f32(g0.data_ptr(), w_hh2.data_ptr(), gates2.data_ptr(), cell2.data_ptr(),
-                                                     dgx2.data_ptr(), T, B, D, H, st)
-        _lib.check(s_, "advstep_lstm_backward_bcast_f32")
+            s_ = lib.advstep_lstm_backward_outer_f32(dzc.data_ptr(), w_over_t.data_ptr(), w_hh2.data_ptr(), gates2.data_ptr(),
+                                                     cell2.data_ptr(), dgx2.data_ptr(), T, B, D, H, st)
+        _lib.check(s_, "advstep_lstm_backward_outer_f32")
         dout1 = _gemm(torch.mm, dgx2.view(T * B, D * 4 * H), w_ih2)                     # (T B, F) = d(first layer's output)
         dgx1 = torch.empty((T, B, D, 4 * H), dtype=dz.dtype, device=dev)
         with _Launch("lstm_backward", dev, tensors=(dout1, gates1, cell1, dgx1)):
@@ -496,8 +497,9 @@ class _LcnnTail(torch.autograd.Function):
         dxt = _gemm(torch.mm, dgx1.view(T * B, D * 4 * H), w_ih1)
         dx4 = torch.empty((B, C, T, W), dtype=dz.dtype, device=dev)
         with _Launch("lcnn_tail_unpack_add", dev, tensors=(dxt, dx4)):
-            s_ = lib.advstep_lcnn_tail_unpack_add_f32(dxt.data_ptr(), g0.data_ptr(), dx4.data_ptr(), B, C, T, W, st)
-        _lib.check(s_, "advstep_lcnn_tail_unpack_add_f32")
+            s_ = lib.advstep_lcnn_tail_unpack_add_outer_f32(dxt.data_ptr(), dzc.data_ptr(), w_over_t.data_ptr(), dx4.data_ptr(), B, C,
+                                                            T, W, st)
+        _lib.check(s_, "advstep_lcnn_tail_unpack_add_outer_f32")
         return (dx4,) + (None,) * 8
 
 

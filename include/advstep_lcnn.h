@@ -155,6 +155,10 @@ int advstep_lstm_backward_f32(const float *dout, const float *w_hh, const float 
  * frames hands back (src/models/lcnn.py:205) — read with a zero frame stride, so the (T, B, D*H) expansion never exists. */
 int advstep_lstm_backward_bcast_f32(const float *dout_row, const float *w_hh, const float *gates, const float *cell,
                                     float *dgx, int64_t T, int64_t B, int64_t D, int64_t H, advstep_stream_t stream);
+/* The same with dout[t][b][f] = dz[b] * row[f] formed inside the kernel: the mean's gradient dz (B) times the Linear's row / T
+ * (D*H) - what `dz.reshape(B, 1) * w_over_t` -> advstep_lstm_backward_bcast_f32 computes with one elementwise launch more. */
+int advstep_lstm_backward_outer_f32(const float *dz, const float *row, const float *w_hh, const float *gates, const float *cell,
+                                    float *dgx, int64_t T, int64_t B, int64_t D, int64_t H, advstep_stream_t stream);
 
 /* ---- around the two BLSTM layers  (src/models/lcnn.py:196-205) ---------------------------------------------------------------
  *   hidden = conv_out.permute(0, 2, 1, 3).contiguous().view(B, T, C*W);  lstm = blstm2(blstm1(hidden));
@@ -169,6 +173,9 @@ int advstep_lcnn_tail_forward_f32(const float *a, const float *xt, const float *
                                   int64_t B, int64_t F, advstep_stream_t stream);
 int advstep_lcnn_tail_unpack_add_f32(const float *dxt, const float *g0, float *dx4, int64_t B, int64_t C, int64_t T, int64_t W,
                                      advstep_stream_t stream);
+/* unpack_add with g0[b][k] = dz[b] * row[k] formed inside the kernel (see advstep_lstm_backward_outer_f32) */
+int advstep_lcnn_tail_unpack_add_outer_f32(const float *dxt, const float *dz, const float *row, float *dx4, int64_t B, int64_t C,
+                                           int64_t T, int64_t W, advstep_stream_t stream);
 
 /* ---- recurrent part of a (bi)directional GRU layer  (src/models/specrnet.py:121-127,176-177: nn.GRU(64, 64, 2 layers,
  * bidirectional); MIOpen runs it as ~400 kernels of ~4 us per forward + backward) --------------------------------------
