@@ -632,6 +632,15 @@ int advstep_lfcc_max_project_f32(const float *band_db, const float *dct, const f
     }
     LFCC_REQUIRE(band_db && out && B * NF <= INT32_MAX && (reinterpret_cast<uintptr_t>(frag) & 15u) == 0 &&
                  (reinterpret_cast<uintptr_t>(band_db) & 15u) == 0 && (reinterpret_cast<uintptr_t>(out) & 15u) == 0);
+    // every workgroup reduces the block maxima itself: fine for the fused STFT kernel's 26 per utterance (13 KB at B = 128), not for
+    // advstep_lfcc_bands_f32's 202 per utterance (100 KB x 808 workgroups) - those are reduced by one launch first and the
+    // projection is handed stats[0] as a one-entry array (it re-publishes the same value)
+    if (n > 8192) {
+        const int st = advstep_lfcc_reduce_max_f32(block_max, n, stats, stream);
+        if (st != ADVSTEP_OK) return st;
+        block_max = stats;
+        n = 1;
+    }
     hipLaunchKernelGGL(lfcc_project_mfma_kernel, dim3((unsigned)ceil_div(B * NF, kPTile)), dim3(kPThreads), 0, as_stream(stream),
                        band_db, frag, block_max, (int)n, stats, top_db, out, B * NF);
     return status_after_launch();

@@ -156,8 +156,9 @@ def main():
     timeit("lfcc_reduce_max", lambda: lib.advstep_lfcc_reduce_max_f32(bmax.data_ptr(), nblk, stats.data_ptr(), st))
     from audio_deepfake_adversarial_attacks_amd.frontend_ops import dct_fragments
     frag = dct_fragments(lf.dct_mat)
+    nblk_stft = lib.advstep_stft_bands_block_count(B, NF)     # what the fused STFT kernel leaves: 26 maxima per utterance
     timeit("lfcc_project", lambda: lib.advstep_lfcc_max_project_f32(band.data_ptr(), lf.dct_mat.data_ptr(), frag.data_ptr(),
-                                                                   bmax.data_ptr(), nblk, stats.data_ptr(), 80.0,
+                                                                   bmax.data_ptr(), nblk_stft, stats.data_ptr(), 80.0,
                                                                    outl.data_ptr(), B, M, NF, K, st),
            bytes_moved=4.0 * (band.numel() + outl.numel()), flops=2.0 * B * NF * M * K)
     dband = torch.empty_like(band)
