@@ -206,7 +206,9 @@ __global__ __launch_bounds__(kBlock) void conv5_mfm_pool2_backward_kernel(const 
     const char *lut_b = reinterpret_cast<const char *>(lut);
     // (Round 3, measured and not kept: requesting channel c + 1's nine (selection byte, gradient) pairs before channel c's are
     // consumed — two register sets, scheduling barriers — 150 -> 159 us; the offset table as five VALU instructions instead of
-    // an LDS read: 161 us.  The loop is bound by its 27 LDS reads per channel, not by the latency of its 18 vector-memory loads.)
+    // an LDS read: 161 us.  The loop is bound by its 27 LDS reads per channel, not by the latency of its 18 vector-memory loads.
+    // Round 4: the (cell, code) windows expanded once per workgroup into float4 entries - 9 ds_read_b128 per channel instead of
+    // 27 reads, bit-identical - 156 -> 184 us: 36 KB of LDS per workgroup leaves 16 waves per CU.)
     for (int c = 0; c < C; ++c) {
         const uint32_t gsoff = (uint32_t)c * plane * 4u, isoff = (uint32_t)c * plane;   // wave-uniform
         const char *wc = reinterpret_cast<const char *>(wl + c * kTabWords);
