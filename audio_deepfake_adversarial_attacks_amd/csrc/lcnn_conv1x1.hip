@@ -40,8 +40,12 @@ __device__ __forceinline__ int mfma_row(int r, int lane) { return (r & 3) + 8 * 
 
 // grid (ceil(P / 128), N).  TILES = ceil(C / 32) channel tiles per half.
 // LDS: w_s[2 * TILES * 32][CIN + 1]; rows [0, 32 TILES) = first half (zero beyond C), rows [32 TILES, 64 TILES) = second.
-// FULL: C == 32 TILES (no accumulator row beyond C): the row-liveness branches of the epilogue compile away.
-template <int CIN, int TILES, bool FULL>
+// MODE 1: C == 32 TILES (no accumulator row beyond C): the row-liveness branches of the epilogue compile away.
+// MODE 2 (round 4): C == 32 TILES - 16 (LCNN's 48-channel block): the 16 leftover rows of BOTH halves share the last 32-row
+// tile - rows 0..15 = channels 32 (TILES - 1) + i of the first half, rows 16..31 the same channels of the second half - so a
+// max-feature-map pair is (acc[r], acc[r + 8]) of one lane, and the block issues 3 matrix instructions per k-step, not 4
+// (the 64-row padding of 48 channels was a third of the kernel's matrix time).  Same k order per output: bit-identical.
+template <int CIN, int TILES, int MODE>
 __global__ __launch_bounds__(kBlock) void conv1x1_mfm_forward_kernel(const float *__restrict__ x,
                                                                      const float *__restrict__ weight,
                                                                      const float *__restrict__ bias,
@@ -110,8 +114,10 @@ __global__ __launch_bounds__(kBlock) void conv1x1_mfm_forward_kernel(const float
     for (int s = 0; s < CIN / 2; ++s)
         xb[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, x_off, (uint32_t)(2 * s) * Pb, 0));
 
+    constexpr bool FULL = MODE != 0;                       // rows of the two-accumulator tiles are all live
+    constexpr int kPairTiles = MODE == 2 ? TILES - 1 : TILES;
 #pragma unroll
-    for (int t = 0; t < TILES; ++t) {
+    for (int t = 0; t < kPairTiles; ++t) {
         f32x16 acc_a = {0}, acc_b = {0};
         const float *wa = w_s + (t * 32 + li) * PITCH + lk;
         const float *wb = wa + CP * PITCH;
@@ -141,6 +147,25 @@ __global__ __launch_bounds__(kBlock) void conv1x1_mfm_forward_kernel(const float
                                                       (uint32_t)c_lo * Pb, 0);
                 __builtin_amdgcn_raw_buffer_store_b32(sw, sr, lk ? kOut : s_off, (uint32_t)c_lo * PWb, 0);
             }
+        }
+    }
+    if constexpr (MODE == 2) {
+        constexpr int t = TILES - 1;
+        f32x16 acc = {0};
+        const float *wm = w_s + (li < 16 ? t * 32 + li : CP + t * 32 + (li - 16)) * PITCH + lk;
+#pragma unroll
+        for (int s = 0; s < CIN / 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wm[2 * s], xb[s], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int c_lo = t * 32 + (r & 3) + 8 * (r >> 2);        // lanes 0-31: channel c_lo, lanes 32-63: c_lo + 4
+            const int c = c_lo + 4 * lk;
+            const float va = acc[r] + par_s[c], vb = acc[r + 8] + par_s[CP + c];
+            const bool tb = mfm_takes_b(va, vb);
+            const unsigned long long word = __ballot(valid && tb);
+            const float v = ((tb ? vb : va) - par_s[2 * CP + c]) * par_s[3 * CP + c];
+            const uint32_t sw = lk ? (uint32_t)(word >> 32) : (uint32_t)word;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), yr, y_off, (uint32_t)c_lo * Pb, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(sw, sr, s_off, (uint32_t)c_lo * PWb, 0);
         }
     }
 }
@@ -280,12 +305,16 @@ void launch_fwd(const float *x, const float *w, const float *b, const float *bn_
     const size_t lds = (size_t)(2 * TILES * 32 * (CIN + 1) + 4 * TILES * 32) * sizeof(float);
     const dim3 grid((unsigned)ceil_div(P, kPixPerBlock), (unsigned)N);
     if (C == TILES * 32) {
-        opt_in_lds(conv1x1_mfm_forward_kernel<CIN, TILES, true>, lds);
-        hipLaunchKernelGGL((conv1x1_mfm_forward_kernel<CIN, TILES, true>), grid, dim3(kBlock), lds, st, x, w, b, bn_mean,
+        opt_in_lds(conv1x1_mfm_forward_kernel<CIN, TILES, 1>, lds);
+        hipLaunchKernelGGL((conv1x1_mfm_forward_kernel<CIN, TILES, 1>), grid, dim3(kBlock), lds, st, x, w, b, bn_mean,
+                           bn_invstd, y, sel, (int)C, P, ceil_div(P, 32));
+    } else if (C == TILES * 32 - 16) {
+        opt_in_lds(conv1x1_mfm_forward_kernel<CIN, TILES, 2>, lds);
+        hipLaunchKernelGGL((conv1x1_mfm_forward_kernel<CIN, TILES, 2>), grid, dim3(kBlock), lds, st, x, w, b, bn_mean,
                            bn_invstd, y, sel, (int)C, P, ceil_div(P, 32));
     } else {
-        opt_in_lds(conv1x1_mfm_forward_kernel<CIN, TILES, false>, lds);
-        hipLaunchKernelGGL((conv1x1_mfm_forward_kernel<CIN, TILES, false>), grid, dim3(kBlock), lds, st, x, w, b, bn_mean,
+        opt_in_lds(conv1x1_mfm_forward_kernel<CIN, TILES, 0>, lds);
+        hipLaunchKernelGGL((conv1x1_mfm_forward_kernel<CIN, TILES, 0>), grid, dim3(kBlock), lds, st, x, w, b, bn_mean,
                            bn_invstd, y, sel, (int)C, P, ceil_div(P, 32));
     }
 }
