@@ -71,11 +71,19 @@ def dct_fragments(dct: torch.Tensor) -> Optional[torch.Tensor]:
     key = (dct.data_ptr(), dct._version, str(dct.device), M, K)
     frag = _FRAGMENTS.get(key)
     if frag is None:
+        if torch.cuda.is_current_stream_capturing():
+            # a table built inside a capture would be filled only when the graph replays, and this cache would hand it to eager
+            # callers before that: take the two-launch path for this call (graphed.py warms up eagerly, so this does not happen
+            # on the shipped path)
+            return None
         if len(_FRAGMENTS) >= 16:
             _FRAGMENTS.clear()
         frag = torch.empty(n, dtype=torch.float32, device=dct.device)
         _lib.check(lib.advstep_lfcc_project_prepare_f32(dct.data_ptr(), M, K, frag.data_ptr(), _stream(dct.device)),
                    "advstep_lfcc_project_prepare_f32")
+        # once per weight version: the table is shared by every stream that calls later, so it must be complete before it is
+        # published (a second stream's first call is not ordered behind this launch)
+        torch.cuda.current_stream(dct.device).synchronize()
         _FRAGMENTS[key] = frag
     return frag
 
@@ -89,7 +97,7 @@ def _rearm(ctx, stats: torch.Tensor, dct: torch.Tensor) -> None:
     `stats[2]` starts again from 0 - and so does the tie counter `stats[1]` where the backward pass is the one that fills it
     (the matrix-core path: stats[3] == 1; the two-launch forward counts the ties itself)."""
     if ctx.backward_calls:
-        if dct_fragments(dct) is not None:
+        if ctx.ties_in_backward:
             stats[1:3].zero_()
         else:
             stats[2:3].zero_()
@@ -125,6 +133,7 @@ class _LfccTail(torch.autograd.Function):
         ctx.save_for_backward(sr, band_db, stats, dct, tables.fbt_start, tables.fbt_w)
         ctx.meta = (B, F, NF, M, K, tables.span_t, float(top_db))
         ctx.backward_calls = 0
+        ctx.ties_in_backward = frag is not None and M == 128 and K == 80
         return out.transpose(1, 2)
 
     @staticmethod
@@ -190,6 +199,7 @@ class _LfccFromWaveform(torch.autograd.Function):
         ctx.save_for_backward(sr, band_db, stats, dct, tables.fbt_start, tables.fbt_w, window)
         ctx.meta = (B, T, F, NF, M, K, tables.span_t, float(top_db), hop, nfft)
         ctx.backward_calls = 0
+        ctx.ties_in_backward = frag is not None and M == 128 and K == 80
         return out.transpose(1, 2)
 
     @staticmethod
@@ -263,6 +273,7 @@ class _LfccFromWaveformFused(torch.autograd.Function):
         ctx.save_for_backward(x, band_db, stats, dct, tables.fbt_start, tables.fbt_w, window)
         ctx.meta = (B, T, NF, M, K, tables.span_t, float(top_db), hop, nfft)
         ctx.backward_calls = 0
+        ctx.ties_in_backward = frag is not None and M == 128 and K == 80
         return out.transpose(1, 2)
 
     @staticmethod
