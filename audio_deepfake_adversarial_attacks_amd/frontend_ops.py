@@ -15,6 +15,7 @@ import torch
 
 from . import _lib, fft_plans
 from .hip_ops import _Launch, _stream
+from .lcnn_ops import _IdKeyed
 
 
 def _direct_fft_enabled() -> bool:
@@ -57,34 +58,34 @@ def filterbank_tables(filter_mat: torch.Tensor) -> FilterbankTables:
                             fbt_w.to(dev).contiguous(), span_t)
 
 
-_FRAGMENTS: dict = {}
+_FRAGMENTS = _IdKeyed()      # weak, keyed by tensor identity
 
 
 def dct_fragments(dct: torch.Tensor) -> Optional[torch.Tensor]:
     """The DCT matrix in the operand order of the matrix-core projection kernels (advstep_lfcc_project_prepare_f32), cached
-    per (storage, version, device); None for sizes without such a path."""
+    per tensor object and version (the entry dies with the tensor: a recycled address cannot hit it); None for sizes without
+    such a path."""
     lib = _lib.load()
     M, K = dct.shape
     n = lib.advstep_lfcc_project_fragment_floats(M, K)
     if n == 0 or not dct.is_contiguous():
         return None
-    key = (dct.data_ptr(), dct._version, str(dct.device), M, K)
-    frag = _FRAGMENTS.get(key)
-    if frag is None:
-        if torch.cuda.is_current_stream_capturing():
-            # a table built inside a capture would be filled only when the graph replays, and this cache would hand it to eager
-            # callers before that: take the two-launch path for this call (graphed.py warms up eagerly, so this does not happen
-            # on the shipped path)
-            return None
-        if len(_FRAGMENTS) >= 16:
-            _FRAGMENTS.clear()
-        frag = torch.empty(n, dtype=torch.float32, device=dct.device)
-        _lib.check(lib.advstep_lfcc_project_prepare_f32(dct.data_ptr(), M, K, frag.data_ptr(), _stream(dct.device)),
-                   "advstep_lfcc_project_prepare_f32")
-        # once per weight version: the table is shared by every stream that calls later, so it must be complete before it is
-        # published (a second stream's first call is not ordered behind this launch)
-        torch.cuda.current_stream(dct.device).synchronize()
-        _FRAGMENTS[key] = frag
+    key = (dct.data_ptr(), dct._version, str(dct.device))
+    hit = _FRAGMENTS.get(dct)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    if torch.cuda.is_current_stream_capturing():
+        # a table built inside a capture would be filled only when the graph replays, and this cache would hand it to eager
+        # callers before that: take the two-launch path for this call (graphed.py warms up eagerly, so this does not happen
+        # on the shipped path)
+        return None
+    frag = torch.empty(n, dtype=torch.float32, device=dct.device)
+    _lib.check(lib.advstep_lfcc_project_prepare_f32(dct.data_ptr(), M, K, frag.data_ptr(), _stream(dct.device)),
+               "advstep_lfcc_project_prepare_f32")
+    # once per weight version: the table is shared by every stream that calls later, so it must be complete before it is
+    # published (a second stream's first call is not ordered behind this launch)
+    torch.cuda.current_stream(dct.device).synchronize()
+    _FRAGMENTS[dct] = (key, frag)
     return frag
 
 
