@@ -913,6 +913,10 @@ __global__ __launch_bounds__(kBlock, 8) void pgd_l2_init_philox_fused_kernel(con
     for (int j = 0; j < kVecs; ++j)
         s += (nz[j].x * nz[j].x + nz[j].y * nz[j].y) + (nz[j].z * nz[j].z + nz[j].w * nz[j].w);
     s = block_reduce(s, SumOp(), lds);
+    // the tile of x is requested BEFORE the exchange (16-byte path): its HBM latency then runs under the wait for the row's other
+    // workgroups; the scalar path (rows not 16-byte addressable) keeps it behind - 16 more live registers make it spill
+    float4 xv[kVecs];
+    if constexpr (VEC) load_tile<VEC>(x + b * T, T, tile, 0.0f, xv);
     const float nrm = sqrtf(row_exchange_sum(gran + b * C, C, tile, s, 1u, spin_limit, lds + 4, &failed));
     if (failed) {
         row_exchange_abandon(fail, b, gran + b * C, nullptr, tile);
@@ -922,8 +926,7 @@ __global__ __launch_bounds__(kBlock, 8) void pgd_l2_init_philox_fused_kernel(con
     const Quad rq = philox4x32_10((uint32_t)b, (uint32_t)((uint64_t)b >> 32), (uint32_t)off1, (uint32_t)(off1 >> 32),
                                   (uint32_t)seed, (uint32_t)(seed >> 32));
     const float scale = (u01(rq.v[0]) / nrm) * eps;
-    float4 xv[kVecs];
-    load_tile<VEC>(x + b * T, T, tile, 0.0f, xv);
+    if constexpr (!VEC) load_tile<VEC>(x + b * T, T, tile, 0.0f, xv);
 #pragma unroll
     for (int j = 0; j < kVecs; ++j) {
         xv[j].x = clampf(xv[j].x + nz[j].x * scale, lo, hi);
