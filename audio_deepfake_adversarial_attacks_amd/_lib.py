@@ -12,7 +12,7 @@ _LIB_PATH = Path(os.environ.get("ADVSTEP_LIB") or Path(__file__).resolve().paren
 _lib = None
 
 OK, EINVAL, EWORKSPACE, ELAUNCH, ENODEVICE = 0, 1, 2, 3, 4
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _p, _i64, _f32, _f64, _u64, _sz = (ctypes.c_void_p, ctypes.c_int64, ctypes.c_float, ctypes.c_double,
                                    ctypes.c_uint64, ctypes.c_size_t)

@@ -562,9 +562,11 @@ __global__ __launch_bounds__(kBlock) void pgd_l2_project_kernel(const float *__r
 // 16 B per sample (adv, grad, orig read once; out written once) instead of 32.  A row is 16 workgroups (T = 64 600); its
 // two norms are exchanged INSIDE the launch through 8-byte {tag, value} granules (one per workgroup and phase, written by ONE
 // agent-scope store, re-read with agent-scope loads until every tag of the row shows the phase: the data is the flag, no
-// fence — /opt/skills/guides/cdna_hip_programming.md Guideline 16, form R2).  The granules are zeroed by a memset node
-// before every launch; tag = phase (1, 2).  The partial sums and their re-reduction are the three-kernel path's own
-// (same block_reduce, same order): results are bit-identical to it.
+// fence — /opt/skills/guides/cdna_hip_programming.md Guideline 16, form R2).  tag = {call epoch, phase}: the workspace's first
+// word counts the single-pass calls that used it (the repair kernel behind every call advances it), so a granule of an earlier
+// call — or a word some other user of the scratch left there — never carries this call's tag and nothing has to be cleaned
+// between calls (round 5; rounds 2-3 zeroed the granules with a memset node, round 4 in the repair kernel).  The partial sums
+// and their re-reduction are the three-kernel path's own (same block_reduce, same order): results are bit-identical to it.
 //
 // Co-residency.  A spinning workgroup must not wait for one that has no slot.  The host takes this path only when the
 // launch fits the device's resident capacity for THIS kernel (CU count x hipOccupancyMaxActiveBlocksPerMultiprocessor,
@@ -575,11 +577,18 @@ __global__ __launch_bounds__(kBlock) void pgd_l2_project_kernel(const float *__r
 // from global memory with the three-kernel path's arithmetic (one workgroup per row, tiles in sequence: same partial sums,
 // same re-reduction, same bits) and returns immediately for all other rows.
 typedef unsigned long long __attribute__((address_space(1))) gu64;
-constexpr unsigned kPoisonTag = 0xFFFFFFFFu;
+// Tags of one call: (epoch + 1) << 2 | {1, 2: the two row sums; 3: poison}.  30 bits of epoch; a zero-filled workspace holds no
+// valid tag (the smallest is 5), and the flag values below (high bit set) are no tag of the first 2^29 calls either.
+constexpr unsigned kPoisonPhase = 3u;
+constexpr unsigned kRowFlagged = 0x80000001u;
+__device__ __forceinline__ unsigned exchange_tag_base(const unsigned *epoch) {
+    return (*epoch + 1u) << 2;
+}
 
 // Returns the row sum; *failed (workgroup-uniform, valid after the call) tells that the sweep was abandoned.
-__device__ __forceinline__ float row_exchange_sum(unsigned long long *granules, int C, int tile, float mine, unsigned phase,
-                                                  unsigned spin_limit, float *lds, int *lds_failed) {
+__device__ __forceinline__ float row_exchange_sum(unsigned long long *granules, int C, int tile, float mine, unsigned base,
+                                                  unsigned phase_no, unsigned spin_limit, float *lds, int *lds_failed) {
+    const unsigned phase = base | phase_no, poison_tag = base | kPoisonPhase;
     if (threadIdx.x == 0) {
         *lds_failed = 0;
         __hip_atomic_store((gu64 *)(granules + tile), ((unsigned long long)phase << 32) | __float_as_uint(mine),
@@ -594,7 +603,7 @@ __device__ __forceinline__ float row_exchange_sum(unsigned long long *granules, 
             if ((int)threadIdx.x < C) {
                 x = __hip_atomic_load((gu64 *)(granules + threadIdx.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 ok = (unsigned)(x >> 32) == phase;
-                poisoned = (unsigned)(x >> 32) == kPoisonTag;
+                poisoned = (unsigned)(x >> 32) == poison_tag;
             }
             if (__any(poisoned)) break;
             if (__all(ok)) {
@@ -613,11 +622,11 @@ __device__ __forceinline__ float row_exchange_sum(unsigned long long *granules, 
 
 // A workgroup that gives up: flag the row, poison this workgroup's granules of the phases it will not reach.
 __device__ __forceinline__ void row_exchange_abandon(unsigned *fail, int64_t b, unsigned long long *g0, unsigned long long *g1,
-                                                     int tile) {
+                                                     int tile, unsigned base) {
     if (threadIdx.x == 0) {
-        __hip_atomic_store((unsigned __attribute__((address_space(1))) *)(fail + b), 1u, __ATOMIC_RELAXED,
+        __hip_atomic_store((unsigned __attribute__((address_space(1))) *)(fail + b), kRowFlagged, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long poison = (unsigned long long)kPoisonTag << 32;
+        const unsigned long long poison = (unsigned long long)(base | kPoisonPhase) << 32;
         if (g0) __hip_atomic_store((gu64 *)(g0 + tile), poison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (g1) __hip_atomic_store((gu64 *)(g1 + tile), poison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -633,7 +642,8 @@ __global__ __launch_bounds__(kBlock, 8) void pgd_l2_fused_kernel(const float *__
                                                                  float alpha, float eps, float eps_div, float lo, float hi,
                                                                  unsigned long long *__restrict__ gran_g,
                                                                  unsigned long long *__restrict__ gran_d,
-                                                                 unsigned *__restrict__ fail, unsigned spin_limit,
+                                                                 unsigned *__restrict__ fail,
+                                                                 const unsigned *__restrict__ epoch, unsigned spin_limit,
                                                                  float *__restrict__ gnorm, float *__restrict__ dnorm) {
     __shared__ float4 xs[kTileVec];
     __shared__ float lds[12];
@@ -653,9 +663,10 @@ __global__ __launch_bounds__(kBlock, 8) void pgd_l2_fused_kernel(const float *__
 #pragma unroll
     for (int j = 0; j < kVecs; ++j) s += (g[j].x * g[j].x + g[j].y * g[j].y) + (g[j].z * g[j].z + g[j].w * g[j].w);
     s = block_reduce(s, SumOp(), lds);
-    const float gsq = row_exchange_sum(gran_g + b * C, C, tile, s, 1u, spin_limit, lds + 4, &failed);
+    const unsigned base = exchange_tag_base(epoch);
+    const float gsq = row_exchange_sum(gran_g + b * C, C, tile, s, base, 1u, spin_limit, lds + 4, &failed);
     if (failed) {
-        row_exchange_abandon(fail, b, gran_g + b * C, gran_d + b * C, tile);
+        row_exchange_abandon(fail, b, gran_g + b * C, gran_d + b * C, tile, base);
         return;
     }
     const float gn_raw = sqrtf(gsq);
@@ -676,9 +687,9 @@ __global__ __launch_bounds__(kBlock, 8) void pgd_l2_fused_kernel(const float *__
         s += (m.x * m.x + m.y * m.y) + (m.z * m.z + m.w * m.w);
     }
     s = block_reduce(s, SumOp(), lds + 8);
-    const float dn = sqrtf(row_exchange_sum(gran_d + b * C, C, tile, s, 2u, spin_limit, lds + 4, &failed));
+    const float dn = sqrtf(row_exchange_sum(gran_d + b * C, C, tile, s, base, 2u, spin_limit, lds + 4, &failed));
     if (failed) {
-        row_exchange_abandon(fail, b, nullptr, gran_d + b * C, tile);
+        row_exchange_abandon(fail, b, nullptr, gran_d + b * C, tile, base);
         return;
     }
     const float f = min_nan((1.0f / dn) * eps, 1.0f);
@@ -702,25 +713,21 @@ __global__ __launch_bounds__(kBlock, 8) void pgd_l2_fused_kernel(const float *__
     }
 }
 
-// Round 4: the single-pass calls are ONE node shorter.  Until round 3 a memset node zeroed the granules and flags before every
-// launch (stale granules of the previous call carry the same phase tags).  Now the repair kernel — queued behind every single-pass
-// launch anyway — leaves the row's state clean for the NEXT call: granules zeroed, the flag moved to `last` (diagnostics) and
-// lowered.  Contract (include/advstep.h): the caller zero-fills a workspace once, before its first use; every call leaves it
-// valid for the next.  A workspace that is NOT clean cannot produce a wrong row: a tag that is neither this phase nor poison makes
-// its readers wait, and a wait that does not end hands the row to the repair pass (slow, never wrong); only a stale granule with
-// a matching tag could be consumed, and those no longer outlive their call.
+// The repair kernel queued behind every single-pass launch also closes the call: it moves the row's flag to `last` (diagnostics),
+// lowers it, and workgroup 0 advances the workspace's epoch word — after which no granule of this call carries a valid tag.
+// Contract (include/advstep.h): the caller zero-fills a workspace once, before its first use (stale FLAGS would send rows to
+// the repair pass: slow, not wrong).  Granules need no cleaning and the float partial planes of the other entry points do not
+// overlap the exchange area of the same (B, T); a word left by a call of ANOTHER shape is consumed only if it equals this
+// call's 32-bit tag at the moment a sibling looks — the epoch makes that a coincidence, not a pattern (the cleaned
+// granules of round 4 could meet `last[b] = 1` of another layout, and 1 was a phase tag).
 // Returns the row's flag (workgroup-uniform).
-__device__ __forceinline__ unsigned take_flag_and_clean(unsigned long long *g0, unsigned long long *g1, int C, unsigned *fail,
-                                                        unsigned *last, int64_t b) {
+__device__ __forceinline__ unsigned take_flag(unsigned *fail, unsigned *last, unsigned *epoch, int64_t b) {
     __shared__ unsigned flag_s;
     if (threadIdx.x == 0) {
         flag_s = fail[b];
-        last[b] = flag_s;
+        last[b] = flag_s ? kRowFlagged : 0u;
         fail[b] = 0u;
-    }
-    if ((int)threadIdx.x < C) {
-        g0[b * C + threadIdx.x] = 0ull;
-        if (g1) g1[b * C + threadIdx.x] = 0ull;
+        if (b == 0) *epoch = *epoch + 1u;          // single writer; the next launch on this stream reads it
     }
     __syncthreads();
     return flag_s;
@@ -734,11 +741,10 @@ template <bool VEC>
 __global__ __launch_bounds__(kBlock) void pgd_l2_repair_kernel(const float *__restrict__ adv, const float *__restrict__ grad,
                                                                const float *__restrict__ orig, float *out, int64_t T, int C,
                                                                float alpha, float eps, float eps_div, float lo, float hi,
-                                                               unsigned long long *gran_g, unsigned long long *gran_d,
-                                                               unsigned *fail, unsigned *last, float *__restrict__ gnorm,
-                                                               float *__restrict__ dnorm) {
+                                                               unsigned *fail, unsigned *last, unsigned *epoch,
+                                                               float *__restrict__ gnorm, float *__restrict__ dnorm) {
     const int64_t b = blockIdx.x;
-    if (!take_flag_and_clean(gran_g, gran_d, C, fail, last, b)) return;
+    if (!take_flag(fail, last, epoch, b)) return;
     __shared__ float gpart[64], dpart[64], lds[12];
     float4 a[kVecs], g[kVecs], x[kVecs];
     for (int tile = 0; tile < C; ++tile) {
@@ -803,7 +809,7 @@ __global__ __launch_bounds__(kBlock) void pgd_l2_repair_kernel(const float *__re
 // rows whose flag is up (diagnostics / tests: how often the repair pass had work)
 __global__ __launch_bounds__(64) void count_flags_kernel(const unsigned *__restrict__ fail, int64_t B, int *__restrict__ count) {
     int n = 0;
-    for (int64_t i = threadIdx.x; i < B; i += 64) n += fail[i] != 0;
+    for (int64_t i = threadIdx.x; i < B; i += 64) n += fail[i] == kRowFlagged;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) n += __shfl_xor(n, off, 64);
     if (threadIdx.x == 0) *count = n;
@@ -901,7 +907,9 @@ __global__ __launch_bounds__(kBlock, 8) void pgd_l2_init_philox_fused_kernel(con
                                                                              float eps, float lo, float hi, uint64_t seed,
                                                                              uint64_t offset,
                                                                              unsigned long long *__restrict__ gran,
-                                                                             unsigned *__restrict__ fail, unsigned spin_limit) {
+                                                                             unsigned *__restrict__ fail,
+                                                                             const unsigned *__restrict__ epoch,
+                                                                             unsigned spin_limit) {
     __shared__ float lds[8];
     __shared__ int failed;
     const int tile = blockIdx.x, C = gridDim.x;
@@ -917,9 +925,10 @@ __global__ __launch_bounds__(kBlock, 8) void pgd_l2_init_philox_fused_kernel(con
     // workgroups; the scalar path (rows not 16-byte addressable) keeps it behind - 16 more live registers make it spill
     float4 xv[kVecs];
     if constexpr (VEC) load_tile<VEC>(x + b * T, T, tile, 0.0f, xv);
-    const float nrm = sqrtf(row_exchange_sum(gran + b * C, C, tile, s, 1u, spin_limit, lds + 4, &failed));
+    const unsigned base = exchange_tag_base(epoch);
+    const float nrm = sqrtf(row_exchange_sum(gran + b * C, C, tile, s, base, 1u, spin_limit, lds + 4, &failed));
     if (failed) {
-        row_exchange_abandon(fail, b, gran + b * C, nullptr, tile);
+        row_exchange_abandon(fail, b, gran + b * C, nullptr, tile, base);
         return;
     }
     const uint64_t off1 = offset + 1;
@@ -942,10 +951,10 @@ __global__ __launch_bounds__(kBlock, 8) void pgd_l2_init_philox_fused_kernel(con
 template <bool VEC>
 __global__ __launch_bounds__(kBlock) void pgd_l2_init_philox_repair_kernel(const float *__restrict__ x, float *out, int64_t T, int C,
                                                                            float eps, float lo, float hi, uint64_t seed,
-                                                                           uint64_t offset, unsigned long long *gran, unsigned *fail,
-                                                                           unsigned *last) {
+                                                                           uint64_t offset, unsigned *fail, unsigned *last,
+                                                                           unsigned *epoch) {
     const int64_t b = blockIdx.x;
-    if (!take_flag_and_clean(gran, nullptr, C, fail, last, b)) return;
+    if (!take_flag(fail, last, epoch, b)) return;
     __shared__ float npart[64], lds[8];
     float4 nz[kVecs], xv[kVecs];
     for (int tile = 0; tile < C; ++tile) {
@@ -1077,21 +1086,39 @@ inline hipStream_t as_stream(advstep_stream_t s) { return reinterpret_cast<hipSt
 struct RowWs {
     float *p0;
     float *p1;
+    unsigned *epoch;               // single-pass PGD-L2 exchange: call counter (the tags' epoch) ...
+    unsigned long long *gran0;     // ... two planes of B x C 8-byte {tag, value} granules ...
+    unsigned long long *gran1;
+    unsigned *fail;                // ... the live "row needs repair" flags and the flags of the LAST single-pass call as its
+    unsigned *last;                //     repair pass left them (advstep_pgd_l2_repaired_rows reads those)
 };
-// four planes of B x C floats: two partial-sum planes for the multi-kernel reductions, or — the single-pass PGD-L2 step —
-// two planes of B x C 8-byte granules laid over all four
-inline size_t row_ws_plane(int64_t B, int64_t T) {
-    const size_t one = (size_t)B * (size_t)tiles_per_row(T) * sizeof(float);
-    return (one + 15) & ~(size_t)15;
+// Layout for a (B, T) batch, C = tiles per row (round 5: the exchange area no longer lies over the float planes):
+//   [16-byte header: epoch word][granule plane 0][granule plane 1][fail flags][last flags][float plane 0][float plane 1]
+inline size_t align16(size_t n) { return (n + 15) & ~(size_t)15; }
+constexpr size_t kWsHeader = 16;
+inline size_t row_ws_plane(int64_t B, int64_t T) { return align16((size_t)B * (size_t)tiles_per_row(T) * sizeof(float)); }
+inline size_t row_ws_granules(int64_t B, int64_t T) {
+    return align16((size_t)B * (size_t)tiles_per_row(T) * sizeof(unsigned long long));
 }
-// ... followed by two 32-bit words per row (single-pass PGD-L2 paths): the live "row needs repair" flags, and the flags of the
-// LAST single-pass call as its repair pass left them (advstep_pgd_l2_repaired_rows reads those)
-inline size_t row_ws_flags(int64_t B) { return ((size_t)B * sizeof(unsigned) + 15) & ~(size_t)15; }
-inline size_t row_ws_bytes(int64_t B, int64_t T) { return 4 * row_ws_plane(B, T) + 2 * row_ws_flags(B); }
+inline size_t row_ws_flags(int64_t B) { return align16((size_t)B * sizeof(unsigned)); }
+inline size_t row_ws_bytes(int64_t B, int64_t T) {
+    return kWsHeader + 2 * row_ws_granules(B, T) + 2 * row_ws_flags(B) + 2 * row_ws_plane(B, T);
+}
 inline bool carve_ws(void *ws, size_t ws_bytes, int64_t B, int64_t T, RowWs *out) {
     if (!ws || !aligned16(ws) || ws_bytes < row_ws_bytes(B, T)) return false;
-    out->p0 = static_cast<float *>(ws);
-    out->p1 = reinterpret_cast<float *>(static_cast<char *>(ws) + row_ws_plane(B, T));
+    char *p = static_cast<char *>(ws);
+    out->epoch = reinterpret_cast<unsigned *>(p);
+    p += kWsHeader;
+    out->gran0 = reinterpret_cast<unsigned long long *>(p);
+    p += row_ws_granules(B, T);
+    out->gran1 = reinterpret_cast<unsigned long long *>(p);
+    p += row_ws_granules(B, T);
+    out->fail = reinterpret_cast<unsigned *>(p);
+    p += row_ws_flags(B);
+    out->last = reinterpret_cast<unsigned *>(p);
+    p += row_ws_flags(B);
+    out->p0 = reinterpret_cast<float *>(p);
+    out->p1 = reinterpret_cast<float *>(p + row_ws_plane(B, T));
     return true;
 }
 
@@ -1355,21 +1382,18 @@ int advstep_pgd_l2_init_philox_f32(const float *x, float *out, int64_t B, int64_
     const void *fused = vec ? (const void *)pgd_l2_init_philox_fused_kernel<true> : (const void *)pgd_l2_init_philox_fused_kernel<false>;
     if (l2_single_pass() && C <= 64 && !overlaps(x, out, (size_t)B * T * sizeof(float)) &&
         B * C <= l2_resident_capacity(vec ? kCapInitVec : kCapInitScalar, fused)) {
-        // the repair kernel behind the launch serves flagged rows and leaves granules + flags clean for the next call
-        unsigned long long *gran = static_cast<unsigned long long *>(ws);
-        unsigned *fail = reinterpret_cast<unsigned *>(static_cast<char *>(ws) + 4 * row_ws_plane(B, T));
-        unsigned *last = reinterpret_cast<unsigned *>(static_cast<char *>(ws) + 4 * row_ws_plane(B, T) + row_ws_flags(B));
+        // the repair kernel behind the launch serves flagged rows, lowers their flags and advances the epoch (closes the call)
         const unsigned spins = l2_spin_limit();
         if (vec) {
             hipLaunchKernelGGL(pgd_l2_init_philox_fused_kernel<true>, dim3(C, (unsigned)B), dim3(kBlock), 0, st, x, out, T, eps, lo,
-                               hi, seed, offset, gran, fail, spins);
+                               hi, seed, offset, w.gran0, w.fail, w.epoch, spins);
             hipLaunchKernelGGL(pgd_l2_init_philox_repair_kernel<true>, dim3((unsigned)B), dim3(kBlock), 0, st, x, out, T, C, eps,
-                               lo, hi, seed, offset, gran, fail, last);
+                               lo, hi, seed, offset, w.fail, w.last, w.epoch);
         } else {
             hipLaunchKernelGGL(pgd_l2_init_philox_fused_kernel<false>, dim3(C, (unsigned)B), dim3(kBlock), 0, st, x, out, T, eps, lo,
-                               hi, seed, offset, gran, fail, spins);
+                               hi, seed, offset, w.gran0, w.fail, w.epoch, spins);
             hipLaunchKernelGGL(pgd_l2_init_philox_repair_kernel<false>, dim3((unsigned)B), dim3(kBlock), 0, st, x, out, T, C, eps,
-                               lo, hi, seed, offset, gran, fail, last);
+                               lo, hi, seed, offset, w.fail, w.last, w.epoch);
         }
         return status_after_launch();
     }
@@ -1394,23 +1418,18 @@ int advstep_pgd_l2_step_f32(const float *adv, const float *grad, const float *or
     if (l2_single_pass() && C <= 64 && !overlaps(adv, out, row_bytes) && !overlaps(grad, out, row_bytes) &&
         !overlaps(orig, out, row_bytes) && B * C <= l2_resident_capacity(vec ? kCapStepVec : kCapStepScalar, fused)) {
         // the launch fits the device's resident capacity for this kernel: one launch, 16 B per sample; the repair kernel behind
-        // it serves rows whose exchange was abandoned and leaves granules + flags clean for the next call (no memset node)
-        const size_t plane = 2 * row_ws_plane(B, T);
-        unsigned long long *gg = static_cast<unsigned long long *>(ws);
-        unsigned long long *gd = reinterpret_cast<unsigned long long *>(static_cast<char *>(ws) + plane);
-        unsigned *fail = reinterpret_cast<unsigned *>(static_cast<char *>(ws) + 2 * plane);
-        unsigned *last = reinterpret_cast<unsigned *>(static_cast<char *>(ws) + 2 * plane + row_ws_flags(B));
+        // it serves rows whose exchange was abandoned, lowers their flags and advances the epoch (no memset node, nothing cleaned)
         const unsigned spins = l2_spin_limit();
         if (vec) {
             hipLaunchKernelGGL(pgd_l2_fused_kernel<true>, dim3(C, (unsigned)B), dim3(kBlock), 0, st, adv, grad, orig, out, T, alpha,
-                               eps, eps_div, lo, hi, gg, gd, fail, spins, gnorm, dnorm);
+                               eps, eps_div, lo, hi, w.gran0, w.gran1, w.fail, w.epoch, spins, gnorm, dnorm);
             hipLaunchKernelGGL(pgd_l2_repair_kernel<true>, dim3((unsigned)B), dim3(kBlock), 0, st, adv, grad, orig, out, T, C, alpha,
-                               eps, eps_div, lo, hi, gg, gd, fail, last, gnorm, dnorm);
+                               eps, eps_div, lo, hi, w.fail, w.last, w.epoch, gnorm, dnorm);
         } else {
             hipLaunchKernelGGL(pgd_l2_fused_kernel<false>, dim3(C, (unsigned)B), dim3(kBlock), 0, st, adv, grad, orig, out, T, alpha,
-                               eps, eps_div, lo, hi, gg, gd, fail, spins, gnorm, dnorm);
+                               eps, eps_div, lo, hi, w.gran0, w.gran1, w.fail, w.epoch, spins, gnorm, dnorm);
             hipLaunchKernelGGL(pgd_l2_repair_kernel<false>, dim3((unsigned)B), dim3(kBlock), 0, st, adv, grad, orig, out, T, C, alpha,
-                               eps, eps_div, lo, hi, gg, gd, fail, last, gnorm, dnorm);
+                               eps, eps_div, lo, hi, w.fail, w.last, w.epoch, gnorm, dnorm);
         }
         return status_after_launch();
     }
@@ -1427,8 +1446,9 @@ int advstep_pgd_l2_repaired_rows(const void *ws, size_t ws_bytes, int64_t B, int
     ADV_REQUIRE(B >= 0 && T >= 0 && count);
     if (B == 0 || T == 0) return hipMemsetAsync(count, 0, sizeof(int), as_stream(stream)) == hipSuccess ? ADVSTEP_OK : ADVSTEP_ELAUNCH;
     if (!ws || !aligned16(ws) || ws_bytes < row_ws_bytes(B, T)) return ADVSTEP_EWORKSPACE;
-    const unsigned *last = reinterpret_cast<const unsigned *>(static_cast<const char *>(ws) + 4 * row_ws_plane(B, T) + row_ws_flags(B));
-    hipLaunchKernelGGL(count_flags_kernel, dim3(1), dim3(64), 0, as_stream(stream), last, B, count);
+    RowWs w;
+    carve_ws(const_cast<void *>(ws), ws_bytes, B, T, &w);
+    hipLaunchKernelGGL(count_flags_kernel, dim3(1), dim3(64), 0, as_stream(stream), (const unsigned *)w.last, B, count);
     return status_after_launch();
 }
 

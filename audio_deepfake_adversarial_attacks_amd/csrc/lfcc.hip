@@ -251,7 +251,7 @@ __global__ __launch_bounds__(kBlock) void lfcc_project_prepare_kernel(const floa
 // the backward pass (stats[3] == 1 tells it so), which sees every dB value anyway.
 __global__ __launch_bounds__(kPThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void lfcc_project_mfma_kernel(const float *__restrict__ band_db,
                                                                      const float *__restrict__ frag,
-                                                                     const float *__restrict__ block_maxima, int nblk,
+                                                                     const float *block_maxima, int nblk,
                                                                      float *stats, float top_db, float *__restrict__ out,
                                                                      int64_t F) {
     __shared__ __attribute__((aligned(16))) float tile[kPTile * kBandPitch];     // 33 792 B: the dB tile, then the cepstra
@@ -295,7 +295,9 @@ __global__ __launch_bounds__(kPThreads) __attribute__((amdgpu_waves_per_eu(4, 4)
     }
     const float gmax = block_max(v, red);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        stats[0] = gmax;
+        // (large batches hand in stats itself as a one-entry array of maxima - not restrict-qualified for that reason: the
+        // other workgroups are reading stats[0] then, so it is not stored again)
+        if (block_maxima != stats) stats[0] = gmax;
         stats[1] = 0.0f;
         stats[2] = 0.0f;
         stats[3] = 1.0f;
@@ -634,7 +636,7 @@ int advstep_lfcc_max_project_f32(const float *band_db, const float *dct, const f
                  (reinterpret_cast<uintptr_t>(band_db) & 15u) == 0 && (reinterpret_cast<uintptr_t>(out) & 15u) == 0);
     // every workgroup reduces the block maxima itself: fine for the fused STFT kernel's 26 per utterance (13 KB at B = 128), not for
     // advstep_lfcc_bands_f32's 202 per utterance (100 KB x 808 workgroups) - those are reduced by one launch first and the
-    // projection is handed stats[0] as a one-entry array (it re-publishes the same value)
+    // projection is handed stats[0] as a one-entry array (which it then leaves alone)
     if (n > 8192) {
         const int st = advstep_lfcc_reduce_max_f32(block_max, n, stats, stream);
         if (st != ADVSTEP_OK) return st;

@@ -93,10 +93,13 @@ def _ptr(t: Optional[torch.Tensor]) -> int:
     return 0 if t is None else t.data_ptr()
 
 
-def _rearm(ctx, stats: torch.Tensor, dct: torch.Tensor) -> None:
-    """A second backward pass through the same forward (retain_graph): the floored-gradient sum the first one accumulated in
-    `stats[2]` starts again from 0 - and so does the tie counter `stats[1]` where the backward pass is the one that fills it
-    (the matrix-core path: stats[3] == 1; the two-launch forward counts the ties itself)."""
+def _rearm(ctx, stats: torch.Tensor) -> None:
+    """A further backward pass through the same forward (retain_graph): the floored-gradient sum the previous one accumulated
+    in `stats[2]` starts again from 0 - and so does the tie counter `stats[1]` where the backward pass is the one that fills it
+    (the matrix-core path: stats[3] == 1; the two-launch forward counts the ties itself).  `stats` is this node's own scratch,
+    kept as a plain attribute of ctx - NOT among the saved tensors, whose version check would refuse the third pass after
+    this in-place reset - and so is the fragment table the forward pass chose: who counts the ties was decided
+    there, the backward pass must not look the table up again (a cache miss would hand it the other kernel)."""
     if ctx.backward_calls:
         if ctx.ties_in_backward:
             stats[1:3].zero_()
@@ -131,7 +134,8 @@ class _LfccTail(torch.autograd.Function):
             st = lib.advstep_lfcc_max_project_f32(band_db.data_ptr(), dct.data_ptr(), _ptr(frag), block_max.data_ptr(), nblk,
                                                   stats.data_ptr(), top_db, out.data_ptr(), B, M, NF, K, _stream(dev))
             _lib.check(st, "advstep_lfcc_max_project_f32")
-        ctx.save_for_backward(sr, band_db, stats, dct, tables.fbt_start, tables.fbt_w)
+        ctx.save_for_backward(sr, band_db, dct, tables.fbt_start, tables.fbt_w)
+        ctx.stats, ctx.frag = stats, frag
         ctx.meta = (B, F, NF, M, K, tables.span_t, float(top_db))
         ctx.backward_calls = 0
         ctx.ties_in_backward = frag is not None and M == 128 and K == 80
@@ -139,16 +143,17 @@ class _LfccTail(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gout):
-        sr, band_db, stats, dct, fbt_start, fbt_w = ctx.saved_tensors
+        sr, band_db, dct, fbt_start, fbt_w = ctx.saved_tensors
+        stats, frag = ctx.stats, ctx.frag
         B, F, NF, M, K, span_t, top_db = ctx.meta
         dev = gout.device
         go = gout.transpose(1, 2).contiguous()     # (B, NF, K); a no-op when the consumer is frame-major
         lib = _lib.load()
         dband = torch.empty((B, NF, M), dtype=torch.float32, device=dev)
         dspec = torch.empty((B, NF, F, 2), dtype=torch.float32, device=dev)
-        _rearm(ctx, stats, dct)
+        _rearm(ctx, stats)
         with _Launch("lfcc_backward", dev):
-            st = lib.advstep_lfcc_project_backward_zero_f32(go.data_ptr(), dct.data_ptr(), _ptr(dct_fragments(dct)),
+            st = lib.advstep_lfcc_project_backward_zero_f32(go.data_ptr(), dct.data_ptr(), _ptr(frag),
                                                             band_db.data_ptr(), stats.data_ptr(), top_db, dband.data_ptr(), B, M, NF,
                                                             K, 0, 0, _stream(dev))
             _lib.check(st, "advstep_lfcc_project_backward_zero_f32")
@@ -197,7 +202,8 @@ class _LfccFromWaveform(torch.autograd.Function):
             st = lib.advstep_lfcc_max_project_f32(band_db.data_ptr(), dct.data_ptr(), _ptr(frag), block_max.data_ptr(), nblk,
                                                   stats.data_ptr(), top_db, out.data_ptr(), B, M, NF, K, _stream(dev))
             _lib.check(st, "advstep_lfcc_max_project_f32")
-        ctx.save_for_backward(sr, band_db, stats, dct, tables.fbt_start, tables.fbt_w, window)
+        ctx.save_for_backward(sr, band_db, dct, tables.fbt_start, tables.fbt_w, window)
+        ctx.stats, ctx.frag = stats, frag
         ctx.meta = (B, T, F, NF, M, K, tables.span_t, float(top_db), hop, nfft)
         ctx.backward_calls = 0
         ctx.ties_in_backward = frag is not None and M == 128 and K == 80
@@ -205,16 +211,17 @@ class _LfccFromWaveform(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gout):
-        sr, band_db, stats, dct, fbt_start, fbt_w, window = ctx.saved_tensors
+        sr, band_db, dct, fbt_start, fbt_w, window = ctx.saved_tensors
+        stats, frag = ctx.stats, ctx.frag
         B, T, F, NF, M, K, span_t, top_db, hop, nfft = ctx.meta
         dev = gout.device
         go = gout.transpose(1, 2).contiguous()
         lib = _lib.load()
         dband = torch.empty((B, NF, M), dtype=torch.float32, device=dev)
         dspec = torch.empty((B, NF, F, 2), dtype=torch.float32, device=dev)
-        _rearm(ctx, stats, dct)
+        _rearm(ctx, stats)
         with _Launch("lfcc_backward", dev):
-            st = lib.advstep_lfcc_project_backward_zero_f32(go.data_ptr(), dct.data_ptr(), _ptr(dct_fragments(dct)),
+            st = lib.advstep_lfcc_project_backward_zero_f32(go.data_ptr(), dct.data_ptr(), _ptr(frag),
                                                             band_db.data_ptr(), stats.data_ptr(), top_db, dband.data_ptr(), B, M, NF,
                                                             K, 0, 0, _stream(dev))
             _lib.check(st, "advstep_lfcc_project_backward_zero_f32")
@@ -271,7 +278,8 @@ class _LfccFromWaveformFused(torch.autograd.Function):
             st = lib.advstep_lfcc_max_project_f32(band_db.data_ptr(), dct.data_ptr(), _ptr(frag), block_max.data_ptr(), nblk,
                                                   stats.data_ptr(), top_db, out.data_ptr(), B, M, NF, K, _stream(dev))
             _lib.check(st, "advstep_lfcc_max_project_f32")
-        ctx.save_for_backward(x, band_db, stats, dct, tables.fbt_start, tables.fbt_w, window)
+        ctx.save_for_backward(x, band_db, dct, tables.fbt_start, tables.fbt_w, window)
+        ctx.stats, ctx.frag = stats, frag
         ctx.meta = (B, T, NF, M, K, tables.span_t, float(top_db), hop, nfft)
         ctx.backward_calls = 0
         ctx.ties_in_backward = frag is not None and M == 128 and K == 80
@@ -279,18 +287,19 @@ class _LfccFromWaveformFused(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gout):
-        x, band_db, stats, dct, fbt_start, fbt_w, window = ctx.saved_tensors
+        x, band_db, dct, fbt_start, fbt_w, window = ctx.saved_tensors
+        stats, frag = ctx.stats, ctx.frag
         B, T, NF, M, K, span_t, top_db, hop, nfft = ctx.meta
         dev = gout.device
         go = gout.transpose(1, 2).contiguous()
         lib = _lib.load()
         dband = torch.empty((B, NF, M), dtype=torch.float32, device=dev)
         dx = torch.empty((B, T), dtype=torch.float32, device=dev)
-        _rearm(ctx, stats, dct)
+        _rearm(ctx, stats)
         with _Launch("lfcc_backward", dev, tensors=(go, band_db, dband, dband, x, dx, dx)):
             # two launches: [DCT^T + floor mask + dB' + tie count; zero-fills dx] -> [floor fix-up folded into the band-gradient
             # load + filterbank^T + FFT pair + overlap-add]
-            st = lib.advstep_lfcc_project_backward_zero_f32(go.data_ptr(), dct.data_ptr(), _ptr(dct_fragments(dct)),
+            st = lib.advstep_lfcc_project_backward_zero_f32(go.data_ptr(), dct.data_ptr(), _ptr(frag),
                                                             band_db.data_ptr(), stats.data_ptr(), top_db, dband.data_ptr(), B, M, NF,
                                                             K, dx.data_ptr(), dx.numel(), _stream(dev))
             _lib.check(st, "advstep_lfcc_project_backward_zero_f32")

@@ -28,7 +28,7 @@ NAME = "hip"
 # plumbing
 # ---------------------------------------------------------------------------------------------------------
 
-_workspaces: Dict[Tuple[int, int], torch.Tensor] = {}
+_workspaces: Dict[Tuple[int, int, int, int], torch.Tensor] = {}     # (device, stream handle, B, T) -> row-reduction scratch
 _profile: Optional[Dict[str, List[Tuple[torch.cuda.Event, torch.cuda.Event]]]] = None
 _profile_work: Dict[str, List[float]] = {}      # per bracketed launch: the arithmetic the caller says it did (flop), or 0
 _profile_bytes: Dict[str, List[float]] = {}     # per bracketed launch: the bytes of the operands the caller named, or 0
@@ -69,12 +69,14 @@ def _stream(device: torch.device) -> int:
 
 
 def _workspace(device: torch.device, B: int, T: int) -> Tuple[int, int]:
-    need = _lib.load().advstep_row_workspace_bytes(B, T)
-    key = (device.index if device.index is not None else torch.cuda.current_device(), _stream(device))
+    # one scratch per (device, stream, batch shape): the layout of the single-pass PGD-L2 exchange area depends on (B, T), and a
+    # buffer that only ever sees one shape never shows a call words another layout left behind (include/advstep.h)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), _stream(device), int(B), int(T))
     ws = _workspaces.get(key)
-    if ws is None or ws.numel() < need:
-        # zero-filled ONCE: the single-pass PGD-L2 calls keep their exchange state clean from call to call (include/advstep.h)
-        ws = torch.zeros(max(need, 1 << 16), dtype=torch.uint8, device=device)
+    if ws is None:
+        need = _lib.load().advstep_row_workspace_bytes(B, T)
+        # zero-filled ONCE: epoch 0, no row flagged (include/advstep.h)
+        ws = torch.zeros(max(need, 256), dtype=torch.uint8, device=device)
         _workspaces[key] = ws
     return ws.data_ptr(), ws.numel()
 

@@ -254,6 +254,13 @@ class BaseLCNN(nn.Module):
         if any(m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or getattr(m, "_backward_pre_hooks", None)
                for m in bypassed):
             return None
+        # ... and so must hooks registered for EVERY module (torch.nn.modules.module.register_module_forward_hook and its pre /
+        # backward variants): they fire from Module.__call__, which the node does not go through either
+        from torch.nn.modules import module as _nn_module
+        if any(getattr(_nn_module, name, None) for name in ("_global_forward_hooks", "_global_forward_pre_hooks",
+                                                            "_global_forward_hooks_always_called", "_global_backward_hooks",
+                                                            "_global_backward_pre_hooks")):
+            return None
         params = [p for m in layers for p in m.parameters()] + list(self.m_output_act.parameters())
         if torch.is_grad_enabled() and any(p.requires_grad for p in params):
             return None

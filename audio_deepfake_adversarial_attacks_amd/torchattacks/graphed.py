@@ -71,11 +71,10 @@ class _Captured:
         with torch.cuda.stream(side):
             two_iterations()
         torch.cuda.current_stream(dev).wait_stream(side)
-        # The graph bakes in the ADDRESS of hip_ops' row-reduction workspace of (device, this stream).  torch hands out stream
-        # handles from a small round-robin pool, so a later capture can land on the same handle, need a larger workspace and
-        # make hip_ops replace — i.e. free — this one while this graph still writes to it on every replay: hold a reference
+        # The graph bakes in the ADDRESSES of hip_ops' row-reduction workspaces of (device, this stream, batch shape): hold a
+        # reference, so that nothing hip_ops does with its table later can free a buffer this graph writes to on every replay
         from .. import hip_ops
-        self._workspaces = [ws for (_, handle), ws in hip_ops._workspaces.items() if handle == side.cuda_stream]
+        self._workspaces = [ws for key, ws in hip_ops._workspaces.items() if key[1] == side.cuda_stream]
         self.graph = torch.cuda.CUDAGraph()
         # thread-local capture mode: with N > 1 ranks the RCCL watchdog thread (event queries), and in the CLI the DataLoader's
         # pinning thread, make HIP calls of their own while this thread captures; in the default "global" mode any such call

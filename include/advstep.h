@@ -13,9 +13,14 @@
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); kernels are stream-ordered,
  *     never synchronise the device, keep no global state and are re-entrant;
  *   - the caller owns every buffer, including the row-reduction scratch `ws`
- *     (>= advstep_row_workspace_bytes(B, T) bytes, 16-byte aligned, ZERO-FILLED ONCE by the caller before its first use: the
- *     single-pass PGD-L2 calls keep their in-launch exchange state in it and leave it clean for the next call — ABI 2; a
- *     workspace that was not zero-filled can cost time, never a wrong row: see advstep_pgd_l2_repaired_rows);
+ *     (>= advstep_row_workspace_bytes(B, T) bytes, 16-byte aligned, ZERO-FILLED ONCE by the caller before its first use, used
+ *     by ONE stream at a time, and best kept for ONE (B, T): the single-pass PGD-L2 calls keep their in-launch exchange state
+ *     in it — a call counter in its first word, tagged 8-byte granules, per-row flags — in an area the float partial sums of
+ *     the other entry points do not touch for the same (B, T).  Nothing has to be cleaned between calls: a granule counts
+ *     only if it carries the tag of THIS call (counter + phase).  What a violated contract costs: flags that are not zero
+ *     send their rows through the repair pass (slower, same bits; advstep_pgd_l2_repaired_rows counts them); a buffer shared
+ *     between shapes can show a call a word another layout left behind, which is consumed only if it equals the call's
+ *     32-bit tag — a coincidence the counter keeps from repeating, not an impossibility.  ABI 3);
  *   - `out` may alias the first waveform input of the same call (in-place update) unless stated otherwise;
  *   - return value: ADVSTEP_OK or an ADVSTEP_E* code; nothing is thrown across the ABI.
  *   - Python-float hyper-parameters of the reference enter as float32 (that is how ATen applies a Python
@@ -32,11 +37,13 @@
 extern "C" {
 #endif
 
-/* 2 (round 4): advstep_conv3x3_mfm_pool2_backward_f32 takes a mode-2 prepared U (a mode-1 U — version 1's contract — gives wrong
+/* 3 (round 5): the row workspace has a new layout (header word + exchange area + float planes: advstep_row_workspace_bytes
+ * grew again) and the single-pass PGD-L2 calls tag their exchange with a call counter instead of cleaning it.
+ * 2 (round 4): advstep_conv3x3_mfm_pool2_backward_f32 takes a mode-2 prepared U (a mode-1 U — version 1's contract — gives wrong
  * gradients without an error) and needs 128 KB of LDS per workgroup for K > 64; advstep_row_workspace_bytes grew in rounds 3
  * and 4, and `ws` must be zero-filled once before its first use (no memset node inside the PGD-L2 calls any more).
  * A binding built against another version must refuse the library (the Python binding does, for every build it is pointed at). */
-#define ADVSTEP_ABI_VERSION 2
+#define ADVSTEP_ABI_VERSION 3
 
 enum {
     ADVSTEP_OK = 0,

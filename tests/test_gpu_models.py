@@ -117,5 +117,15 @@ def test_lcnn_fused_tail_steps_aside_for_hooks(cuda):
     seen.clear()
     again = model(x)
     assert not seen and torch.equal(again, fused)               # hook gone: the fused node is back, bit for bit
+    # hooks registered for EVERY module fire from Module.__call__ as well - same rule
+    calls = []
+    handle = torch.nn.modules.module.register_module_forward_hook(
+        lambda m, i, o: calls.append(m) if m is model.m_output_act else None)
+    try:
+        hooked = model(x)
+    finally:
+        handle.remove()
+    assert len(calls) == 1 and (hooked - fused).abs().max().item() <= 2e-6
+    assert torch.equal(model(x), fused)
     # the weight's w / T row is cached off the Parameter: nothing extra is pickled with the model
     assert not hasattr(model.m_output_act.weight, "_advstep_over_t")

@@ -39,13 +39,14 @@ def test_header_symbols_are_exported_and_bound(lib):
 
 
 def test_library_basics_without_gpu(lib):
-    assert lib.advstep_abi_version() == 2
+    assert lib.advstep_abi_version() == 3
     assert lib.advstep_device_count() >= 0
     assert lib.advstep_status_string(0) == b"ok" and b"workspace" in lib.advstep_status_string(2)
-    # 4 planes of ceil(T / 4096) floats per row (two partial-sum planes, or two planes of 8-byte granules) + two 32-bit words
-    # per row: the live "row needs repair" flag and the last single-pass call's (single-pass PGD-L2 paths; round 4)
-    assert lib.advstep_row_workspace_bytes(128, 64_600) == 4 * 128 * 16 * 4 + 2 * 128 * 4
-    assert lib.advstep_row_workspace_bytes(1, 1) == 64 + 2 * 16 and lib.advstep_row_workspace_bytes(0, 5) == 0
+    # round 5 (ABI 3): a 16-byte header (the single-pass PGD-L2 calls' counter), two planes of ceil(T / 4096) 8-byte granules
+    # per row, two 32-bit words per row (the live "row needs repair" flag and the last single-pass call's), and - no longer
+    # underneath the granules - the two float partial-sum planes of the multi-kernel reductions
+    assert lib.advstep_row_workspace_bytes(128, 64_600) == 16 + 2 * 128 * 16 * 8 + 2 * 128 * 4 + 2 * 128 * 16 * 4
+    assert lib.advstep_row_workspace_bytes(1, 1) == 16 + 2 * 16 + 2 * 16 + 2 * 16 and lib.advstep_row_workspace_bytes(0, 5) == 0
 
 
 def test_argument_validation_needs_no_device(lib):
