@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "advstep_lcnn.h"
 
@@ -241,6 +242,177 @@ __global__ __launch_bounds__(kBlock) void conv5_mfm_pool2_backward_kernel(const 
     }
 }
 
+// ---- round 5: the same gradient, cell-centric -------------------------------------------------------------------------------
+// The gather above reads, per 2x2 input patch and channel, the (gradient, code) pair of 9 pooled cells and 9 x 3 LDS words
+// (27 LDS instructions, 18 vector-memory loads) for 36 multiply-adds: the LDS - one per compute unit - is what bounds it
+// (profiles/r04_model_kernel_pmc_deep.txt).  Turned round: a thread owns a pooled CELL.  Its winner (channel half, position
+// inside the 2x2 window) sends the 5x5 taps to a 6x6 window of input pixels around the cell; that window is a function of the
+// channel and the 3-bit code alone, so all 8 of them sit expanded in LDS (36 floats each: the taps shifted by the winner's
+// position, zeros around) and a cell reads its window with nine 16-byte loads at `code * 144`: per cell and channel 2
+// vector-memory loads and 9 LDS reads for the same 36 multiply-adds, accumulated over all channels in 36 registers.  Only then
+// do the 3x3 blocks of a window go to the patches they belong to: ONE exchange through LDS per tile (nine phases of one float4
+// per cell), after which a thread holds the finished gradient of the 2x2 patch under its own cell.  A tile is the full plane
+// width (no halo columns: cells beyond the plane do not exist) by band x CPT rows, of which the outer two are halo (computed
+// twice).  Deterministic: fixed summation order, no atomics.
+constexpr int kWinFloats = 36, kWinBytes = kWinFloats * 4;      // 144 B: the 8 windows of a channel start in 8 different
+constexpr int kChanBytes = 8 * kWinBytes;                       // 16-byte bank groups (144 k mod 256 is a permutation)
+constexpr int kCellsMaxWidth = 64;
+
+template <int CPT>
+__global__ __launch_bounds__(kBlock) void conv5_mfm_pool2_backward_cells_kernel(const float *__restrict__ gy,
+                                                                                const uint8_t *__restrict__ idx,
+                                                                                const float *__restrict__ weight,
+                                                                                float *__restrict__ gx, int C, int H, int W,
+                                                                                int TR) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int Ho = H >> 1, Wo = W >> 1, Hp = (H + 1) >> 1, Wp = (W + 1) >> 1;
+    const int TRo = TR - 2, cells = TR * Wp;       // TR = (CPT * 256) / Wp tile rows; cell k * 256 + thread of the tile, row-major
+    char *tab = smem;
+    float4 *xch = reinterpret_cast<float4 *>(smem);        // [3][TR * Wp], over the tables once the channel loop is done
+    {
+        float4 *t4 = reinterpret_cast<float4 *>(tab);
+        for (int i = threadIdx.x; i < C * kChanBytes / 16; i += kBlock) t4[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        __syncthreads();
+        // one (channel, tap) per thread and trip, 32 lanes per channel (25 used): no integer division in the fill - at 25
+        // trips of ~70 instructions the first version's fill cost as much as the channel loop - and the weights of 8 trips are
+        // requested together (one L2 round trip per batch, not per trip)
+        for (int i0 = threadIdx.x; i0 < 2 * C * 32; i0 += 8 * kBlock) {
+            float w[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * kBlock, ch = i >> 5, tap = i & 31;
+                w[u] = (tap < KK && ch < 2 * C) ? weight[ch * KK + tap] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * kBlock, ch = i >> 5, tap = i & 31;
+                if (tap < KK && ch < 2 * C) {
+                    const int kh = (tap * 13) >> 6, kw = tap - kh * K;          // tap / 5 for tap < 25
+                    const int half = ch >= C, c = ch - half * C;
+                    float *win = reinterpret_cast<float *>(tab + c * kChanBytes + (half << 2) * kWinBytes) + kh * 6 + kw;
+                    // window[r][s] = tap (r - ph, s - pw) of the winner's filter: four copies, shifted by (ph, pw)
+                    win[0] = w[u];
+                    win[kWinFloats + 1] = w[u];
+                    win[2 * kWinFloats + 6] = w[u];
+                    win[3 * kWinFloats + 7] = w[u];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    const uint32_t plane = (uint32_t)(Ho * Wo);
+    const int64_t n = blockIdx.y;
+    const int t0 = blockIdx.x * TRo;    // first output patch row of the tile
+    const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(gy + n * (int64_t)C * plane), 0, (int)((uint32_t)C * plane * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ir = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t *>(idx + n * (int64_t)C * plane), 0, (int)((uint32_t)C * plane), 0x00020000);
+    uint32_t cell[CPT];          // cell index inside the plane; 0x20000000 = outside (reads 0 through the descriptors)
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+        const int id = k * kBlock + threadIdx.x, trow = id / Wp, col = id - trow * Wp, r = t0 - 1 + trow;
+        cell[k] = (id < cells && r >= 0 && r < Ho && col < Wo) ? (uint32_t)(r * Wo + col) : 0x20000000u;
+    }
+    f32x2 acc[CPT][18];
+#pragma unroll
+    for (int k = 0; k < CPT; ++k)
+#pragma unroll
+        for (int j = 0; j < 18; ++j) acc[k][j] = (f32x2){0.0f, 0.0f};
+
+    auto request = [&](uint32_t c, float (&g)[CPT], uint32_t (&code)[CPT]) {
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            code[k] = __builtin_amdgcn_raw_buffer_load_b8(ir, cell[k], c * plane, 0);
+            g[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gr, cell[k] * 4u, c * plane * 4u, 0));
+        }
+    };
+    auto accumulate = [&](int c, const float (&g)[CPT], const uint32_t (&code)[CPT]) {
+        const uint32_t cbase = (uint32_t)c * kChanBytes;
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            const float4 *w4 = reinterpret_cast<const float4 *>(tab + ((code[k] & 7u) * (uint32_t)kWinBytes + cbase));
+            const f32x2 gg = {g[k], g[k]};
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                const float4 a = w4[j];
+                acc[k][2 * j] = __builtin_elementwise_fma(gg, (f32x2){a.x, a.y}, acc[k][2 * j]);
+                acc[k][2 * j + 1] = __builtin_elementwise_fma(gg, (f32x2){a.z, a.w}, acc[k][2 * j + 1]);
+            }
+        }
+    };
+    // two channels per trip, two register sets: the next channel's (code, gradient) pairs are in flight under this one's products
+    float ga[CPT], gb[CPT];
+    uint32_t ca[CPT], cb[CPT];
+    request(0, ga, ca);
+    for (int c = 0; c < C; c += 2) {
+        const bool second = c + 1 < C;
+        request((uint32_t)(second ? c + 1 : c), gb, cb);
+        accumulate(c, ga, ca);
+        if (second) {
+            request((uint32_t)(c + 2 < C ? c + 2 : c), ga, ca);
+            accumulate(c + 1, gb, cb);
+        }
+    }
+    // the exchange: block (bh, bw) of a cell's window (rows 2 bh, 2 bh + 1; columns 2 bw, 2 bw + 1) belongs to patch
+    // (row + bh - 1, col + bw - 1)
+    float4 pacc[CPT];
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) pacc[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    // three phases (block rows), three float4 per cell and phase; the buffer lies over the window tables, which nobody reads
+    // any more (one tile per workgroup)
+    __syncthreads();
+#pragma unroll
+    for (int bh = 0; bh < 3; ++bh) {
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            const int id = k * kBlock + threadIdx.x;
+            if (id < cells) {
+#pragma unroll
+                for (int bw = 0; bw < 3; ++bw) {
+                    const f32x2 top = acc[k][(2 * bh) * 3 + bw], bot = acc[k][(2 * bh + 1) * 3 + bw];
+                    xch[bw * cells + id] = make_float4(top.x, top.y, bot.x, bot.y);
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            const int id = k * kBlock + threadIdx.x, trow = id / Wp, col = id - trow * Wp;
+            const int sr = trow + 1 - bh;          // source cell's tile row
+            if (id < cells && sr >= 0 && sr < TR) {
+#pragma unroll
+                for (int bw = 0; bw < 3; ++bw) {
+                    const int sc = col + 1 - bw;
+                    if (sc >= 0 && sc < Wp) {
+                        const float4 v = xch[bw * cells + sr * Wp + sc];
+                        pacc[k].x += v.x;
+                        pacc[k].y += v.y;
+                        pacc[k].z += v.z;
+                        pacc[k].w += v.w;
+                    }
+                }
+            }
+        }
+        if (bh < 2) __syncthreads();
+    }
+    float *xn = gx + n * (int64_t)H * W;
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+        const int id = k * kBlock + threadIdx.x, trow = id / Wp, col = id - trow * Wp, hp = t0 - 1 + trow;
+        if (id < cells && trow >= 1 && trow <= TR - 2 && hp < Hp) {
+            const int h0 = 2 * hp, w0 = 2 * col;
+            *reinterpret_cast<f32x2 *>(xn + (int64_t)h0 * W + w0) = (f32x2){pacc[k].x, pacc[k].y};
+            if (h0 + 1 < H) *reinterpret_cast<f32x2 *>(xn + (int64_t)(h0 + 1) * W + w0) = (f32x2){pacc[k].z, pacc[k].w};
+        }
+    }
+}
+
+// ADVSTEP_CONV0_BWD=gather keeps the patch-centric kernel (A/B measurements); read at every call
+inline bool conv0_cells_enabled() {
+    const char *e = getenv("ADVSTEP_CONV0_BWD");
+    return !(e && e[0] == 'g');
+}
+
 constexpr int64_t kMaxGridY = 65535;
 
 }  // namespace
@@ -273,7 +445,27 @@ int advstep_conv5_mfm_pool2_backward_f32(const float *gy, const uint8_t *idx, co
     if (C == 0 || H / 2 == 0 || W / 2 == 0)
         return hipMemsetAsync(gx, 0, (size_t)N * H * W * sizeof(float), st) == hipSuccess ? ADVSTEP_OK : ADVSTEP_ELAUNCH;
     CONV0_REQUIRE(gy && idx && weight);
-    const int64_t patches = ((H + 1) / 2) * ((W + 1) / 2);
+    const int64_t Wp = (W + 1) / 2, Hp = (H + 1) / 2;
+    if (conv0_cells_enabled() && Wp <= kCellsMaxWidth && W % 2 == 0 && (reinterpret_cast<uintptr_t>(gx) & 7u) == 0 &&
+        C * (H / 2) * (W / 2) < (1 << 27)) {
+        // cell-centric kernel: full-width tiles of TR = 3 * 256 / Wp rows (two of them halo), trimmed to what the tile count needs.
+        // (At LCNN's 202 x 40 cells and B = 128: 12 tiles of 17 + 2 rows per sample = 1 536 workgroups, exactly two rounds of the
+        // three workgroups a compute unit holds; 2 or 4 cells per thread were measured slower: 80 / 101 us against 70.)
+        constexpr int CPT = 3;
+        const int TRmax = (int)((int64_t)CPT * kBlock / Wp);
+        const int tiles = TRmax >= 3 ? (int)ceil_div(Hp, TRmax - 2) : 0;
+        const int TR = tiles ? (int)ceil_div(Hp, tiles) + 2 : 0;
+        const size_t xch = (size_t)3 * TR * Wp * sizeof(float4), tabs = (size_t)C * kChanBytes;
+        const size_t lds = xch > tabs ? xch : tabs;
+        if (tiles && lds <= 160 * 1024) {
+            (void)hipFuncSetAttribute((const void *)conv5_mfm_pool2_backward_cells_kernel<CPT>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(conv5_mfm_pool2_backward_cells_kernel<CPT>, dim3((unsigned)tiles, (unsigned)N), dim3(kBlock), lds, st,
+                               gy, idx, weight, gx, (int)C, (int)H, (int)W, TR);
+            return status_after_launch();
+        }
+    }
+    const int64_t patches = Hp * Wp;
     const dim3 grid((unsigned)ceil_div(patches, kBlock), (unsigned)N);
     const size_t lds = (size_t)(2 * (C * kTabWords + 4) + 8) * sizeof(float);
     hipLaunchKernelGGL(conv5_mfm_pool2_backward_kernel, grid, dim3(kBlock), lds, st, gy, idx, weight, gx, (int)C, (int)H,

@@ -66,8 +66,11 @@ int advstep_mfm_pool2_backward_f32(const float *gy, const uint8_t *idx, const fl
 int advstep_conv5_mfm_pool2_forward_f32(const float *x, const float *weight, const float *bias, float *y, uint8_t *idx,
                                         int64_t N, int64_t C, int64_t H, int64_t W, advstep_stream_t stream);
 
-/* Input gradient of the block above: gx (N, 1, H, W) from gy (N, C, H/2, W/2), idx and the weights (no atomics:
- * every 2x2 input patch gathers from the <= 9 pooled cells whose winner can reach it). */
+/* Input gradient of the block above: gx (N, 1, H, W) from gy (N, C, H/2, W/2), idx and the weights.  No atomics, fixed
+ * summation order.  Round 5: for even W <= 128 a thread owns a pooled CELL, accumulates over the channels what its winner
+ * sends to the 6x6 input window around it (the window, by channel and selection code, is read from a table in LDS) and
+ * the 3x3 blocks of the windows meet in one exchange per tile; other shapes - and ADVSTEP_CONV0_BWD=gather - take the
+ * kernel of rounds 1-4, where every 2x2 input patch gathers from the <= 9 pooled cells whose winner can reach it. */
 int advstep_conv5_mfm_pool2_backward_f32(const float *gy, const uint8_t *idx, const float *weight, float *gx, int64_t N,
                                          int64_t C, int64_t H, int64_t W, advstep_stream_t stream);
 
