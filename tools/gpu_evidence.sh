@@ -1,9 +1,9 @@
 #!/bin/bash
-# The evidence run of a round on the MI355X box (`gpurun --timeout 3000 -- 'bash tools/gpu_evidence.sh r04'`): the whole GPU test
+# The evidence run of a round on the MI355X box (`gpurun --timeout 3000 -- 'bash tools/gpu_evidence.sh r05'`): the whole GPU test
 # suite, the three bench lines, rocprofv3 kernel traces of configs[1] / configs[2] reduced to step summaries, the kernel
 # micro-benchmarks, the matrix-pipe PMC pass (counters in their own runs, --kernel-trace only) and the through-the-loop
 # probe.  Everything lands in gpurun_out/<tag>/ ; copy what is to be judged into profiles/ with the <tag>_ prefix.
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$R"
 O=$R/gpurun_out/$TAG
@@ -26,6 +26,7 @@ done
 python tools/kernel_microbench.py --json "$O/kernel_microbench.json" 2>&1 | grep -v amdgpu.ids > "$O/kernel_microbench.txt"
 python tools/model_kernel_bench.py --json "$O/model_kernel_microbench.json" 2>&1 | grep -v amdgpu.ids > "$O/model_kernel_microbench.txt"
 python tools/specrnet_conv_probe.py 128 2>&1 | grep -v amdgpu.ids > "$O/specrnet_conv_probe.txt"
+python tools/conv0_bwd_probe.py 2>&1 | grep -v amdgpu.ids > "$O/conv0_bwd_probe.txt"
 rm -rf /tmp/pmc1 /tmp/pmc2
 (cd /tmp && rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA --kernel-trace --output-format csv -d /tmp/pmc1 -- python "$R/tools/model_kernel_bench.py" --launches 3 > /dev/null 2>&1)
 (cd /tmp && rocprofv3 --pmc SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES --kernel-trace --output-format csv -d /tmp/pmc2 -- python "$R/tools/model_kernel_bench.py" --launches 3 > /dev/null 2>&1)
