@@ -183,6 +183,39 @@ def test_conv5_mfm_pool2_matches_float64_reference(L, cuda, shape, C, with_bias)
     assert close.float().mean().item() >= 0.999       # MIOpen's own rounding may flip a near-tie winner
 
 
+@pytest.mark.parametrize("shape,C", [((4, 1, 404, 80), 32), ((3, 1, 9, 16), 8), ((2, 1, 101, 20), 3), ((5, 1, 38, 128), 32),
+                                     ((2, 1, 7, 2), 32), ((1, 1, 64, 66), 96)])
+def test_conv5_backward_cell_centric_equals_the_gather(L, cuda, monkeypatch, shape, C):
+    """Round 5: the first block's input gradient with a thread per pooled CELL (window table in LDS, one exchange per tile) against
+    the patch-centric gather of rounds 1-4 on the same (gradient, selection bytes, weights): the same sums in another order - equal
+    to float rounding, both finite, the tile seams (rows 17 / 34 / ... of the pooled plane at width 40), the trailing odd row and
+    the narrow / wide / many-channel shapes included.  ADVSTEP_CONV0_BWD=gather selects the old kernel."""
+    g = torch.Generator().manual_seed(shape[2] * 7 + shape[3] + C)
+    x = torch.randn(shape, generator=g).to(cuda)
+    weight = (torch.randn(2 * C, 1, 5, 5, generator=g) * 0.3).to(cuda)
+    bias = torch.randn(2 * C, generator=g).to(cuda)
+    outs = {}
+    for mode in ("cells", "gather"):
+        monkeypatch.setenv("ADVSTEP_CONV0_BWD", mode)
+        xa = x.clone().requires_grad_(True)
+        y = L.conv5_mfm_pool2(xa, weight, bias)
+        gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(5)).to(cuda)
+        (outs[mode],) = torch.autograd.grad(y, xa, gy)
+    scale = outs["gather"].abs().max().item()
+    assert torch.isfinite(outs["cells"]).all()
+    assert (outs["cells"] - outs["gather"]).abs().max().item() <= 4e-6 * max(scale, 1.0)
+    # a pooled gradient that is zero except ONE cell next to a tile seam: its 5x5 footprint must come out whole
+    if shape[2] >= 40:
+        gy1 = torch.zeros_like(gy)
+        gy1[0, 0, 17, min(3, gy.shape[3] - 1)] = 1.0
+        res = {}
+        for mode in ("cells", "gather"):
+            monkeypatch.setenv("ADVSTEP_CONV0_BWD", mode)
+            xa = x.clone().requires_grad_(True)
+            (res[mode],) = torch.autograd.grad(L.conv5_mfm_pool2(xa, weight, bias), xa, gy1)
+        assert torch.equal(res["cells"], res["gather"]) and int((res["cells"] != 0).sum()) == 25
+
+
 @pytest.mark.parametrize("kind", ["conv5", "conv3x3"])
 def test_fused_conv_pool_selection_with_nans_ties_and_infinities(L, cuda, kind):
     """The pooling epilogues of the convolution kernels take a short path when no candidate in a wave is NaN and the
