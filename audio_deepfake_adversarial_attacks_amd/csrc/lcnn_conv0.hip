@@ -458,8 +458,9 @@ int advstep_conv5_mfm_pool2_backward_f32(const float *gy, const uint8_t *idx, co
         const size_t xch = (size_t)3 * TR * Wp * sizeof(float4), tabs = (size_t)C * kChanBytes;
         const size_t lds = xch > tabs ? xch : tabs;
         if (tiles && lds <= 160 * 1024) {
+            // (the same value at every call: two host threads launching different channel counts cannot undercut each other)
             (void)hipFuncSetAttribute((const void *)conv5_mfm_pool2_backward_cells_kernel<CPT>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             hipLaunchKernelGGL(conv5_mfm_pool2_backward_cells_kernel<CPT>, dim3((unsigned)tiles, (unsigned)N), dim3(kBlock), lds, st,
                                gy, idx, weight, gx, (int)C, (int)H, (int)W, TR);
             return status_after_launch();
