@@ -9,10 +9,12 @@
 // the <= 9 pooled cells whose winner can reach it, straight from gy + the selection bytes.
 //   forward : thread = one pooled output position, 6x6 input window in registers, loop over the C channel
 //             pairs with the 2 x 25 taps + 2 biases as wave-uniform (scalar) operands: 100 v_pk_fma_f32 per pair.
-//   backward: thread = one 2x2 input patch; taps staged in LDS as zero-bordered tables (branch-free per-lane lookup,
-//             start offset by selection code from an 8-entry LDS table); gradients / codes through buffer descriptors
-//             with scalar channel offsets; no atomics.
-// VALU-bound (13.2 GFLOP at B = 128), not HBM-bound; MFMA does not apply (K = 25, one input channel).
+//   backward: (round 5, even widths up to 128) thread = one pooled CELL: its winner's 6x6 window of taps comes out of an LDS
+//             table indexed by (channel, selection code), accumulates over the channels in registers, and the windows' 3x3
+//             blocks meet in one exchange per tile - 9 LDS reads + 2 loads per cell and channel; LDS-bound (the useful
+//             arithmetic is an eighth of the forward's).  Other shapes: thread = one 2x2 input patch gathering from its 9
+//             pooled cells (rounds 1-4: 27 LDS reads + 18 loads per patch and channel).  No atomics either way.
+// Forward: VALU-bound (13.2 GFLOP at B = 128), not HBM-bound; MFMA does not apply (K = 25, one input channel).
 // Accumulation order is fixed (taps row-major, then channels), fma contraction allowed: deterministic, and within
 // float rounding of any other convolution implementation (MIOpen's differs in the last bits as well).
 
