@@ -774,8 +774,11 @@ constexpr int kBwdFramesPerBlock = kWavesPerBlock * kBwdGroupsPerWave * kGroup; 
 // gradients meet in its own LDS block, every sample they touch is summed in frame order, and the <= 2 waves that share a sample
 // (4 hops = 640 samples of advance against 352 of overlap) combine with one float atomic each onto the zeroed dx — two
 // operands, commutative, so bit-reproducible; no workgroup barrier after the tables are staged.
+// Waves per SIMD the register allocator is asked to fit (and the dispatcher allowed to place): 4 = what the 40 KB of LDS per
+// workgroup admit (four workgroups per CU).  Round 4 shipped this kernel pinned at 2 - a leftover of a build that needed more than
+// 128 registers - although it allocates 118: 101.7 us pinned at 2, 98.2 at 3, 78.1 at 4 (151.7 at 1), round 5.
 #ifndef STFT_BWD_WAVES
-#define STFT_BWD_WAVES 2
+#define STFT_BWD_WAVES 4
 #endif
 template <int SPAN_CAP>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(STFT_BWD_WAVES, STFT_BWD_WAVES)))
