@@ -146,7 +146,9 @@ class _Conv5MfmPool2(torch.autograd.Function):
         N, C, H, W = ctx.shape
         gy = gy.contiguous()
         gx = torch.empty((N, 1, H, W), dtype=gy.dtype, device=gy.device)
-        with _Launch("conv5_mfm_pool2_backward", gy.device, work=100.0 * N * C * H * W, tensors=(gy, idx, gx)):
+        # work = the multiply-adds the gradient needs: 25 taps per pooled output and channel (2 x 25 x N C H/2 W/2) - an eighth of
+        # the dense transposed convolution rounds 1-4 priced here, which no kernel of this library executes
+        with _Launch("conv5_mfm_pool2_backward", gy.device, work=12.5 * N * C * H * W, tensors=(gy, idx, gx)):
             st = _lib.load().advstep_conv5_mfm_pool2_backward_f32(gy.data_ptr(), idx.data_ptr(), weight.data_ptr(),
                                                                   gx.data_ptr(), N, C, H, W, _stream(gy.device))
         _lib.check(st, "advstep_conv5_mfm_pool2_backward_f32")

@@ -514,7 +514,9 @@ def main():
                          "empty_event_pair_ms), i.e. kernel time; shares are of the timed region's ms_per_step (the bracketed "
                          "step itself runs `step_ms_profiled`: ~1 200 event pairs cost it ~10 %)",
                 "conventions": "mfma: Winograd products through the matrix cores (direct count / 2.25); valu: 2 flop per "
-                               "multiply-add of the direct convolution; hbm: bytes of the operands a launch reads or writes once",
+                               "multiply-add of the direct convolution (the first block's input gradient: of the 25 taps per pooled "
+                               "output and channel it needs, an eighth of a dense transposed convolution; that kernel is bound by its "
+                               "LDS reads, DESIGN.md 4k); hbm: bytes of the operands a launch reads or writes once",
                 "rows": rows}
             # (2c) the loop the user runs: generate_attacks over a synthetic dataset with its DataLoader workers, staging stream and
             #      hipGraph replay — HIP events after batch 4 and after the last batch, ONE host synchronisation at the end
