@@ -540,7 +540,10 @@ __global__ __launch_bounds__(kThreads) void stft_bands_backward_kernel(const flo
 }
 
 // ---- round 4: the LFCC pair on the register-resident transform -----------------------------------------------------------
-constexpr int kGroupsPerWave = 2;                                                   // 4-frame groups a wave works through
+#ifndef STFT_FWD_GROUPS
+#define STFT_FWD_GROUPS 2
+#endif
+constexpr int kGroupsPerWave = STFT_FWD_GROUPS;                                                   // 4-frame groups a wave works through
 constexpr int kBandsFramesPerBlock = kWavesPerBlock * kGroupsPerWave * kGroup;     // 32 consecutive frames per workgroup
 
 struct LdsReg {
@@ -767,7 +770,10 @@ struct LdsRegBwd {
     int32_t fbt_start[kBins + 1];
 };   // 40 104 B with SPAN_CAP = 2: four workgroups per CU (a fifth array — the band gradients had one — makes it three)
 
-constexpr int kBwdGroupsPerWave = 4;                                                    // 16 consecutive frames per wave
+#ifndef STFT_BWD_GROUPS
+#define STFT_BWD_GROUPS 4
+#endif
+constexpr int kBwdGroupsPerWave = STFT_BWD_GROUPS;                                                    // 16 consecutive frames per wave
 constexpr int kBwdFramesPerBlock = kWavesPerBlock * kBwdGroupsPerWave * kGroup;        // 64 per workgroup
 
 // grid (ceil(NF / 64), B).  A wave owns 4 CONSECUTIVE frames at a time and overlap-adds them itself: its 4 windowed frame
