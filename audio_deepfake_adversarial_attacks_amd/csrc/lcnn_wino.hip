@@ -251,6 +251,9 @@ struct GenArgs {
     float slope;
     int xcd;          // 1: workgroups b, b + 8, b + 16, ... (one XCD, one L2) take the slices of the same tile ranges
     int few;          // EPI 7: channels of x2 (1 or 2) whose 1x1 convolution is added in the epilogue
+    int halves;       // NT == 1, round 5: the launch's "slices" are the two 16-row HALVES of slice `slice0` (rows 16 h .. 16 h + 15:
+                      // component h of the A pairs) - a one-slice layer on a small plane (LCNN's 64 -> 32 input gradient at 50 x 10:
+                      // 1 000 tile groups, 125 workgroups) then fills the chip with 250 workgroups of half the matrix instructions
 };
 
 // WODD (SRC 0): the plane width is odd, so the last tile of a row has no second column and its pair load's second element must
@@ -272,7 +275,8 @@ __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restri
         slice_i = w % slices;
         range = x * (ranges >> 3) + w / slices;
     }
-    const int slice = slice0 + slice_i;
+    const int half = (NT == 1 && ga.halves) ? slice_i : 0;
+    const int slice = (NT == 1 && ga.halves) ? slice0 : slice0 + slice_i;
     const int chunks = (K + kChunkCin - 1) / kChunkCin, steps = K / 4;
     const float *Usl = U + (int64_t)slice * chunks * kChunkFloats;
     // STREAM with a compact source: a chunk goes global -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers, nothing
@@ -475,8 +479,13 @@ __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restri
         auto step = [&](const Patch &patch, int s_idx, const float *us, auto first) {
             f32x2 a[8][2];
             auto request = [&](int grp) {
-                a[grp][0] = *reinterpret_cast<const f32x2 *>(us + (2 * grp) * (kChunkCin * 32));
-                a[grp][1] = *reinterpret_cast<const f32x2 *>(us + (2 * grp + 1) * (kChunkCin * 32));
+                if constexpr (NT == 1) {      // one accumulator tile: only this half's component of the pair (4-byte reads)
+                    a[grp][0].x = us[(2 * grp) * (kChunkCin * 32) + half];
+                    a[grp][1].x = us[(2 * grp + 1) * (kChunkCin * 32) + half];
+                } else {
+                    a[grp][0] = *reinterpret_cast<const f32x2 *>(us + (2 * grp) * (kChunkCin * 32));
+                    a[grp][1] = *reinterpret_cast<const f32x2 *>(us + (2 * grp + 1) * (kChunkCin * 32));
+                }
             };
             request(0);
             request(1);
@@ -615,7 +624,7 @@ __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restri
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int m = 0; m < NT; ++m) {
-                    const int ch = slice * 32 + m * 16 + 4 * g + r;
+                    const int ch = slice * 32 + (m + half) * 16 + 4 * g + r;
                     const bool live = valid && ch < Cout;
                     const float *hp = bn_mean + (((size_t)n * Cout + (live ? ch : 0)) * H + 2 * th) * W + 2 * tw;
                     const bool h1 = 2 * th + 1 < H, w1 = 2 * tw + 1 < W;
@@ -645,7 +654,7 @@ __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restri
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int m = 0; m < NT; ++m) {
-                    const int ch = slice * 32 + m * 16 + 4 * g + r;
+                    const int ch = slice * 32 + (m + half) * 16 + 4 * g + r;
                     const bool live = valid && ch < Cout;
                     hb6[r][m] = live ? idx[(((size_t)n * Cout + ch) * TH + th) * TW + tw] : 0u;
                 }
@@ -725,7 +734,7 @@ __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restri
             } else if (EPI == 4 || EPI == 7) {
 #pragma unroll
                 for (int m = 0; m < NT; ++m) {
-                    const int ch = slice * 32 + m * 16 + 4 * g + r;
+                    const int ch = slice * 32 + (m + half) * 16 + 4 * g + r;
                     const bool live = ch < Cout;
                     if (EPI == 7) {
                         const float w0 = few_w[(m * 16 + 4 * g + r) * 2], w1 = few_w[(m * 16 + 4 * g + r) * 2 + 1];
@@ -749,7 +758,7 @@ __global__ __launch_bounds__(kThreads) void wino3x3_kernel(const float *__restri
             } else {
 #pragma unroll
                 for (int m = 0; m < NT; ++m) {
-                    const int ch = slice * 32 + m * 16 + 4 * g + r;
+                    const int ch = slice * 32 + (m + half) * 16 + 4 * g + r;
                     if (!(valid && ch < Cout)) continue;
                     if (EPI == 3) {
                         uint32_t bits = 0;
@@ -823,7 +832,7 @@ inline bool half_slice_enabled() {
 template <int EPI, int SRC, bool GEN = false>
 int launch_wino(const float *x, const uint8_t *xsel, const float *U, const float *bias, const float *bn_mean,
                 const float *bn_invstd, float *y, uint8_t *idx, int64_t N, int64_t K, int64_t H, int64_t W, int64_t Cout,
-                int slices, hipStream_t st, GenArgs ga = GenArgs{nullptr, 0, 0, 1.0f, 0, 0}) {
+                int slices, hipStream_t st, GenArgs ga = GenArgs{nullptr, 0, 0, 1.0f, 0, 0, 0}) {
     const int cus = 256;
     const int chunks = (int)ceil_div(K, kChunkCin);
     const bool stream = chunks > kMaxResident;
@@ -858,6 +867,17 @@ int launch_wino(const float *x, const uint8_t *xsel, const float *U, const float
             full = slices - 1;
             if (stream) wodd ? go(wino3x3_kernel<EPI, true, SRC, 1, GEN, SRC == 0>, 1, slices - 1) : go(wino3x3_kernel<EPI, true, SRC, 1, GEN>, 1, slices - 1);
             else wodd ? go(wino3x3_kernel<EPI, false, SRC, 1, GEN, SRC == 0>, 1, slices - 1) : go(wino3x3_kernel<EPI, false, SRC, 1, GEN>, 1, slices - 1);
+        }
+    }
+    if constexpr (EPI == 0 && SRC == 1 && !GEN) {
+        // a ONE-slice layer whose tile groups do not fill the chip's 2 048 wave slots even once: the slice as its two 16-row
+        // halves, one accumulator tile each - twice the workgroups, half the matrix instructions per wave (the patch loads and
+        // input transforms are done twice, on compute units that would have idled).  ADVSTEP_WINO_HALVES=0: one launch (A/B)
+        const char *eh = getenv("ADVSTEP_WINO_HALVES");
+        if (full == 1 && slices == 1 && Cout == 32 && groups <= (int64_t)cus * kWaves / 2 && !(eh && eh[0] == '0')) {
+            ga.halves = 1;
+            stream ? go(wino3x3_kernel<EPI, true, SRC, 1, GEN>, 2, 0) : go(wino3x3_kernel<EPI, false, SRC, 1, GEN>, 2, 0);
+            return status_after_launch();
         }
     }
     if (full > 0) {
@@ -999,7 +1019,7 @@ int advstep_resconv_forward_act_f32(const float *x1, const float *x2, const floa
     if (const int st = resconv_check(x1, x2, U, y, N, K1, K2, rows, H, W)) return st;
     const int64_t K = (K1 + K2 <= 8) ? 8 : ceil_div(K1 + K2, 4) * 4;      // at least two k-steps; an odd count is fine
     return launch_wino<3, 0, true>(x1, nullptr, U, shift, nullptr, nullptr, y, act, N, K, H, W, rows, (int)ceil_div(rows, 32),
-                                   as_stream(stream), GenArgs{x2, (int)K1, (int)(K1 + K2), slope, 0, 0});
+                                   as_stream(stream), GenArgs{x2, (int)K1, (int)(K1 + K2), slope, 0, 0, 0});
 }
 
 int advstep_resconv_forward_f32(const float *x1, const float *x2, const float *U, const float *shift, float slope, float *y,
@@ -1017,7 +1037,7 @@ int advstep_resconv_pool2_forward_f32(const float *x1, const float *x2, const fl
     if (const int st = resconv_check(x1, x2, U, y, N, K1, K2, rows, H, W)) return st;
     const int64_t K = (K1 + K2 <= 8) ? 8 : ceil_div(K1 + K2, 4) * 4;      // at least two k-steps; an odd count is fine
     return launch_wino<4, 0, true>(x1, nullptr, U, bias, nullptr, nullptr, y, sel, N, K, H, W, rows, (int)ceil_div(rows, 32),
-                                   as_stream(stream), GenArgs{x2, (int)K1, (int)(K1 + K2), 1.0f, 0, 0});
+                                   as_stream(stream), GenArgs{x2, (int)K1, (int)(K1 + K2), 1.0f, 0, 0, 0});
 }
 
 static int pooled_grad(const float *gy, const uint8_t *sel, const float *U, const float *h, const uint8_t *act, float slope,
@@ -1032,7 +1052,7 @@ static int pooled_grad(const float *gy, const uint8_t *sel, const float *U, cons
     WINO_REQUIRE((uint64_t)N * K * (H / 2) * (W / 2) < (1ull << 29) && (uint64_t)N * rows * H * W * 4 < (1ull << 33) &&
                  (uint64_t)N * ((H + 1) / 2) * ((W + 1) / 2) < (1ull << 31));
     const int64_t Kp = K <= 8 ? 8 : ceil_div(K, 4) * 4;
-    const GenArgs ga{nullptr, (int)K, (int)K, slope, 0, 0};
+    const GenArgs ga{nullptr, (int)K, (int)K, slope, 0, 0, 0};
     if (act)
         return launch_wino<6, 2, true>(gy, sel, U, nullptr, nullptr, nullptr, g, const_cast<uint8_t *>(act), N, Kp, H, W, rows,
                                        (int)ceil_div(rows, 32), as_stream(stream), ga);
@@ -1052,7 +1072,7 @@ int advstep_resconv_pool2_forward_few_f32(const float *x1, const float *x2, cons
     if (const int st = resconv_check(x1, nullptr, U, y, N, K1, 0, rows, H, W)) return st;
     const int64_t K = K1 <= 8 ? 8 : ceil_div(K1, 4) * 4;
     return launch_wino<7, 0, true>(x1, nullptr, U, bias, wd, nullptr, y, sel, N, K, H, W, rows, (int)ceil_div(rows, 32),
-                                   as_stream(stream), GenArgs{x2, (int)K1, (int)K1, 1.0f, 0, (int)K2});
+                                   as_stream(stream), GenArgs{x2, (int)K1, (int)K1, 1.0f, 0, (int)K2, 0});
 }
 
 int advstep_resconv_pooled_grad_f32(const float *gy, const uint8_t *sel, const float *U, const float *h, float slope, float *g,
