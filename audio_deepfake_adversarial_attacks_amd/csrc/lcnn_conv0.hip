@@ -19,6 +19,7 @@
 // float rounding of any other convolution implementation (MIOpen's differs in the last bits as well).
 
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -459,10 +460,24 @@ int advstep_conv5_mfm_pool2_backward_f32(const float *gy, const uint8_t *idx, co
         const int TR = tiles ? (int)ceil_div(Hp, tiles) + 2 : 0;
         const size_t xch = (size_t)3 * TR * Wp * sizeof(float4), tabs = (size_t)C * kChanBytes;
         const size_t lds = xch > tabs ? xch : tabs;
-        if (tiles && lds <= 160 * 1024) {
-            // (the same value at every call: two host threads launching different channel counts cannot undercut each other)
-            (void)hipFuncSetAttribute((const void *)conv5_mfm_pool2_backward_cells_kernel<CPT>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        // The opt-in to more than 64 KB of dynamic LDS is made once per device (function attributes are per device) and its
+        // RESULT kept: 160 KB when the runtime granted it, else the 64 KB every kernel has.  Always the same value, so two
+        // host threads launching different channel counts cannot undercut each other.  Shapes whose tables need more than
+        // the limit fall through to the gather kernel below (< 38 KB), which handled them in rounds 1-4 (a refused
+        // attribute used to end in ADVSTEP_ELAUNCH, and the attribute call ran at every launch).
+        static std::atomic<int> granted_kb[64];                       // 0 = not asked yet
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::atomic<int> &slot = granted_kb[dev & 63];
+        int kb = slot.load(std::memory_order_relaxed);
+        if (kb == 0) {
+            kb = hipFuncSetAttribute((const void *)conv5_mfm_pool2_backward_cells_kernel<CPT>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess ? 160 : 64;
+            (void)hipGetLastError();                                  // a refusal is handled here, not reported by the launch below
+            slot.store(kb, std::memory_order_relaxed);
+        }
+        const size_t cells_lds_limit = (size_t)kb * 1024;
+        if (tiles && lds <= cells_lds_limit) {
             hipLaunchKernelGGL(conv5_mfm_pool2_backward_cells_kernel<CPT>, dim3((unsigned)tiles, (unsigned)N), dim3(kBlock), lds, st,
                                gy, idx, weight, gx, (int)C, (int)H, (int)W, TR);
             return status_after_launch();

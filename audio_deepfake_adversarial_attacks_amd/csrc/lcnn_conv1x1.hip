@@ -12,7 +12,13 @@
 //     memory — 128 B contiguous per half wave — and live in Cin/2 registers;
 //   * W is staged once per workgroup in LDS with an odd row pitch (conflict-free fragment reads);
 //   * rows of the two channel halves land in the SAME (lane, register) slot of two accumulators, so the max-feature-map
-//     is a register-to-register max; bias, the eval BatchNorm and the selection bit (wave ballot) are the epilogue;
+//     is a register-to-register max; bias, the eval BatchNorm and the selection bit are the epilogue;
+//   * selection bits (round 6): a lane keeps the bits of ITS OWN channels - bit 16 t + r for accumulator register r of
+//     channel tile t - and stores them once per pixel tile: [n][pixel tile][pixel % 32][lane half] uint16 (C <= 32) or
+//     uint32, 128 / 256 contiguous bytes per wave.  Rounds 1-5 wrote one ballot word per channel and 32-pixel tile
+//     ([n][c][p / 32]): 16 four-byte stores per wave to 32 different rows, each a partial line that the 8 XCDs' L2s
+//     wrote back separately - 10 us of the first block's 67 (profiles/r06_conv1x1_experiments.txt); the backward read
+//     them with one broadcast load per k-step and now reads ONE word per lane;
 //   * backward is the transposed GEMM over K = 2C with the max-feature-map backward applied while the B fragment is
 //     formed (the gradient goes to the selected half's weight row), so the 2C-channel gradient never exists either.
 // HBM traffic: Cin*4 B in, C*4 B + 1 bit out per pixel.  Accumulator map (32x32 tile, 16 registers): col = lane & 31,
@@ -38,6 +44,14 @@ inline int status_after_launch() { return hipGetLastError() == hipSuccess ? ADVS
 __device__ __forceinline__ bool mfm_takes_b(float a, float b) { return !(a != a) && !(a >= b); }
 __device__ __forceinline__ int mfma_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
+// Selection format.  Channel c of a pixel lives in the forward lane half h = (c >> 2) & 1 of that pixel, bit
+// 16 (c >> 5) + (c & 3) + 4 ((c & 31) >> 3) of that lane's mask (= 16 t + r for accumulator register r of tile t; in MODE 2's
+// shared last tile r < 8).  Masks are uint16 for C <= 32 and uint32 above; the two halves of a pixel are adjacent.
+// The backward's k-step s feeds channel c = 2 s + lk: h = (s >> 1) & 1 and the bit is sel_bit(s) + lk - all but lk known per step.
+__host__ __device__ constexpr int sel_bit(int s) { return 16 * (s >> 4) + 2 * (s & 1) + 4 * ((s >> 2) & 3); }
+__host__ __device__ constexpr int sel_half(int s) { return (s >> 1) & 1; }
+inline int64_t sel_mask_bytes(int64_t C) { return C <= 32 ? 2 : 4; }
+
 // grid (ceil(P / 128), N).  TILES = ceil(C / 32) channel tiles per half.
 // LDS: w_s[2 * TILES * 32][CIN + 1]; rows [0, 32 TILES) = first half (zero beyond C), rows [32 TILES, 64 TILES) = second.
 // MODE 1: C == 32 TILES (no accumulator row beyond C): the row-liveness branches of the epilogue compile away.
@@ -51,10 +65,11 @@ __global__ __launch_bounds__(kBlock) void conv1x1_mfm_forward_kernel(const float
                                                                      const float *__restrict__ bias,
                                                                      const float *__restrict__ bn_mean,
                                                                      const float *__restrict__ bn_invstd,
-                                                                     float *__restrict__ y, uint32_t *__restrict__ sel,
+                                                                     float *__restrict__ y, uint8_t *__restrict__ sel,
                                                                      int C, int64_t P, int64_t PW) {
     extern __shared__ __attribute__((aligned(16))) float w_s[];
     constexpr int CP = TILES * 32, PITCH = CIN + 1;
+    constexpr uint32_t SELB = TILES == 1 ? 2u : 4u;        // bytes of a lane's mask (the host picks TILES = 1 iff C <= 32)
     float *par_s = w_s + 2 * CP * PITCH;  // [4][CP]: bias of half a, bias of half b, BN mean, BN invstd
     // weights -> LDS in batches of kWBatch loads per thread, all issued before the first is used (a load -> LDS write
     // loop pays one L2 latency per iteration: 24-32 iterations cost more than the tile's matrix instructions)
@@ -98,17 +113,19 @@ __global__ __launch_bounds__(kBlock) void conv1x1_mfm_forward_kernel(const float
     // (row 4 lk or lk, pixel p — fixed for the whole kernel) and a wave-uniform row offset in an SGPR.  An out-of-range
     // pixel gets an out-of-range lane offset (loads return 0, stores are dropped).  (64-bit pointer arithmetic per access cost ~300 of this kernel's ~570 VALU
     // instructions, and VALU time adds to matrix time on this part: DESIGN.md section 4f.)
-    const uint32_t Pb = (uint32_t)P * 4u, PWb = (uint32_t)PW * 4u;
+    const uint32_t Pb = (uint32_t)P * 4u;
     const __amdgpu_buffer_rsrc_t xr =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x + n * CIN * P), 0, (int)(CIN * Pb), 0x00020000);
     const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(y + n * (int64_t)C * P, 0, (int)(C * Pb), 0x00020000);
     const __amdgpu_buffer_rsrc_t sr =
-        __builtin_amdgcn_make_buffer_rsrc(sel + n * (int64_t)C * PW, 0, (int)(C * PWb), 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(sel + n * PW * (int64_t)(64u * SELB), 0, (int)((uint32_t)PW * 64u * SELB), 0x00020000);
     constexpr uint32_t kOut = 0x80000000u;
     const uint32_t pb = (uint32_t)p * 4u;
     const uint32_t x_off = valid ? (uint32_t)lk * Pb + pb : kOut;                          // row lk, pixel p
     const uint32_t y_off = valid ? 4u * (uint32_t)lk * Pb + pb : kOut;                     // row 4 lk, pixel p
-    const uint32_t s_off = li == 0 ? 4u * (uint32_t)lk * PWb + (uint32_t)(p >> 5) * 4u : kOut;  // one lane per half stores
+    const uint32_t s_off = valid ? (uint32_t)(2 * li + lk) * SELB : kOut;                  // this lane's mask inside the wave's tile
+    const uint32_t s_tile = (uint32_t)(wave_p0 >> 5) * 64u * SELB;
+    uint32_t mask = 0;                                                                     // bit 16 t + r: the second half won
     float xb[CIN / 2];
 #pragma unroll
     for (int s = 0; s < CIN / 2; ++s)
@@ -133,19 +150,15 @@ __global__ __launch_bounds__(kBlock) void conv1x1_mfm_forward_kernel(const float
             const int c = c_lo + 4 * lk;
             const float va = acc_a[r] + par_s[c], vb = acc_b[r] + par_s[CP + c];
             const bool tb = mfm_takes_b(va, vb);
-            // one ballot, two 32-bit selection words
-            const unsigned long long word = __ballot(valid && tb);
+            mask |= tb ? (1u << (16 * t + r)) : 0u;      // (rows >= C: zero weights and parameters, the bit stays 0)
             const float v = ((tb ? vb : va) - par_s[2 * CP + c]) * par_s[3 * CP + c];
             // the descriptor's range check covers the lane offset only, NOT the scalar row offset: rows >= C must not be
             // stored.  Wave-uniform cases first (C a multiple of 8 never takes the per-lane one).
-            const uint32_t sw = lk ? (uint32_t)(word >> 32) : (uint32_t)word;
             if (FULL || c_lo + 4 < C) {
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), yr, y_off, (uint32_t)c_lo * Pb, 0);
-                __builtin_amdgcn_raw_buffer_store_b32(sw, sr, s_off, (uint32_t)c_lo * PWb, 0);
             } else if (c_lo < C) {
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), yr, lk ? kOut : y_off,
                                                       (uint32_t)c_lo * Pb, 0);
-                __builtin_amdgcn_raw_buffer_store_b32(sw, sr, lk ? kOut : s_off, (uint32_t)c_lo * PWb, 0);
             }
         }
     }
@@ -161,13 +174,14 @@ __global__ __launch_bounds__(kBlock) void conv1x1_mfm_forward_kernel(const float
             const int c = c_lo + 4 * lk;
             const float va = acc[r] + par_s[c], vb = acc[r + 8] + par_s[CP + c];
             const bool tb = mfm_takes_b(va, vb);
-            const unsigned long long word = __ballot(valid && tb);
+            mask |= tb ? (1u << (16 * t + r)) : 0u;
             const float v = ((tb ? vb : va) - par_s[2 * CP + c]) * par_s[3 * CP + c];
-            const uint32_t sw = lk ? (uint32_t)(word >> 32) : (uint32_t)word;
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), yr, y_off, (uint32_t)c_lo * Pb, 0);
-            __builtin_amdgcn_raw_buffer_store_b32(sw, sr, s_off, (uint32_t)c_lo * PWb, 0);
         }
     }
+    // one selection store per wave: 64 lanes x SELB contiguous bytes
+    if constexpr (SELB == 2) __builtin_amdgcn_raw_buffer_store_b16((uint16_t)mask, sr, s_off, s_tile, 0);
+    else __builtin_amdgcn_raw_buffer_store_b32(mask, sr, s_off, s_tile, 0);
 }
 
 // grid (ceil(P / 128), N).  MT = ceil(CIN / 32) output tiles (input channels).  LDS: w_s[2C][32 MT + 1], columns >= CIN zero.
@@ -175,7 +189,7 @@ __global__ __launch_bounds__(kBlock) void conv1x1_mfm_forward_kernel(const float
 // before the first MFMA; STEPS = 0 is the generic runtime loop.
 template <int CIN, int MT, int STEPS>
 __global__ __launch_bounds__(kBlock) void conv1x1_mfm_backward_kernel(const float *__restrict__ gy,
-                                                                      const uint32_t *__restrict__ sel,
+                                                                      const uint8_t *__restrict__ sel,
                                                                       const float *__restrict__ weight,
                                                                       const float *__restrict__ gscale,
                                                                       float *__restrict__ gx, int C, int64_t P,
@@ -218,17 +232,31 @@ __global__ __launch_bounds__(kBlock) void conv1x1_mfm_backward_kernel(const floa
     if ((int64_t)blockIdx.x * kPixPerBlock + wave * 32 >= P) return;
 
     // 32-bit, mostly scalar addressing as in the forward kernel
-    const uint32_t Pb = (uint32_t)P * 4u, PWb = (uint32_t)PW * 4u;
+    const uint32_t Pb = (uint32_t)P * 4u;
+    const bool wide = C > 32;                    // uint32 masks (the forward's TILES = 2), else uint16
+    const uint32_t pairb = wide ? 8u : 4u;       // bytes of a pixel's two masks
     const __amdgpu_buffer_rsrc_t gr =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(gy + n * (int64_t)C * P), 0, (int)(C * Pb), 0x00020000);
-    const __amdgpu_buffer_rsrc_t sr =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(sel + n * (int64_t)C * PW), 0, (int)(C * PWb), 0x00020000);
+    const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t *>(sel + n * PW * (int64_t)(32u * pairb)), 0, (int)((uint32_t)PW * 32u * pairb), 0x00020000);
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(gx + n * CIN * P, 0, (int)(CIN * Pb), 0x00020000);
     constexpr uint32_t kOut = 0x80000000u;
     const uint32_t pb = (uint32_t)p * 4u;
     const uint32_t g_off = valid ? (uint32_t)lk * Pb + pb : kOut;                              // row lk, pixel p
-    const uint32_t s_off = valid ? (uint32_t)lk * PWb + (uint32_t)(p >> 5) * 4u : kOut;         // row lk, word of p
     const uint32_t x_off = valid ? 4u * (uint32_t)lk * Pb + pb : kOut;                         // row 4 lk, pixel p
+    // the pixel's two masks (forward lane halves 0 and 1) in ONE load per lane; m[h] >> lk puts the bit of channel 2 s + lk
+    // at sel_bit(s).  (Rounds 1-5: one broadcast word per k-step.)
+    const uint32_t s_off = valid ? (uint32_t)li * pairb : kOut;
+    const uint32_t s_tile = (uint32_t)(((int64_t)blockIdx.x * kPixPerBlock + wave * 32) >> 5) * 32u * pairb;
+    uint32_t m[2];
+    if (wide) {
+        m[0] = __builtin_amdgcn_raw_buffer_load_b32(sr, s_off, s_tile, 0) >> lk;
+        m[1] = __builtin_amdgcn_raw_buffer_load_b32(sr, s_off + (valid ? 4u : 0u), s_tile, 0) >> lk;
+    } else {
+        const uint32_t both = __builtin_amdgcn_raw_buffer_load_b32(sr, s_off, s_tile, 0);
+        m[0] = (both & 0xffffu) >> lk;
+        m[1] = (both >> 16) >> lk;
+    }
     f32x16 acc[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) acc[m] = (f32x16){0};
@@ -236,17 +264,14 @@ __global__ __launch_bounds__(kBlock) void conv1x1_mfm_backward_kernel(const floa
     // selected half only (max-feature-map backward), the other B fragment is zero
     if constexpr (STEPS > 0) {
         float g[STEPS];
-        uint32_t taken = 0;  // bit s: the second half won for channel 2 s + lk at this lane's pixel
 #pragma unroll
-        for (int s = 0; s < STEPS; ++s) {
+        for (int s = 0; s < STEPS; ++s)
             g[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gr, g_off, (uint32_t)(2 * s) * Pb, 0));
-            taken |= ((__builtin_amdgcn_raw_buffer_load_b32(sr, s_off, (uint32_t)(2 * s) * PWb, 0) >> li) & 1u) << s;
-        }
 #pragma unroll
         for (int s = 0; s < STEPS; ++s) {
             const int c = 2 * s + lk;
             const float gs = g[s] * gs_s[c];
-            const bool tb = (taken >> s) & 1u;
+            const bool tb = (m[sel_half(s)] >> sel_bit(s)) & 1u;   // the second half won for channel c at this lane's pixel
             const float ga = tb ? 0.0f : gs, gb = tb ? gs : 0.0f;
             const float *wa = w_s + c * PITCH + li;
             const float *wb = wa + C * PITCH;
@@ -264,7 +289,7 @@ __global__ __launch_bounds__(kBlock) void conv1x1_mfm_backward_kernel(const floa
         const float g = live ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gr, g_off, (uint32_t)(2 * s) * Pb, 0)) *
                                    gs_s[c]
                              : 0.0f;
-        const bool tb = live && ((__builtin_amdgcn_raw_buffer_load_b32(sr, s_off, (uint32_t)(2 * s) * PWb, 0) >> li) & 1u);
+        const bool tb = live && ((m[sel_half(s)] >> sel_bit(s)) & 1u);
         const float ga = tb ? 0.0f : g, gb = tb ? g : 0.0f;
         const float *wa = w_s + (live ? c : 0) * PITCH + li;
         const float *wb = w_s + ((live ? c : 0) + C) * PITCH + li;
@@ -301,7 +326,7 @@ void opt_in_lds(K kernel, size_t bytes) {
 
 template <int CIN, int TILES>
 void launch_fwd(const float *x, const float *w, const float *b, const float *bn_mean, const float *bn_invstd, float *y,
-                uint32_t *sel, int64_t N, int64_t C, int64_t P, hipStream_t st) {
+                uint8_t *sel, int64_t N, int64_t C, int64_t P, hipStream_t st) {
     const size_t lds = (size_t)(2 * TILES * 32 * (CIN + 1) + 4 * TILES * 32) * sizeof(float);
     const dim3 grid((unsigned)ceil_div(P, kPixPerBlock), (unsigned)N);
     if (C == TILES * 32) {
@@ -320,7 +345,7 @@ void launch_fwd(const float *x, const float *w, const float *b, const float *bn_
 }
 
 template <int CIN, int MT, int STEPS>
-void launch_bwd_steps(const float *gy, const uint32_t *sel, const float *w, const float *gscale, float *gx, int64_t N,
+void launch_bwd_steps(const float *gy, const uint8_t *sel, const float *w, const float *gscale, float *gx, int64_t N,
                       int64_t C, int64_t P, hipStream_t st) {
     const size_t lds = (size_t)(2 * C * (MT * 32 + 1) + C) * sizeof(float);
     opt_in_lds(conv1x1_mfm_backward_kernel<CIN, MT, STEPS>, lds);
@@ -332,7 +357,7 @@ void launch_bwd_steps(const float *gy, const uint32_t *sel, const float *w, cons
 // LCNN's blocks have C == Cin (the conv doubles the channels, the max-feature-map halves them): that case gets the
 // fully unrolled kernel, anything else the runtime loop
 template <int CIN, int MT>
-void launch_bwd(const float *gy, const uint32_t *sel, const float *w, const float *gscale, float *gx, int64_t N, int64_t C,
+void launch_bwd(const float *gy, const uint8_t *sel, const float *w, const float *gscale, float *gx, int64_t N, int64_t C,
                 int64_t P, hipStream_t st) {
     if (C == CIN)
         launch_bwd_steps<CIN, MT, CIN / 2>(gy, sel, w, gscale, gx, N, C, P, st);
@@ -353,7 +378,7 @@ int advstep_conv1x1_mfm_supported(int64_t Cin) { return Cin == 32 || Cin == 48 |
 
 size_t advstep_conv1x1_mfm_sel_bytes(int64_t N, int64_t C, int64_t P) {
     if (N <= 0 || C <= 0 || P <= 0) return 0;
-    return (size_t)N * (size_t)C * (size_t)ceil_div(P, 32) * sizeof(uint32_t);
+    return (size_t)N * (size_t)ceil_div(P, 32) * 64u * (size_t)sel_mask_bytes(C);   // a mask per lane of every 32-pixel tile
 }
 
 int advstep_conv1x1_mfm_forward_f32(const float *x, const float *weight, const float *bias, const float *bn_mean,
@@ -363,7 +388,7 @@ int advstep_conv1x1_mfm_forward_f32(const float *x, const float *weight, const f
     if (N == 0 || C == 0 || P == 0) return ADVSTEP_OK;
     C11_REQUIRE(x && weight && y && sel && N <= kMaxGridY && C <= 64 && ((reinterpret_cast<uintptr_t>(sel) & 3u) == 0));
     C11_REQUIRE((bn_mean == nullptr) == (bn_invstd == nullptr));
-    auto *s32 = static_cast<uint32_t *>(sel);
+    auto *s32 = static_cast<uint8_t *>(sel);
     hipStream_t st = as_stream(stream);
     const bool two = C > 32;
     switch (Cin) {
@@ -392,7 +417,8 @@ int advstep_conv1x1_mfm_backward_f32(const float *gy, const void *sel, const flo
     if (C == 0)
         return hipMemsetAsync(gx, 0, (size_t)N * Cin * P * sizeof(float), st) == hipSuccess ? ADVSTEP_OK : ADVSTEP_ELAUNCH;
     C11_REQUIRE(gy && sel && weight);
-    auto *s32 = static_cast<const uint32_t *>(sel);
+    C11_REQUIRE((reinterpret_cast<uintptr_t>(sel) & 3u) == 0);
+    auto *s32 = static_cast<const uint8_t *>(sel);
     switch (Cin) {
         case 32: launch_bwd<32, 1>(gy, s32, weight, gscale, gx, N, C, P, st); break;
         case 48: launch_bwd<48, 2>(gy, s32, weight, gscale, gx, N, C, P, st); break;

@@ -68,17 +68,35 @@ def _stream(device: torch.device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
 
+_WORKSPACE_SLOTS = 32      # bound of the scratch table: distinct (device, stream, B, T) kept alive at once
+
+
 def _workspace(device: torch.device, B: int, T: int) -> Tuple[int, int]:
     # one scratch per (device, stream, batch shape): the layout of the single-pass PGD-L2 exchange area depends on (B, T), and a
-    # buffer that only ever sees one shape never shows a call words another layout left behind (include/advstep.h)
+    # buffer that only ever sees one shape and one stream never shows a call words another layout or another stream's call left
+    # behind (include/advstep.h).  The table is a small LRU: variable-length clips or short last batches
+    # would otherwise add a zero-filled buffer per distinct shape for the life of the process.  Evicting is safe: the tensor
+    # was allocated and only ever used on the stream of its key, so the caching allocator re-issues its memory in stream order;
+    # a captured graph OWNS the buffers it baked in (`release_stream_workspaces`), they are not in this table any more.
     key = (device.index if device.index is not None else torch.cuda.current_device(), _stream(device), int(B), int(T))
-    ws = _workspaces.get(key)
+    ws = _workspaces.pop(key, None)
     if ws is None:
         need = _lib.load().advstep_row_workspace_bytes(B, T)
         # zero-filled ONCE: epoch 0, no row flagged (include/advstep.h)
         ws = torch.zeros(max(need, 256), dtype=torch.uint8, device=device)
-        _workspaces[key] = ws
+        while len(_workspaces) >= _WORKSPACE_SLOTS:
+            _workspaces.pop(next(iter(_workspaces)))                 # least recently used first (dicts keep insertion order)
+    _workspaces[key] = ws                                            # (re-)inserted last = most recently used
     return ws.data_ptr(), ws.numel()
+
+
+def release_stream_workspaces(stream_handle: int) -> list:
+    """Hand over — and forget — every scratch buffer keyed by `stream_handle`.  A captured graph calls this right after its
+    capture: the graph replays kernels that write to these ADDRESSES, so it must own the buffers, and an eager call on a stream
+    that torch later gives the same handle (its pool is round-robin) must NOT get the same buffer — two streams sharing one
+    workspace is outside the C ABI's contract (the exchange's call counter is advanced by a plain read-modify-write)."""
+    keys = [k for k in _workspaces if k[1] == stream_handle]
+    return [_workspaces.pop(k) for k in keys]
 
 
 def _out_like(ref: torch.Tensor, out: Optional[torch.Tensor], name: str = "out") -> torch.Tensor:

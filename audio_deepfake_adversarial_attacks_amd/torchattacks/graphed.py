@@ -71,10 +71,7 @@ class _Captured:
         with torch.cuda.stream(side):
             two_iterations()
         torch.cuda.current_stream(dev).wait_stream(side)
-        # The graph bakes in the ADDRESSES of hip_ops' row-reduction workspaces of (device, this stream, batch shape): hold a
-        # reference, so that nothing hip_ops does with its table later can free a buffer this graph writes to on every replay
         from .. import hip_ops
-        self._workspaces = [ws for key, ws in hip_ops._workspaces.items() if key[1] == side.cuda_stream]
         self.graph = torch.cuda.CUDAGraph()
         # thread-local capture mode: with N > 1 ranks the RCCL watchdog thread (event queries), and in the CLI the DataLoader's
         # pinning thread, make HIP calls of their own while this thread captures; in the default "global" mode any such call
@@ -83,6 +80,11 @@ class _Captured:
         # by the warm-up, OUTSIDE the capture, so nothing that outlives this object is allocated from the graph's private pool
         with torch.cuda.graph(self.graph, stream=side, capture_error_mode="thread_local"):
             two_iterations()
+        # The graph bakes in the ADDRESSES of hip_ops' row-reduction workspaces of (device, warm-up stream, batch shape): it takes
+        # them OUT of hip_ops' table and owns them from here on — nothing hip_ops does later can free a buffer this graph writes
+        # to on every replay, and no eager call on a stream that re-uses the warm-up stream's handle is ever given the same
+        # buffer (one workspace, one stream: include/advstep.h)
+        self._workspaces = hip_ops.release_stream_workspaces(side.cuda_stream)
 
     def run(self, adv, images, labels, target, pairs: int) -> torch.Tensor:
         # (adv_a / adv_b became autograd leaves during the capture: write through detached views)

@@ -10,17 +10,20 @@
  *   - plain C symbols, raw DEVICE pointers, sizes as int64_t, scalars by value, no torch / C++ types;
  *   - tensors are contiguous row-major float32: waveforms are (B, T) (T = 64 600 for the repo's 4 s cut),
  *     "flat" entry points take n = B*T;  per-row scalars are (B);
- *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); kernels are stream-ordered,
- *     never synchronise the device, keep no global state and are re-entrant;
- *   - the caller owns every buffer, including the row-reduction scratch `ws`
- *     (>= advstep_row_workspace_bytes(B, T) bytes, 16-byte aligned, ZERO-FILLED ONCE by the caller before its first use, used
- *     by ONE stream at a time, and best kept for ONE (B, T): the single-pass PGD-L2 calls keep their in-launch exchange state
- *     in it — a call counter in its first word, tagged 8-byte granules, per-row flags — in an area the float partial sums of
- *     the other entry points do not touch for the same (B, T).  Nothing has to be cleaned between calls: a granule counts
- *     only if it carries the tag of THIS call (counter + phase).  What a violated contract costs: flags that are not zero
- *     send their rows through the repair pass (slower, same bits; advstep_pgd_l2_repaired_rows counts them); a buffer shared
- *     between shapes can show a call a word another layout left behind, which is consumed only if it equals the call's
- *     32-bit tag — a coincidence the counter keeps from repeating, not an impossibility.  ABI 3);
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); kernels are stream-ordered, never
+ *     synchronise the device and keep no state in the library or the process: the ONLY state that survives a call is what
+ *     the caller's own `ws` buffer holds (next item).  Calls on different streams with different buffers are independent;
+ *   - the caller owns every buffer, including the row-reduction scratch `ws`: >= advstep_row_workspace_bytes(B, T) bytes,
+ *     16-byte aligned, ZERO-FILLED ONCE by the caller before its first use, and from then on used by ONE stream at a time and
+ *     for ONE (B, T).  The single-pass PGD-L2 calls keep their in-launch exchange state in it — a call counter in its first
+ *     word, tagged 8-byte granules, per-row flags — in an area the float partial sums of the other entry points do not touch
+ *     for the same (B, T); nothing has to be cleaned between calls (a granule counts only if it carries the tag of THIS call:
+ *     counter + phase), and flags that are not zero merely send their rows through the repair pass (slower, same bits;
+ *     advstep_pgd_l2_repaired_rows counts them).  Sharing one `ws` between two (B, T) or between two streams that may run
+ *     concurrently is OUTSIDE the contract and the results of the single-pass PGD-L2 calls are then UNDEFINED: the layouts
+ *     overlap, the counter is advanced by a plain read-modify-write, and a word another layout or another stream's call left
+ *     behind is taken for this call's whenever it equals the 32-bit tag.  The library cannot diagnose it (a status code
+ *     would need a device synchronisation); give every (stream, B, T) its own buffer, as the Python binding does.  ABI 3);
  *   - `out` may alias the first waveform input of the same call (in-place update) unless stated otherwise;
  *   - return value: ADVSTEP_OK or an ADVSTEP_E* code; nothing is thrown across the ABI.
  *   - Python-float hyper-parameters of the reference enter as float32 (that is how ATen applies a Python

@@ -76,9 +76,12 @@ int advstep_conv5_mfm_pool2_backward_f32(const float *gy, const uint8_t *idx, co
 
 /* ---- 1x1 blocks fused: Conv2d(Cin, 2C, (1,1)) -> MaxFeatureMap2D  (src/models/lcnn.py:125-126,132-133,139-140,146-147)
  * A skinny GEMM (K = Cin) run on the matrix cores (fp32-in / fp32-accumulate MFMA: exact f32).
- * x (N, Cin, P) with P = H*W, weight (2C, Cin), bias (2C) or NULL -> y (N, C, P); sel gets ONE bit per output
- * (N * C * ceil(P/32) 32-bit words, bit = pixel % 32, set when the second channel half won).  The 2C-channel conv
- * output is never written.  Cin must be one advstep_conv1x1_mfm_supported() accepts (32, 48, 64: LCNN's); C <= 64.
+ * x (N, Cin, P) with P = H*W, weight (2C, Cin), bias (2C) or NULL -> y (N, C, P); sel gets ONE bit per output, set
+ * when the second channel half won, in the layout the kernels' lanes own them (round 6; opaque to callers, size from
+ * advstep_conv1x1_mfm_sel_bytes, 4-byte aligned): [n][p / 32][p % 32][h] masks of 16 bits (C <= 32) or 32 bits, where
+ * channel c sits in half h = (c >> 2) & 1 at bit 16 (c >> 5) + (c & 3) + 4 ((c & 31) >> 3) - one 128- / 256-byte store
+ * per wave and 32-pixel tile, one load per lane in the backward.  (Rounds 1-5: [n][c][p / 32] ballot words, sixteen
+ * partial-line stores per wave; -7 us of the first block's 67.)  The 2C-channel conv output is never written.  Cin must be one advstep_conv1x1_mfm_supported() accepts (32, 48, 64: LCNN's); C <= 64.
  * bn_mean / bn_invstd (C) or both NULL: the eval-mode BatchNorm2d(affine=False) that follows each of these blocks
  * (lcnn.py:127,134,141,148), y = (max - mean[c]) * invstd[c], folded into the epilogue. */
 int advstep_conv1x1_mfm_supported(int64_t Cin);

@@ -33,7 +33,8 @@ import numpy as np
 import torch
 
 REF = Path("/root/reference")
-OUT = Path(__file__).resolve().parent
+HERE = Path(__file__).resolve().parent
+OUT = HERE          # `main(out_dir)` / `--out DIR` redirect the fixtures (tests/test_golden_recipe.py regenerates into a temp dir)
 T_FULL = 64_600
 T_RAGGED = 4_099  # odd: exercises the scalar tails / unaligned rows
 T_SMALL = 4_096
@@ -432,6 +433,26 @@ def gen_metrics():
     np.savez_compressed(OUT / "metrics.npz", **out)
 
 
+_STAND_IN_NAMES = ("torchaudio", "torchaudio.functional", "soundfile", "asteroid_filterbanks")
+
+
+@contextlib.contextmanager
+def _stand_ins():
+    """The inert module objects a generator puts into sys.modules live only as long as that generator: left behind, a
+    spec-less `torchaudio` makes a later `import transformers.audio_utils` (gen_frontends_xcheck) fail with
+    `ValueError: torchaudio.__spec__ is None` (What's weak 9).  Reference modules imported meanwhile stay
+    cached; they hold their own references to the stand-ins."""
+    before = {k: sys.modules.get(k) for k in _STAND_IN_NAMES}
+    try:
+        yield
+    finally:
+        for k, v in before.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
 def _inert_torchaudio():
     """An object that satisfies `import torchaudio` + the three module-level constructor calls of
     src/frontends.py:13-38 and does nothing else (calling the result raises)."""
@@ -506,7 +527,7 @@ def gen_rawnet3_body():
     encoder itself is NOT pinned.  Full-size model (C = 1024); weights by the seeded recipe of helpers."""
     import json
 
-    sys.path.insert(0, str(OUT.parent))
+    sys.path.insert(0, str(HERE.parent))
     import helpers
 
     afb = types.ModuleType("asteroid_filterbanks")
@@ -662,7 +683,7 @@ def gen_datasets():
     import json
     import tempfile
 
-    sys.path.insert(0, str(OUT.parent))
+    sys.path.insert(0, str(HERE.parent))
     import helpers
 
     ta = sys.modules.get("torchaudio") or _inert_torchaudio()
@@ -754,7 +775,11 @@ def gen_datasets():
     (OUT / "datasets_listing.json").write_text(json.dumps(listing, indent=0))
 
 
-def main():
+def main(out_dir=None):
+    global OUT
+    if out_dir is not None:
+        OUT = Path(out_dir)
+        OUT.mkdir(parents=True, exist_ok=True)
     _import_reference()
     torch.set_num_threads(1)  # fixed thread count: the reference is bit-reproducible at a fixed thread count
     torch.use_deterministic_algorithms(True)
@@ -771,11 +796,14 @@ def main():
     gen_trainer()
     gen_attack_save(ta, aa_utils)
     gen_metrics()
-    gen_model_bodies()
-    gen_rawnet3_body()
+    with _stand_ins():
+        gen_model_bodies()
+    with _stand_ins():
+        gen_rawnet3_body()
     gen_frontends_xcheck()
     gen_frontends_batch_floor()
-    gen_datasets()
+    with _stand_ins():
+        gen_datasets()
     for p in sorted(OUT.glob("*.npz")):
         print(f"{p.name}: {p.stat().st_size / 1e6:.2f} MB")
 
@@ -789,5 +817,7 @@ if __name__ == "__main__":
         from adversarial_attacks import torchattacks as ta
         from src.aa import utils as aa_utils
         gen_attack_save(ta, aa_utils)
+    elif sys.argv[1:2] == ["--out"]:                   # the whole recipe into another directory (nothing under tests/ is touched)
+        main(sys.argv[2])
     else:
         main()

@@ -110,11 +110,16 @@ def _codes_from_selection(kind: str, saved, shape, pooled: bool) -> torch.Tensor
     lib = _lib.load()
     N, C, H, W = shape
     dev = saved.device
-    if kind == "bits":                     # conv1x1: one bit per output, bit = pixel % 32 of word [n, c, pixel / 32]
+    if kind == "bits":                     # conv1x1 (round-6 layout, include/advstep_lcnn.h): [n][p / 32][p % 32][h] lane masks
         P = H * W
-        words = saved.view(torch.int32)[: N * C * ((P + 31) // 32)].view(N, C, -1)
-        bits = (words.unsqueeze(-1) >> torch.arange(32, device=dev, dtype=torch.int32)) & 1
-        return bits.reshape(N, C, -1)[:, :, :P].reshape(N, C, H, W).to(torch.uint8)
+        PW = (P + 31) // 32
+        wide = C > 32
+        raw = saved[: N * PW * 64 * (4 if wide else 2)].view(torch.int32 if wide else torch.int16).view(N, PW, 32, 2)
+        raw = raw.to(torch.int64) & (0xFFFFFFFF if wide else 0xFFFF)
+        c = torch.arange(C, device=dev)
+        half, bit = (c >> 2) & 1, 16 * (c >> 5) + (c & 3) + 4 * ((c & 31) >> 3)
+        bits = (raw[:, :, :, half] >> bit) & 1                       # (N, PW, 32, C)
+        return bits.permute(0, 3, 1, 2).reshape(N, C, PW * 32)[:, :, :P].reshape(N, C, H, W).to(torch.uint8)
     gx = torch.empty((N, 2 * C, H, W), dtype=torch.float32, device=dev)
     ones = _ones_like_output(N, C, H, W, pooled, dev)
     if kind == "pool":

@@ -346,17 +346,18 @@ def test_conv1x1_mfm_writes_nothing_outside_its_tensors(cuda, Cin, C):
     g = torch.Generator().manual_seed(Cin + C)
     x = torch.randn(N, Cin, P, generator=g).to(cuda)
     w = (torch.randn(2 * C, Cin, generator=g) * 0.2).to(cuda)
-    PW = (P + 31) // 32
+    nsel = lib.advstep_conv1x1_mfm_sel_bytes(N, C, P) // 4       # opaque layout: its size comes from the library
+    assert nsel == N * ((P + 31) // 32) * 64 * (2 if C <= 32 else 4) // 4
     pad = 64 * P
     ybuf = torch.full((pad + N * C * P + pad,), 7.5, device=cuda)
-    sbuf = torch.full((pad + N * C * PW + pad,), 0x5A5A5A5A, dtype=torch.int32, device=cuda)
-    y, sel = ybuf[pad:pad + N * C * P], sbuf[pad:pad + N * C * PW]
+    sbuf = torch.full((pad + nsel + pad,), 0x5A5A5A5A, dtype=torch.int32, device=cuda)
+    y, sel = ybuf[pad:pad + N * C * P], sbuf[pad:pad + nsel]
     stream = torch.cuda.current_stream(cuda).cuda_stream
     assert lib.advstep_conv1x1_mfm_forward_f32(x.data_ptr(), w.data_ptr(), None, None, None, y.data_ptr(), sel.data_ptr(),
                                                N, Cin, C, P, stream) == 0
     torch.cuda.synchronize()
     assert (ybuf[:pad] == 7.5).all() and (ybuf[pad + N * C * P:] == 7.5).all()
-    assert (sbuf[:pad] == 0x5A5A5A5A).all() and (sbuf[pad + N * C * PW:] == 0x5A5A5A5A).all()
+    assert (sbuf[:pad] == 0x5A5A5A5A).all() and (sbuf[pad + nsel:] == 0x5A5A5A5A).all()
     conv = torch.einsum("ok,nkp->nop", w.double(), x.double())
     want = torch.maximum(conv[:, :C], conv[:, C:])
     assert (y.view(N, C, P).double() - want).abs().max().item() <= 2e-5
@@ -502,6 +503,37 @@ def test_conv3x3_mfm_pool2_matches_float64_reference(L, cuda, N, Cin, C, H, W, w
     tol = 2e-5 * max(gx_ref.abs().max().item(), 1.0)
     # at most a handful of pooling windows may resolve a near tie differently
     assert (err > tol).float().mean().item() <= 1e-3, ((err > tol).sum().item(), err.max().item())
+    assert (err.max().item() <= tol) or (err > tol).sum().item() <= 9 * 8 * Cin
+
+
+@pytest.mark.parametrize("N,C,H,W", [(4, 32, 50, 10), (3, 32, 11, 9), (2, 64, 50, 10), (3, 64, 7, 13), (1, 64, 2, 2)])
+def test_conv3x3_pool2_backward_half_slice_launch_equals_the_single_launch(L, cuda, monkeypatch, N, C, H, W):
+    """a one-slice input gradient (Cin = 32 output rows) on a plane that does not fill the chip is launched as
+    its two 16-row halves (round 5, `ga.halves`; every NT = 1 kernel then reads its A operand as one component of the
+    stored pair).  A/B through the switch the launcher reads at call time: the same bits, for the resident weights
+    (K = 2 C = 64) and the streamed ones (K = 128), on even and odd planes."""
+    g = torch.Generator().manual_seed(C * 100 + H * 10 + W)
+    Cin = 32
+    x = torch.randn(N, Cin, H, W, generator=g).to(cuda)
+    weight = (torch.randn(2 * C, Cin, 3, 3, generator=g) * 0.1).to(cuda)
+    bias = torch.randn(2 * C, generator=g).to(cuda)
+    mean, var = torch.randn(C, generator=g).to(cuda), (torch.rand(C, generator=g) + 0.5).to(cuda)
+    bn = (mean, (1.0 / torch.sqrt(var + 1e-5)).contiguous())
+    gy = torch.randn(N, C, H // 2, W // 2, generator=g).to(cuda)
+    got = {}
+    for halves in ("1", "0"):
+        monkeypatch.setenv("ADVSTEP_WINO_HALVES", halves)
+        xa = x.clone().requires_grad_(True)
+        y = L.conv3x3_mfm_pool2(xa, weight, bias, bn)
+        (got[halves],) = torch.autograd.grad(y, xa, gy)
+    assert torch.equal(got["1"], got["0"])
+    # and the gradient is the right one (float64 direct convolution through the kernel's own winners, as in the test above)
+    xr = x.double().requires_grad_(True)
+    conv = torch.nn.functional.conv2d(xr, weight.double(), bias.double(), padding=1)
+    y_ref = (ref_mfm_pool(conv) - mean.double().view(1, -1, 1, 1)) * bn[1].double().view(1, -1, 1, 1)
+    (gx_ref,) = torch.autograd.grad(y_ref, xr, gy.double())
+    err = (got["1"].double() - gx_ref).abs()
+    tol = 2e-5 * max(gx_ref.abs().max().item(), 1.0)
     assert (err.max().item() <= tol) or (err > tol).sum().item() <= 9 * 8 * Cin
 
 

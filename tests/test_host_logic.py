@@ -399,3 +399,40 @@ def test_save_reproduces_the_reference_files(golden, tmp_path):
         assert np.array_equal(labels.numpy(), g[f"{kind}_labels"]) and np.array_equal(preds.numpy(), g[f"{kind}_preds"])
         assert rob_acc == float(g[f"{kind}_rob_acc"]) and abs(l2 - float(g[f"{kind}_l2"])) <= 1e-9
         assert atk._return_type == str(g[f"{kind}_return_type_after"]) == "float"
+
+
+def test_row_workspace_table_is_a_bounded_lru_and_graphs_take_their_buffers_out(monkeypatch):
+    """one scratch buffer per (device, stream, B, T) — the C ABI's "one workspace, one stream, one shape" rule
+    (include/advstep.h) — but no more than a fixed number alive, least recently used first out, and a captured graph's
+    buffers leave the table so that a stream re-using the capture stream's handle never shares them.  Host logic only:
+    the library and the stream handle are stubbed, buffers are CPU tensors."""
+    from audio_deepfake_adversarial_attacks_amd import hip_ops
+
+    class _Lib:
+        @staticmethod
+        def advstep_row_workspace_bytes(B, T):
+            return 64 * B
+
+    handle = {"v": 11}
+    monkeypatch.setattr(hip_ops._lib, "load", lambda: _Lib)
+    monkeypatch.setattr(hip_ops, "_stream", lambda device: handle["v"])
+    monkeypatch.setattr(hip_ops, "_workspaces", {})
+    monkeypatch.setattr(hip_ops, "_WORKSPACE_SLOTS", 4)
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 0)
+    cpu = torch.device("cpu")
+    first = hip_ops._workspace(cpu, 1, 100)
+    assert hip_ops._workspace(cpu, 1, 100) == first                  # same key: same buffer, nothing re-zeroed
+    for B in (2, 3, 4):
+        hip_ops._workspace(cpu, B, 100)
+    assert len(hip_ops._workspaces) == 4
+    hip_ops._workspace(cpu, 1, 100)                                  # touch: B = 1 becomes the most recent
+    hip_ops._workspace(cpu, 5, 100)                                  # evicts B = 2, the least recently used
+    assert [k[2] for k in hip_ops._workspaces] == [3, 4, 1, 5]
+    handle["v"] = 22                                                 # another stream: its own buffers
+    ptr22, _ = hip_ops._workspace(cpu, 1, 100)
+    assert ptr22 != first[0]
+    taken = hip_ops.release_stream_workspaces(22)
+    assert len(taken) == 1 and taken[0].data_ptr() == ptr22
+    assert all(k[1] == 11 for k in hip_ops._workspaces)
+    fresh, _ = hip_ops._workspace(cpu, 1, 100)                       # the handle comes round again: a NEW zero-filled buffer
+    assert fresh != ptr22 and int(hip_ops._workspaces[(0, 22, 1, 100)].sum()) == 0
