@@ -33,6 +33,7 @@ _profile: Optional[Dict[str, List[Tuple[torch.cuda.Event, torch.cuda.Event]]]] =
 _profile_work: Dict[str, List[float]] = {}      # per bracketed launch: the arithmetic the caller says it did (flop), or 0
 _profile_bytes: Dict[str, List[float]] = {}     # per bracketed launch: the bytes of the operands the caller named, or 0
 _profile_all = False                            # start_profile("*"): every entry point
+_profile_graph_ok = False                       # start_profile(..., graph_ok=True): only launches OUTSIDE captured graphs matter
 
 
 def _require(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
@@ -122,7 +123,8 @@ class _Launch:
     def __enter__(self):
         self.guard.__enter__()
         self.pair = None
-        if _profile is not None and (_profile_all or self.name in _profile):
+        if (_profile is not None and (_profile_all or self.name in _profile)
+                and not torch.cuda.is_current_stream_capturing()):       # an event cannot be recorded into a graph
             self.pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             self.pair[0].record(torch.cuda.current_stream(self.device))
         return self
@@ -136,10 +138,13 @@ class _Launch:
         return self.guard.__exit__(*exc)
 
 
-def start_profile(*entry_points: str) -> None:
+def start_profile(*entry_points: str, graph_ok: bool = False) -> None:
     """Bracket every later launch of the named entry points ("*": of every entry point) with HIP events on their launch
-    stream."""
-    global _profile, _profile_all
+    stream.  graph_ok: the caller prices launches that stay OUTSIDE the attacks' captured graphs (the update steps,
+    min-max, random starts) and the iteration may keep replaying its model part from a hipGraph (torchattacks/graphed.py);
+    without it profiling keeps the whole loop eager so that launches of the model part can be bracketed too."""
+    global _profile, _profile_all, _profile_graph_ok
+    _profile_graph_ok = bool(graph_ok)
     _profile_all = "*" in entry_points
     _profile = {n: [] for n in entry_points if n != "*"}
     _profile_work.clear()
@@ -149,8 +154,8 @@ def start_profile(*entry_points: str) -> None:
 def stop_profile(with_work=False):
     """Synchronise and return {entry point: [milliseconds per launch]}; with_work: also {entry point: [flop per launch]};
     with_work="bytes": also {entry point: [algorithmic bytes per launch]} as a third result."""
-    global _profile, _profile_all
-    prof, _profile, _profile_all = _profile or {}, None, False
+    global _profile, _profile_all, _profile_graph_ok
+    prof, _profile, _profile_all, _profile_graph_ok = _profile or {}, None, False, False
     torch.cuda.synchronize()
     ms = {n: [a.elapsed_time(b) for a, b in pairs] for n, pairs in prof.items()}
     if with_work == "bytes":

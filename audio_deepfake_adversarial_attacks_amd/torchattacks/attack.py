@@ -29,6 +29,10 @@ class Attack(object):
     The device is taken from the model's first parameter; by default the model is switched to eval mode
     for the duration of an attack call (see `set_training_mode`)."""
 
+    # the attack's inner loop can replay from a hipGraph (torchattacks/graphed.py): PGD, PGDL2.  evaluation.generate_attacks
+    # keeps two batches in flight for those (additive attribute; the reference has no counterpart)
+    replays_from_graph = False
+
     def __init__(self, name, model):
         # attack.py:14-35
         self.attack = name

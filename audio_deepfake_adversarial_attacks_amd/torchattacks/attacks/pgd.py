@@ -18,6 +18,8 @@ class PGD(Attack):
         >>> adv_images = attack(images, labels)
     """
 
+    replays_from_graph = True
+
     def __init__(self, model, eps=0.3, alpha=2 / 255, steps=40, random_start=True):
         super().__init__("PGD", model)
         self.eps = eps

@@ -19,6 +19,8 @@ class PGDL2(Attack):
         >>> adv_images = attack(images, labels)
     """
 
+    replays_from_graph = True
+
     def __init__(self, model, eps=1.0, alpha=0.2, steps=40, random_start=True, eps_for_division=1e-10):
         super().__init__("PGDL2", model)
         self.eps = eps

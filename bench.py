@@ -20,6 +20,12 @@ itself under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --ma
     3  configs[3]  RawNet3 -> LCNN + LFCC transfer, FGSM + CW-100, B = 64 (a step attacks the batch with both)
                                                                        roofline: advstep_cw_adam_step_f32,  32 B/sample
 
+Round 6: the timed region runs the SHIPPED launch path — the attack iteration's model part replayed from its hipGraph, the
+update step launched (and bracketed) between the replays — with `--in-flight` batches in flight on streams of their own
+(default 2 for the graph-replayed attacks of configs 1 and 2: batch i on stream i % 2; evaluation._Lanes).  Every step is
+still one batch through the whole body; K steps are timed between the same barriers.  Untimed priming steps in front of the
+W warm-up steps let every stream capture its graph (a graph is captured at the second sight of a workload).
+
 `roofline` prices the dominant hand-written kernel of the workload with HIP events recorded on its launch stream
 inside the timed region; `cpu_baseline` times the CPU oracle ("port": oracle/attacks.py, torch CPU ops in the
 reference's order) on a bounded sample of the same workload on this box's host cores (rank 0, N = 1 only)."""
@@ -104,6 +110,9 @@ def parse(argv=None):
     p.add_argument("--warmup", type=int, default=None, help="untimed steps (default 2; 1 for --config 3)")
     p.add_argument("--config", type=int, default=1, choices=sorted(WORKLOADS), help="BASELINE.json configs[N]")
     p.add_argument("--batch", type=int, default=None, help="utterances per GPU per step (default: the config's)")
+    p.add_argument("--in-flight", type=int, default=None,
+                   help="batches in flight, each on its own stream (default: 2 for --config 1 and 2, 1 for --config 3 whose CW "
+                        "loop is driven from the host)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extras", action="store_true",
                    help="skip the legs after the timed region (graph-replay timing, model-side roofline, cold-regime and "
@@ -118,6 +127,8 @@ def parse(argv=None):
         a.steps = 2 if a.config == 3 else 4
     if a.warmup is None:
         a.warmup = 1 if a.config == 3 else 2
+    if a.in_flight is None:
+        a.in_flight = 1 if a.config == 3 else 2
     return a
 
 
@@ -159,7 +170,7 @@ def cpu_baseline(config: int, threads: int, iterations: float = 0.0):
         return dict(fail, sample="timed out (900 s)")
 
 
-def through_loop(config: int, spec, B: int, device, warm: int = 4, timed: int = 16, workers: int = 3):
+def through_loop(config: int, spec, B: int, device, warm: int = 6, timed: int = 16, workers: int = 3, in_flight=None):
     """Steady-state rate of the SHIPPED loop (evaluation.generate_attacks: DataLoader with `workers` worker processes,
     pinned staging + side-stream upload one batch ahead, hipGraph replay of the attack iteration, scores kept on the device)
     for the workload's first attack: utterances / second between a HIP event recorded when batch `warm` has been queued and
@@ -178,7 +189,12 @@ def through_loop(config: int, spec, B: int, device, warm: int = 4, timed: int = 
     cls, params = AttackEnum[member].value
     marks = {}
 
+    tail = 2          # batches queued AFTER the closing mark: the interval ends while every stream still has work (a stream that
+                      # runs its last batch alone finishes it faster than in steady state)
+
     def queued(i):
+        # called under the stream batch i was queued on.  `timed` is even, so with two batches in flight both marks sit on the
+        # same stream and the interval is timed / 2 batches of that stream, during which the other completes as many
         if i in (warm - 1, warm + timed - 1):
             marks[i] = torch.cuda.Event(enable_timing=True)
             marks[i].record(torch.cuda.current_stream(device))
@@ -186,14 +202,16 @@ def through_loop(config: int, spec, B: int, device, warm: int = 4, timed: int = 
     set_seed(42)
     rep = generate_attacks([None, None, None], cfg(spec["target"]), str(device), attack_model_config=cfg(spec["attacked"]),
                            attack_method=cls, attack_params=params, batch_size=B,
-                           dataset=SyntheticDetectionDataset(B * (warm + timed)), share_weights=spec["white_box"], shuffle=False,
-                           num_workers=workers, on_batch_queued=queued)
+                           dataset=SyntheticDetectionDataset(B * (warm + timed + tail)), share_weights=spec["white_box"], shuffle=False,
+                           num_workers=workers, on_batch_queued=queued, in_flight=in_flight)
     torch.cuda.synchronize()
     ms = marks[warm - 1].elapsed_time(marks[warm + timed - 1])
     return {"value": B * timed / (ms * 1e-3), "unit": "utterances/s", "ms_per_batch": ms / timed, "batches_timed": timed,
             "batches_warm": warm, "dataloader_workers": workers, "attack": member, "accuracy": rep["adv_eval/accuracy"],
+            "batches_in_flight": in_flight if in_flight is not None else "default (2 for PGD / PGDL2)",
             "what": "evaluation.generate_attacks end to end (collate in worker processes, H2D through pinned buffers on a side "
-                    "stream, hipGraph replay, one host sync at the end); HIP-event time between batch 4 and the last batch"}
+                    "stream, hipGraph replay, one host sync at the end); HIP-event time from the end of batch `batches_warm` to the end of "
+                    "batch `batches_warm + batches_timed`, two more batches queued behind it (steady state on every stream)"}
 
 
 def live_traffic(entry_point: str, B: int):
@@ -282,7 +300,7 @@ def main():
     from audio_deepfake_adversarial_attacks_amd import hip_ops, metrics
     from audio_deepfake_adversarial_attacks_amd.aa.aa_types import AttackEnum
     from audio_deepfake_adversarial_attacks_amd.datasets.synthetic import synthetic_waveforms
-    from audio_deepfake_adversarial_attacks_amd.evaluation import (aggregate_across_ranks, attack_batch, score_batch)
+    from audio_deepfake_adversarial_attacks_amd.evaluation import (_Lanes, aggregate_across_ranks, attack_batch, score_batch)
 
     spec = WORKLOADS[args.config]
     target, attacked = build_models(spec, device)
@@ -305,43 +323,62 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed_loop(first, last):
-        """The loop body for batches [first, last): per attack the scores, labels and a per-step event mark."""
+    lanes = _Lanes(device, args.in_flight)          # batch i on stream i % in_flight (1: the current stream, as in rounds 1-5)
+    one_lane = _Lanes(device, 1)
+    counter = [0]                                    # steps queued so far: consecutive steps alternate streams across calls
+
+    def timed_loop(first, last, lanes=lanes):
+        """The loop body for batches [first, last): per attack the scores, labels and a per-step event mark (recorded on the
+        stream the step ran on); returns after every stream's work has been ordered in front of the caller's stream."""
         out = {m: ([], [], []) for m, _ in attacks}
-        correct = {m: torch.zeros((), dtype=torch.int64, device=device) for m, _ in attacks}
+        correct = {m: [torch.zeros((), dtype=torch.int64, device=device) for _ in range(lanes.n)] for m, _ in attacks}
         marks = [torch.cuda.Event(enable_timing=True)]
         marks[0].record()
         for i in range(first, last):
             bx, by = x_all[i * B:(i + 1) * B], y_all[i * B:(i + 1) * B]
-            for m, atk in attacks:
-                adv = attack_batch(atk, bx, by)
-                p, l = score_batch(target, adv)
-                out[m][0].append(p), out[m][1].append(l), out[m][2].append(by)
-                correct[m] += (l == by.int()).sum()
-                marks.append(torch.cuda.Event(enable_timing=True))
-                marks[-1].record()
-        return out, correct, marks
+            with lanes.batch(counter[0], (B, T)) as lane:
+                counter[0] += 1
+                for m, atk in attacks:
+                    adv = attack_batch(atk, bx, by)
+                    p, l = score_batch(target, adv)
+                    out[m][0].append(p), out[m][1].append(l), out[m][2].append(by)
+                    correct[m][lane] += (l == by.int()).sum()
+                    lanes.keep(p, l)
+                    marks.append(torch.cuda.Event(enable_timing=True))
+                    marks[-1].record()
+        for m in correct:
+            lanes.keep(*correct[m])
+        lanes.join()
+        return out, {m: torch.stack(v).sum() for m, v in correct.items()}, marks
 
     def aggregate(out, correct, n_steps):
         total = torch.tensor(B * n_steps, dtype=torch.int64, device=device)
         return {m: aggregate_across_ranks(torch.cat(out[m][0]), torch.cat(out[m][1]), torch.cat(out[m][2]),
                                           correct[m], total) for m, _ in attacks}
 
+    # Priming (untimed, in front of the W warm-up steps): a stream captures its graph at the second sight of the workload, so
+    # two steps per stream in flight bring every stream to steady-state replay whatever W is.
     # Warm-up = the timed loop's body, bookkeeping kernels and launch profiling included: the first launch of any kernel
     # loads its code object (tens of milliseconds in the first process on a fresh box), which must not land in a timed
     # step ... and the end-of-run aggregate (RCCL communicator set-up for world > 1, the D2H copy kernels otherwise).
+    graph_replayed = all(getattr(atk, "replays_from_graph", False) for _, atk in attacks)
+    prime = 2 * lanes.n if graph_replayed else 0
+    hip_ops.start_profile(*PROFILED, graph_ok=True)
+    for j in range(prime):
+        timed_loop(j % n_batches, j % n_batches + 1)
     if args.warmup > 0:
-        hip_ops.start_profile(*PROFILED)
         w_out, w_correct, _ = timed_loop(0, args.warmup)
         aggregate(w_out, w_correct, args.warmup)
-        hip_ops.stop_profile()
         del w_out, w_correct
     elif world > 1:  # communicator warm-up outside the timed region
         z = torch.zeros(B, device=device)
         aggregate_across_ranks(z, z, z, torch.zeros((), device=device), torch.zeros((), device=device))
+    hip_ops.stop_profile()
     sync_all()
 
-    hip_ops.start_profile(*PROFILED)
+    # graph_ok: the brackets sit on launches OUTSIDE the captured model part (update step, random start, min-max), so the
+    # iteration keeps replaying from its graph — the timed region runs the shipped launch path
+    hip_ops.start_profile(*PROFILED, graph_ok=True)
     t0 = time.perf_counter()
     out, correct, marks = timed_loop(args.warmup, n_batches)
     gathered = aggregate(out, correct, args.steps)
@@ -375,7 +412,10 @@ def main():
             b.record(stream)
         torch.cuda.synchronize()
         empty_ms = sorted(a.elapsed_time(b) for a, b in pairs)[len(pairs) // 2]
-        each = [a.elapsed_time(b) for a, b in zip(marks[:-1], marks[1:])]
+        # completion time of every (step, attack) after the loop's start mark, differenced in step order (one batch in flight:
+        # the step's own duration; two: the interval at which steps complete — consecutive steps run on different streams)
+        ends = [marks[0].elapsed_time(m) for m in marks[1:]]
+        each = [e - p for p, e in zip([0.0] + ends[:-1], ends)]
         k = len(attacks)
         line = {
             "metric": spec["metric"],
@@ -394,6 +434,9 @@ def main():
                 "workload": f"{spec['what']}, batch={B}/GPU, T={T} (BASELINE.json {spec['tag']}); "
                             f"step = minmax -> attack -> revert -> target fwd -> score",
                 "global_batch": B * world,
+                "batches_in_flight": lanes.n,
+                "launch_path": ("hipGraph replay of the attack iteration's model part, update step launched between the replays"
+                                if graph_replayed else "eager launches (host-driven attack loop)"),
                 "sharding": f"{world} independent contiguous shards, no per-step collective; one "
                             f"{'RCCL' if args.backend == 'nccl' else args.backend} all-reduce + all-gather of the "
                             f"scores after the last step",
@@ -429,24 +472,41 @@ def main():
         if k == 1:
             line["adv_eval"] = line["adv_eval"][attacks[0][0]]
         if extras:
-            # (1) the shipped default path: the same K steps with launch profiling OFF, so the PGD / PGDL2 inner loop replays
-            #     from its hipGraph (torchattacks/graphed.py; the timed region above brackets the priced kernel with HIP
-            #     events, which a graph cannot carry, and therefore launches eagerly).  Two untimed batches first: a graph is
-            #     captured when the same (model state, shape) shows up a second time.
+            # (1) the same K steps with launch profiling OFF (no event brackets around the update step): what the brackets of the
+            #     timed region cost.  Same launch path, same streams, graphs already captured.
             from audio_deepfake_adversarial_attacks_amd.torchattacks import graphed
-            timed_loop(0, min(2, n_batches))
-            timed_loop(0, min(2, n_batches))
             sync_all()
             t1 = time.perf_counter()
             o2, c2, _ = timed_loop(args.warmup, n_batches)
             aggregate(o2, c2, args.steps)
             sync_all()
             dt = time.perf_counter() - t1
-            line["shipped_path"] = {"launch_path": "hipGraph replay of the attack iteration" if len(graphed._GRAPHS) else
-                                    "eager launches (this workload's attacks do not replay from a graph)",
-                                    "graphs_captured": len(graphed._GRAPHS), "steps": args.steps,
+            line["shipped_path"] = {"launch_path": line["config"]["launch_path"] + ", no event brackets",
+                                    "graphs_captured": len(graphed._GRAPHS), "batches_in_flight": lanes.n, "steps": args.steps,
                                     "ms_per_step": 1e3 * dt / args.steps, "value": utterances / dt, "unit": "utterances/s"}
             del o2, c2
+            # (1b) ONE batch in flight (rounds 1-5's schedule), same launch path and brackets: the timed region's counterpart
+            #      for the in-flight comparison, and the priced kernel's in-loop bracket with the chip to itself
+            if lanes.n > 1:
+                for j in range(2 if graph_replayed else 0):           # the caller's stream captures its own graph
+                    timed_loop(j % n_batches, j % n_batches + 1, one_lane)
+                sync_all()
+                hip_ops.start_profile(*PROFILED, graph_ok=True)
+                t1 = time.perf_counter()
+                o2, c2, _ = timed_loop(args.warmup, n_batches, one_lane)
+                aggregate(o2, c2, args.steps)
+                sync_all()
+                dt = time.perf_counter() - t1
+                k1 = hip_ops.stop_profile().get(entry) or [float("nan")]
+                a1 = sum(k1) / len(k1)
+                line["one_in_flight"] = {"ms_per_step": 1e3 * dt / args.steps, "value": utterances / dt, "unit": "utterances/s",
+                                         "priced_kernel_avg_launch_ms": a1,
+                                         "priced_kernel_frac": launch_bytes / (a1 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                         "what": "the same K steps, same graphs-plus-bracketed-steps launch path, ONE batch in flight "
+                                                 "(the schedule of rounds 1-5); with two in flight the priced kernel shares the chip "
+                                                 "with the other batch's convolutions, so `roofline.frac` (timed region) reads lower "
+                                                 "than this leg's `priced_kernel_frac` for the same kernel"}
+                del o2, c2
             # (2) model-side roofline: ONE step with HIP events around every launch of the attacked model's hand-written
             #     matrix-core kernels (outside the timed region: ~400 event pairs per step would cost it ~2 %)
             names = MODEL_MATRIX_KERNELS[args.config]
@@ -454,7 +514,7 @@ def main():
                 hip_ops.start_profile(*names)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                timed_loop(args.warmup, args.warmup + 1)
+                timed_loop(args.warmup, args.warmup + 1, one_lane)
                 e1.record()
                 ms, work = hip_ops.stop_profile(with_work=True)
                 step_ms_profiled = e0.elapsed_time(e1)
@@ -482,10 +542,13 @@ def main():
             hip_ops.start_profile("*")
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            timed_loop(args.warmup, args.warmup + 1)
+            timed_loop(args.warmup, args.warmup + 1, one_lane)
             e1.record()
             ms_all, work_all, bytes_all = hip_ops.stop_profile(with_work="bytes")
             step_ms_all = e0.elapsed_time(e1)
+            # shares are of a step with ONE batch in flight (the brackets time kernels that have the chip to themselves; with two
+            # batches in flight a step completes faster than the sum of its kernels' solo durations)
+            base_ms = line.get("one_in_flight", {}).get("ms_per_step") or line["ms_per_step"]
             rows, covered, seen = [], 0.0, set()
             for family, bound, names in STEP_FAMILIES:
                 n_launch = sum(len(ms_all.get(n, ())) for n in names)
@@ -499,19 +562,20 @@ def main():
                 peak = {"mfma": MFMA_F32_PEAK_TFLOPS, "valu": VALU_F32_PEAK_TFLOPS, "hbm": HBM_PEAK_GBS}[bound]
                 achieved = amount / (net * 1e-3) / (1e9 if bound == "hbm" else 1e12) if net > 0 else 0.0
                 rows.append({"family": family, "bound": bound, "ms_per_step": round(net, 3), "ms_per_step_bracketed": round(raw, 3),
-                             "share_of_step": round(net / line["ms_per_step"], 4), "launches": n_launch, "achieved": round(achieved, 2),
+                             "share_of_step": round(net / base_ms, 4), "launches": n_launch, "achieved": round(achieved, 2),
                              "peak": peak, "unit": "GB/s" if bound == "hbm" else "TFLOP/s", "frac": round(achieved / peak, 4)})
                 covered += net
             stray = {n: round(sum(v), 3) for n, v in ms_all.items() if n not in seen and v}
             rows.append({"family": "not bracketed: ATen / hipFFT launches, other hand-written launches, gaps between launches",
-                         "bound": None, "ms_per_step": round(line["ms_per_step"] - covered, 3),
-                         "share_of_step": round(1.0 - covered / line["ms_per_step"], 4), "other_hand_written_ms": stray})
+                         "bound": None, "ms_per_step": round(base_ms - covered, 3),
+                         "share_of_step": round(1.0 - covered / base_ms, 4), "other_hand_written_ms": stray})
             line["roofline_step"] = {
                 "step_ms_profiled": round(step_ms_all, 3), "launches_bracketed": sum(len(v) for v in ms_all.values()),
-                "share_priced": round(covered / line["ms_per_step"], 4),
+                "share_priced": round(covered / base_ms, 4), "share_base_ms_per_step": round(base_ms, 3),
                 "clock": "HIP events on the launch stream around every hand-written launch (and the recurrent layers' library "
                          "GEMMs) of ONE step after the timed region; a row's ms_per_step = sum over its launches of (bracket - "
-                         "empty_event_pair_ms), i.e. kernel time; shares are of the timed region's ms_per_step (the bracketed "
+                         "empty_event_pair_ms), i.e. kernel time; shares are of `share_base_ms_per_step` = a step with ONE batch in flight "
+                         "(`one_in_flight.ms_per_step`; the timed region's own ms_per_step when it runs one in flight; the bracketed "
                          "step itself runs `step_ms_profiled`: ~1 200 event pairs cost it ~10 %)",
                 "conventions": "mfma: Winograd products through the matrix cores (direct count / 2.25); valu: 2 flop per "
                                "multiply-add of the direct convolution (the first block's input gradient: of the 25 taps per pooled "
@@ -521,6 +585,8 @@ def main():
             # (2c) the loop the user runs: generate_attacks over a synthetic dataset with its DataLoader workers, staging stream and
             #      hipGraph replay — HIP events after batch 4 and after the last batch, ONE host synchronisation at the end
             line["through_loop"] = through_loop(args.config, spec, B, device)
+            if graph_replayed:
+                line["through_loop_one_in_flight"] = through_loop(args.config, spec, B, device, in_flight=1)
             # (3) the priced kernel with its operands rotated past the 256 MiB Infinity Cache (the hot figure above runs on a
             #     132 MB working set that the cache holds): same clock, one event pair per launch
             sys.path.insert(0, str(ROOT / "tools"))
