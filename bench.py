@@ -506,6 +506,8 @@ def main():
                                                  "(the schedule of rounds 1-5); with two in flight the priced kernel shares the chip "
                                                  "with the other batch's convolutions, so `roofline.frac` (timed region) reads lower "
                                                  "than this leg's `priced_kernel_frac` for the same kernel"}
+                line["roofline"]["avg_launch_ms_one_in_flight"] = a1
+                line["roofline"]["frac_one_in_flight"] = line["one_in_flight"]["priced_kernel_frac"]
                 del o2, c2
             # (2) model-side roofline: ONE step with HIP events around every launch of the attacked model's hand-written
             #     matrix-core kernels (outside the timed region: ~400 event pairs per step would cost it ~2 %)
@@ -601,9 +603,12 @@ def main():
                 line["roofline"]["frac_rocprof_cold"] = launch_bytes / (rp * 1e-3) / 1e9 / HBM_PEAK_GBS
             line["roofline"]["which_is_hbm_honest"] = (
                 "frac_cold / frac_rocprof_cold: operands rotated past the 256 MiB Infinity Cache (HIP-event bracket / rocprofv3 "
-                "kernel-trace duration of the same launches).  `frac` is the in-loop event bracket on a 132 MB working set the "
-                "Infinity Cache partly serves; its kernel-trace counterpart (profiles/r04_bench_c*_step_summary.txt) can exceed "
-                "the HBM copy rate for that reason and is not an HBM figure")
+                "kernel-trace duration of the same launches) - the kernel's HBM figure.  `frac` is the event bracket around the "
+                "kernel's launches INSIDE the timed region, as the bench contract asks: with two batches in flight the bracket "
+                "opens when the stream's previous graph retires and closes when the kernel has found compute units next to the "
+                "other batch's convolutions and finished - it measures the schedule, not the kernel.  `frac_one_in_flight` is the "
+                "same bracket in the same loop with one batch in flight (the figure of rounds 1-5: the kernel alone on the chip, "
+                "its 132 MB working set partly served by the Infinity Cache, so it is not an HBM figure either)")
         # CW stops early on its own cost (cw.py:107-110): report what it executed, per iteration, and price the CPU leg at the
         # iterations the GPU run executed
         cw_iters = len(kernel_ms.get("cw_adam_step", ())) / args.steps if args.config == 3 else 0.0

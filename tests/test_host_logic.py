@@ -436,3 +436,28 @@ def test_row_workspace_table_is_a_bounded_lru_and_graphs_take_their_buffers_out(
     assert all(k[1] == 11 for k in hip_ops._workspaces)
     fresh, _ = hip_ops._workspace(cpu, 1, 100)                       # the handle comes round again: a NEW zero-filled buffer
     assert fresh != ptr22 and int(hip_ops._workspaces[(0, 22, 1, 100)].sum()) == 0
+
+
+def test_in_flight_defaults_and_cpu_lanes(monkeypatch):
+    """evaluation._Lanes on a CPU device is a pass-through (the 2-rank gloo tests run the loop there); two batches in
+    flight is the default only for attacks whose inner loop replays from a graph, on a HIP device, without a callback."""
+    from audio_deepfake_adversarial_attacks_amd import evaluation
+    lanes = evaluation._Lanes("cpu", 2)
+    assert lanes.n == 1
+    with lanes.batch(0, (4, 10)) as lane:
+        assert lane == 0
+    lanes.keep(torch.zeros(1))
+    lanes.join()
+    pgd = torchattacks.PGD(Surrogate(), steps=4)
+    cw = torchattacks.CW(Surrogate(), steps=4)
+    monkeypatch.delenv("ADVSTEP_IN_FLIGHT", raising=False)
+    monkeypatch.delenv("ADVSTEP_ATTACK_GRAPH", raising=False)
+    assert evaluation.default_in_flight(pgd, "cuda:0", False) == 2
+    assert evaluation.default_in_flight(pgd, "cuda:0", True) == 1          # the analyser's callback reads every batch back
+    assert evaluation.default_in_flight(pgd, "cpu", False) == 1
+    assert evaluation.default_in_flight(cw, "cuda:0", False) == 1          # host-driven loop
+    assert evaluation.default_in_flight(None, "cuda:0", False) == 1
+    monkeypatch.setenv("ADVSTEP_ATTACK_GRAPH", "0")
+    assert evaluation.default_in_flight(pgd, "cuda:0", False) == 1         # eager launches keep the host busy: nothing to overlap
+    monkeypatch.setenv("ADVSTEP_IN_FLIGHT", "3")
+    assert evaluation.default_in_flight(cw, "cuda:0", True) == 3
