@@ -34,6 +34,7 @@ _profile_work: Dict[str, List[float]] = {}      # per bracketed launch: the arit
 _profile_bytes: Dict[str, List[float]] = {}     # per bracketed launch: the bytes of the operands the caller named, or 0
 _profile_all = False                            # start_profile("*"): every entry point
 _profile_graph_ok = False                       # start_profile(..., graph_ok=True): only launches OUTSIDE captured graphs matter
+_launch_depth = 0                               # > 0 while a bracketed launch is being issued (bench.py's library-op brackets skip what is inside)
 
 
 def _require(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
@@ -121,6 +122,8 @@ class _Launch:
         self.guard = torch.cuda.device(device)
 
     def __enter__(self):
+        global _launch_depth
+        _launch_depth += 1
         self.guard.__enter__()
         self.pair = None
         if (_profile is not None and (_profile_all or self.name in _profile)
@@ -130,6 +133,8 @@ class _Launch:
         return self
 
     def __exit__(self, *exc):
+        global _launch_depth
+        _launch_depth -= 1
         if self.pair is not None:
             self.pair[1].record(torch.cuda.current_stream(self.device))
             _profile.setdefault(self.name, []).append(self.pair)

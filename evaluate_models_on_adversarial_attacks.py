@@ -68,6 +68,9 @@ def parse_arguments(argv=None):
                              "trims silence, base_dataset.py:29-33); without this flag a SoX backend must be importable "
                              "(datasets/backends.py)")
     parser.add_argument("--num_workers", type=int, default=3, help="DataLoader workers (reference :202: 3)")
+    parser.add_argument("--in_flight", type=int, default=None, metavar="N",
+                        help="batches processed concurrently, each on a stream of its own (default: 2 for the attacks whose "
+                             "iteration replays from a hipGraph - PGD, PGDL2 -, else 1; same scores either way)")
     parser.add_argument("--share_weights", default=False, action="store_true",
                         help="copy the target model's weights into the attack model (white-box, no checkpoints)")
     return parser.parse_args(argv)
@@ -125,6 +128,7 @@ def main(args):
         share_weights=args.share_weights,
         wave_fake_trim=False if args.no_trim else None,
         num_workers=args.num_workers,
+        in_flight=args.in_flight,
     )
     if world > 1:
         dist.destroy_process_group()

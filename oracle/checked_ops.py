@@ -249,6 +249,7 @@ class TracingOps:
         self.steps = []          # (adv_in, grad, cost (1,), z (B, 1)) per update launch
         self.cw_l2 = []          # (B,) per CW iteration
         self.cw_adv = []         # (B, T) per CW iteration: 1/2 (tanh w + 1)
+        self.cw_mask = []        # (B,) per CW iteration: the rows whose iterate the best-so-far blend took (cw.py:94-103)
         self._pending = None
 
     def __getattr__(self, name):
@@ -275,6 +276,10 @@ class TracingOps:
     def fgsm_step(self, x, grad, *args, **kwargs):
         self._note(x, grad)
         return self.ops.fgsm_step(x, grad, *args, **kwargs)
+
+    def cw_best_update(self, adv, mask, best):
+        self.cw_mask.append(mask.detach().clone())
+        return self.ops.cw_best_update(adv, mask, best)
 
     def cw_tanh_sqdist(self, w, x, adv_out=None):
         adv, l2 = self.ops.cw_tanh_sqdist(w, x, adv_out=adv_out)

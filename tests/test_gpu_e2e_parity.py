@@ -194,6 +194,105 @@ def test_pgdl2_40_at_full_batch_on_specrnet_with_sampled_oracle_checks(cuda, hip
                                                            "l2_norm_max": norms.max().item(), "l2_norm_min": norms.min().item()}
 
 
+def test_cw_on_rawnet3_where_the_blend_takes_iterates_matches_cpu_oracle(cuda, hip, parity_record):
+    """VERDICT r05, What's missing 4: in every configs[3] run CW stops after 11 iterations without fooling RawNet3 on a row
+    it classified correctly, so the best-so-far blend (cw.py:94-103) only ever took iteration 0 (where adv == x) - on a
+    real detector the masked blend was covered by the surrogate fixture alone.  Here the attack SUCCEEDS: c = 1e4 makes the
+    model term outweigh the distances (the seeded RawNet3 emits z ~ +0.02 for every row, so the rows labelled 1 need z < 0),
+    steps = 20 compares the cost every 2 iterations.  WHICH iterate the blend takes is as chaotic as the trajectory (Adam turns
+    rounding-level gradient entries into +-lr moves): the CPU oracle on 8 threads flips rows 2 / 3 at iterations 9 / 9 and stops
+    after 11, started one ulp away at 8 / 10, on the GPU box's 16 threads at 9 / 7; the product at 7 / 10, stopping after 13.
+      * free-running, product vs oracle: the same rows are taken, the taken iterates fool the attacked model on both sides,
+        within a few iterations of each other (squared distances grow by ~2 per iteration) - the oracle's own spread;
+      * teacher-forced: the product's blend kernel driven along the ORACLE's trajectory (its iterates, distances and
+        logits, from the trace) reproduces the oracle's best adversarials and best distances bit for bit."""
+    import copy
+    from audio_deepfake_adversarial_attacks_amd import torchattacks
+    from oracle import attacks as OA
+    from oracle.checked_ops import TracingOps
+    raw = _model("rawnet3", {}, cuda)
+    x, y = _batch(4, 31)
+    hyper = dict(c=1e4, kappa=0, steps=20, lr=0.01)
+    model_cpu = copy.deepcopy(raw).cpu()
+    x01, _, _ = OA.to_minmax(x)
+    trace = []
+    with E.cpu_threads(16), OA.attack_mode(model_cpu):
+        want01 = OA.cw(model_cpu, x01, y, trace=trace, **hyper)
+
+    # the oracle's blend history from its trace: cw.py:94-103 restated on (l2, z) per iteration
+    best_l2 = 1e10 * torch.ones(len(x01))
+    best = x01.clone()
+    took = []
+    for _, l2, z, adv in trace:
+        correct = ((z > 0).long() == y).float()          # argmax of (-z, z) is 1 iff z > 0 (ties -> index 0, as torch.max)
+        mask = (1 - correct) * (best_l2 > l2).float()
+        best_l2 = mask * l2 + (1 - mask) * best_l2
+        best = mask.view(-1, 1) * adv + (1 - mask.view(-1, 1)) * best
+        took.append(mask.clone())
+    assert torch.equal(best, want01)                     # the restatement IS the oracle's blend
+    changed_oracle = ((want01 - x01).abs().amax(1) > 1e-6)
+    assert changed_oracle.tolist() == [False, False, True, True], "the oracle run of this test no longer flips rows 2 and 3"
+
+    # product, free-running
+    tops = TracingOps(hip)
+    atk = E.armed(torchattacks.CW(raw, **hyper), tops)
+    xg, yg = x.to(cuda), y.to(cuda)
+    g01, _, _ = hip.to_minmax(xg)
+    got01 = atk(g01, yg)
+    got = got01.cpu()
+    changed_product = ((got - x01).abs().amax(1) > 1e-6)
+    first_oracle = [int(torch.stack(took)[:, r].argmax()) if torch.stack(took)[:, r].any() else -1 for r in range(4)]
+    pm = torch.stack([m.cpu() for m in tops.cw_mask])
+    last_product = [int(pm[:, r].nonzero().max()) if pm[:, r].any() else -1 for r in range(4)]
+    last_oracle = [int(torch.stack(took)[:, r].nonzero().max()) if torch.stack(took)[:, r].any() else -1 for r in range(4)]
+    l2_product = ((got - x01) ** 2).sum(1)
+    l2_oracle = ((want01 - x01) ** 2).sum(1)
+    with torch.no_grad(), OA.attack_mode(model_cpu):
+        z_oracle_best = model_cpu(want01).view(-1)
+    raw.train()
+    for mod in raw.modules():
+        if "BatchNorm" in mod.__class__.__name__ or "Dropout" in mod.__class__.__name__:
+            mod.eval()
+    with torch.no_grad():
+        z_product_best = raw(got01).view(-1).cpu()
+    raw.eval()
+    fig = {"hyper": hyper, "iterations_product": len(tops.cw_l2), "iterations_oracle": len(trace),
+           "rows_changed_product": changed_product.tolist(), "rows_changed_oracle": changed_oracle.tolist(),
+           "first_taken_iteration_oracle": first_oracle, "last_taken_iteration_oracle": last_oracle,
+           "last_taken_iteration_product": last_product,
+           "best_l2_product": l2_product.tolist(), "best_l2_oracle": l2_oracle.tolist(),
+           "logit_of_best_product": z_product_best.tolist(), "logit_of_best_oracle": z_oracle_best.tolist(),
+           "blended_rows_max_abs": (got - want01).abs().amax(1).tolist(),
+           "oracle_spread_note": "the CPU oracle itself: 8 threads takes rows 2 / 3 at iterations 9 / 9 (squared distances 17.4 / "
+                                 "17.8), started one ulp away at 8 / 10 (15.6 / 19.6), 16 threads on the GPU box's host at 9 / 7"}
+    parity_record["configs3_cw_rows_that_flip_rawnet3_gpu_vs_cpu_oracle"] = fig
+    assert changed_product.tolist() == changed_oracle.tolist(), fig
+    assert abs(fig["iterations_product"] - fig["iterations_oracle"]) <= 4, fig       # two cost checks (every 2 iterations) apart at most
+    for r in (2, 3):
+        # the taken iterate fools the attacked model (label 1 needs z > 0 to be classified correctly) on both sides
+        assert z_product_best[r] <= 0 and z_oracle_best[r] <= 0, fig
+        # taken within a few iterations of the oracle's (measured 2 and 3; the oracle against itself: 1 and 2), at a squared
+        # distance that follows the iteration count (measured 22 % and 42 % apart)
+        assert abs(last_product[r] - last_oracle[r]) <= 5, fig
+        assert abs(l2_product[r] - l2_oracle[r]).item() <= 0.6 * l2_oracle[r].item(), fig
+        assert 5.0 <= l2_product[r].item() <= 30.0, fig
+    assert got.min() >= 0 and got.max() <= 1
+    # rows the model misclassifies from the start are taken at iteration 0 only (distance ~ 0): unchanged on both sides
+    assert pm[0, :2].tolist() == [1.0, 1.0] and pm[1:, :2].sum().item() == 0, fig
+
+    # teacher-forced: the product's blend kernel along the oracle's trajectory
+    best_d = x01.clone().to(cuda)
+    best_l2_d = 1e10 * torch.ones(len(x01), device=cuda)
+    for (_, l2, z, adv), mask_o in zip(trace, took):
+        l2d, zd = l2.to(cuda), z.to(cuda)
+        correct = ((zd > 0).long() == yg).float()
+        mask = (1 - correct) * (best_l2_d > l2d).float()
+        assert torch.equal(mask.cpu(), mask_o)
+        best_l2_d = mask * l2d + (1 - mask) * best_l2_d
+        hip.cw_best_update(adv.to(cuda).contiguous(), mask.contiguous(), best_d)
+    assert torch.equal(best_d.cpu(), want01) and torch.equal(best_l2_d.cpu(), best_l2)
+
+
 def test_fgsm_and_cw_at_full_batch_rawnet3_to_lcnn_with_sampled_oracle_checks(cuda, hip, lcnn, parity_record):
     """configs[3] at full size: attack model RawNet3, target LCNN + LFCC, B = 64; FGSM (AttackEnum.FGSM: eps 0.0005) and CW
     (AttackEnum.CW: c 1, 100 steps, lr 0.01, early stop on) with every 10th launch of every kernel re-computed by the C
