@@ -839,8 +839,13 @@ int launch_wino(const float *x, const uint8_t *xsel, const float *U, const float
     const int64_t groups = ceil_div(N * ((H + 1) / 2) * ((W + 1) / 2), 16);
     const size_t lds = (size_t)(stream ? (SRC == 1 ? 4 : 2) : chunks) * kChunkFloats * sizeof(float);
     const bool wodd = SRC == 0 && (W & 1);
+    // ADVSTEP_WINO_RANGE_MULT=k (read per call, default 1): k times the workgroups, each walking 1 / k of the tile groups - a
+    // grid that is NOT persistent, so that workgroups of another stream's launch find compute units while this one runs (round 6
+    // experiment; the weights are staged once per workgroup, i.e. k times as often)
+    const char *em = getenv("ADVSTEP_WINO_RANGE_MULT");
+    const int mult = em && em[0] >= '1' && em[0] <= '8' ? em[0] - '0' : 1;
     auto go = [&](auto kernel, int n_slices, int slice0) {
-        int ranges = cus / n_slices;
+        int ranges = mult * cus / n_slices;
         if ((int64_t)ranges * kWaves > groups) ranges = (int)ceil_div(groups, kWaves);
         if (ranges < 1) ranges = 1;
         // the slices of one tile range read the same input tiles at the same time: put them on ONE XCD (workgroups b, b + 8, ...

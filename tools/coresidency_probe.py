@@ -20,6 +20,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--reps", type=int, default=40)
+    ap.add_argument("--only-wino", action="store_true", help="just the pairs with a Winograd kernel (ADVSTEP_WINO_RANGE_MULT A/B)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = _lib.load()
@@ -115,6 +116,8 @@ def main():
                    ("lstm_forward", "wino_L6_forward"), ("lstm_backward", "wino_L6_backward"), ("lstm_forward", "conv1x1_L3_forward"),
                    ("lstm_forward", "conv5_forward"), ("wino_L6_forward", "wino_L6_forward_2"), ("wino_L6_forward", "conv1x1_L3_forward"),
                    ("wino_L6_forward", "conv5_forward"), ("conv5_forward", "conv1x1_L3_forward"), ("lstm_forward", "lstm_backward")):
+        if a.only_wino and "wino" not in na + nb:
+            continue
         # equal total work on both streams: launch counts in inverse proportion to the solo durations
         ta, tb = solo[na], solo[nb]
         ra = a.reps
