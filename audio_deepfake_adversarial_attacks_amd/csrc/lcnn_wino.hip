@@ -868,7 +868,10 @@ int launch_wino(const float *x, const uint8_t *xsel, const float *U, const float
     int full = slices;
     if constexpr (EPI == 0 || EPI == 3 || EPI == 5 || EPI == 6) {
         const int live_last = (int)(Cout - (int64_t)(slices - 1) * 32);
-        if (live_last <= 16 && half_slice_enabled()) {
+#ifndef WINO_TIMING_NT1          // timing-only builds (tools/build_variant.sh ... -DWINO_TIMING_NT1=1): the last slice ALWAYS as one
+#define WINO_TIMING_NT1 0       // accumulator tile, i.e. rows 16..31 of a 17..32-row slice dropped (wrong results) - what SpecRNet's
+#endif                          // 20-row layers would cost if their 12 dead rows were free
+        if ((live_last <= 16 || WINO_TIMING_NT1) && half_slice_enabled()) {
             full = slices - 1;
             if (stream) wodd ? go(wino3x3_kernel<EPI, true, SRC, 1, GEN, SRC == 0>, 1, slices - 1) : go(wino3x3_kernel<EPI, true, SRC, 1, GEN>, 1, slices - 1);
             else wodd ? go(wino3x3_kernel<EPI, false, SRC, 1, GEN, SRC == 0>, 1, slices - 1) : go(wino3x3_kernel<EPI, false, SRC, 1, GEN>, 1, slices - 1);
